@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark: restored frames/s of the Shift-Net deblur hot path on MI355X (BASELINE.json configs[1]).
+
+One "step" = one clip window per GPU: Shift-Net-s (gshift_deblur2), 1280x720, one_len = 16 restored frames from
+T_in = 20 input frames, bf16 storage / fp32 accumulation, synthetic GoPro-shaped frames and a synthetic checkpoint
+(no datasets or weights ship with the reference).  The frames a rank owns are resident in HBM when the timed region
+starts; a step is  [halo exchange (N>1 only)] -> GShiftNet.forward -> restored frames in HBM.
+
+N > 1: launched by torch.distributed.run, one rank per GPU; windows are independent (weak scaling), the only
+communication is the all-gather of the 2+2 halo frames (shiftnet_amd/clip_parallel.py).
+
+Prints ONE JSON line on rank 0 (see the repository prompt / DESIGN.md "Measurement" for the field definitions).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "shift-net_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
+VARIANT = "gshift_deblur2"
+H, W, ONE_LEN = 720, 1280, 16
+# elements per full-res pixel: stage0+stage1 per INPUT frame, stage2 per OUTPUT frame (Shift-Net-s)
+E_IN, E_OUT = 765.2 + 2180.0, 765.2
+
+
+def algorithmic_bytes_window(h, w, t_in, t_out, s=2):
+    return h * w * s * (t_in * E_IN + t_out * E_OUT)
+
+
+def kernel_alg_bytes(fn, meta):
+    """Minimal HBM bytes of ONE launch given its interface (each distinct input read once, output written once)."""
+    if meta and meta[0] == "naf":
+        _, T, h, w, c, mode = meta
+        px = T * h * w * 2
+        return {"sn_gsts_shiftconv": px * c, "sn_ln_gemm": px * (3.5 * c if mode else 3 * c), "sn_dw_gate": px * 3 * c,
+                "sn_dw_gemm_gate": px * 2 * c, "sn_scale_gemm_res": px * 3 * c}.get(fn, 0)
+    if meta and meta[0] == "conv":
+        _, T, ho, wo, cin, cs_out, k, stride, in_mode, out_mode = meta
+        pin = T * ho * wo * stride * stride / (4 if in_mode == 1 else 1)
+        return 2 * (pin * cin + T * ho * wo * cs_out)
+    if meta and meta[0] == "ew":
+        _, T, h, w, cs = meta
+        return 2 * 3 * T * h * w * cs
+    return 0
+
+
+def cpu_baseline(budget_s=20.0):
+    """The CPU oracle (a port of the reference forward, kind 'port') timed on this host's cores on a bounded sample."""
+    from oracle import shiftnet_oracle as O
+    from shiftnet_amd import synth
+    from shiftnet_amd.weights import synth_state_dict
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synth_state_dict(VARIANT)
+    V = O.VARIANTS[VARIANT]
+
+    def run(t_in, h, w):
+        blur, _ = synth.blurred_clip(t_in, h, w, seed=2)
+        x = O.frames_to_tensor(list(blur))
+        t0 = time.time()
+        with torch.no_grad():
+            O.forward(V, sd, x, None, 2, 2)
+        return time.time() - t0
+    run(5, 64, 64)                                   # warm up the thread pool / mkldnn primitives
+    probe = run(5, 128, 128)
+    per_pxf = probe / (5 * 128 * 128)
+    side = int(min(720, max(128, (budget_s / per_pxf / 5) ** 0.5)) // 8 * 8)
+    hh, ww = side, min(1280, side * 16 // 9 // 8 * 8)
+    dt = run(5, hh, ww)
+    per_pxf = dt / (5 * hh * ww)
+    fps = ONE_LEN / ((ONE_LEN + 4) * H * W * per_pxf)
+    return {"value": fps, "unit": "restored frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 forward of {VARIANT} on T_in=5 {ww}x{hh} ({dt:.1f} s), cost/pixel/frame extrapolated "
+                      f"linearly to T_in=20 1280x720 (torch {torch.__version__}, {cores} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--height", type=int, default=H)
+    ap.add_argument("--width", type=int, default=W)
+    ap.add_argument("--one-len", type=int, default=ONE_LEN)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from basicsr.models.archs.gshift_deblur2 import GShiftNet
+    from shiftnet_amd import synth
+    from shiftnet_amd.clip_parallel import assemble_window
+    from shiftnet_amd.weights import synth_state_dict
+
+    h, w, L = args.height, args.width, args.one_len
+    net = GShiftNet(future_frames=2, past_frames=2)
+    net.load_state_dict(synth_state_dict(VARIANT), strict=True)
+    net = net.to(torch.bfloat16).to(dev).eval()
+
+    # this rank's slice of one long synthetic clip: L owned frames (+ the clip edges on the first / last rank)
+    blur, _ = synth.blurred_clip(L + 4, h, w, seed=100 + rank)
+    fr = (torch.from_numpy(blur).permute(0, 3, 1, 2).to(dev).to(torch.bfloat16) / 255).contiguous()
+    own, first_edge, last_edge = fr[2:2 + L].contiguous(), fr[:2].contiguous(), fr[-2:].contiguous()
+
+    def step():
+        win = assemble_window(own, first_edge, last_edge, rank, world)
+        return net(win.unsqueeze(0))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    assert out.shape == (L, 3, h, w) and torch.isfinite(out.float()).all()
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+
+    result = None
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        fps = world * L * args.steps / elapsed
+        # ---- per-kernel durations, live, from events on the launch stream (one extra, untimed step) -----------
+        eng = net.prepare()
+        eng.prof = []
+        with torch.no_grad():
+            step()
+        torch.cuda.synchronize()
+        agg = {}
+        unit_ms = 0.0
+        unit_bytes = 0.0
+        for fn, label, meta, e0, e1 in eng.prof:
+            a = agg.setdefault(fn, {"ms": 0.0, "n": 0, "bytes": 0.0})
+            d = e0.elapsed_time(e1)
+            a["ms"] += d; a["n"] += 1; a["bytes"] += kernel_alg_bytes(fn, meta)
+            if meta and meta[0] == "naf":
+                unit_ms += d
+                if fn == "sn_scale_gemm_res":            # one CAB finished: its fused-unit bytes = read x + write y
+                    unit_bytes += 2 * meta[1] * meta[2] * meta[3] * meta[4] * 2
+        eng.prof = None
+        dom = max(agg, key=lambda k: agg[k]["ms"])
+        ach = agg[dom]["bytes"] / (agg[dom]["ms"] * 1e-3) / 1e9
+        kernels = {k: {"ms_total": round(v["ms"], 3), "launches": v["n"],
+                       "gbps_algorithmic": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)} for k, v in agg.items()}
+        win_bytes = algorithmic_bytes_window(h, w, L + 4, L)
+        result = {
+            "metric": "restored frames/sec at 1280x720 T=16 bf16", "value": round(fps, 3), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Shift-Net-s (gshift_deblur2) deblur, {w}x{h}, one_len={L} (T_in={L + 4}), "
+                                   "one window per GPU, synthetic checkpoint", "parallelism": f"clip-parallel x{world}"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "avg_launch_ms": round(agg[dom]["ms"] / agg[dom]["n"], 4), "launches": agg[dom]["n"]},
+            "gsts_unit_roofline": {"achieved": round(unit_bytes / max(unit_ms, 1e-9) / 1e6, 1), "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": round(unit_bytes / max(unit_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
+                                   "note": "SURVEY 8(d) fused-unit bytes (read x + write y per CAB2/CAB1) / time of all GSTS kernels"},
+            "whole_net_roofline": {"achieved": round(win_bytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(win_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,131 @@
+/* shiftnet_hip.h -- C ABI of libshiftnet_hip.so: the MI355X (gfx950) kernels behind GShiftNet.forward.
+ *
+ * The reference has no native code and no FFI: its "operators" are the ATen calls made by
+ * basicsr/models/archs/gshift_{deblur,denoise}{1,2}.py.  This header is the boundary a maintainer binds instead
+ * (ctypes stub: INTEGRATION.md).  Each entry point names the reference expression it replaces.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless said otherwise; the caller owns every buffer (outputs and workspaces
+ *     included), the library never allocates or frees and keeps no global mutable state (thread compatible);
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*) and returns immediately;
+ *   - return 0 on success, negative errno-style code otherwise (-22 bad argument, -5 launch failure); nothing throws;
+ *   - activations: NHWC bf16 [T][H][W][Cs], Cs a multiple of 8, pad channels must be (and are kept) zero;
+ *   - "wfrag" arguments are weights prepacked by the host into MFMA A-fragment order (shiftnet_amd/prep.py):
+ *     bf16 [MT][KS][64 lanes][8], see csrc/sn_common.h for the lane/slot convention.
+ */
+#ifndef SHIFTNET_HIP_H
+#define SHIFTNET_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SN_ABI_VERSION 1
+
+/* element types of NCHW tensors exchanged with the PyTorch side */
+#define SN_F32 0
+#define SN_F16 1
+#define SN_BF16 2
+
+int sn_abi_version(void);
+
+/* MFMA lane-layout self test: D = A.B on one 16x16x32 tile with asymmetric operands written in the slot
+ * convention of sn_common.h.  a:[16][32] f32, b:[32][16] f32 row major, d:[16][16] f32 out (all device). */
+int sn_selftest_mfma(const float* a, const float* b, float* d, void* stream);
+
+/* x = x[0]; torch.cat((x, noise_map), 1) and the implicit NCHW->kernel layout change
+ * (gshift_deblur1.py:784-787, gshift_denoise1.py:828-831).  src:[T][C][H][W] of `src_dtype`, noise:[T][1][H][W]
+ * or NULL, dst:[T][H][W][8] bf16 (channels C(+1)..7 zeroed). */
+int sn_ingest(const void* src, int src_dtype, const void* noise, void* dst, int T, int C, int H, int W, void* stream);
+
+/* One dense nn.Conv2d (+ what the reference applies around it), as an implicit GEMM on MFMA. */
+typedef struct sn_conv_desc {
+    const void* in[3];   /* 1..3 NHWC inputs of equal shape, concatenated along channels (torch.cat(...,1)):
+                            rconcat gshift_deblur1.py:772, conv_hr0 :640 */
+    int n_in;
+    int cs_in;           /* storage channels of each input */
+    int T, h_in, w_in;   /* spatial size the convolution sees */
+    int in_mode;         /* 0: as is; 1: inputs are [T][h_in/2][w_in/2] and are bilinearly upsampled x2,
+                            align_corners=False, while staging (SkipUpSample.up[0], gshift_deblur1.py:344) */
+    int k, stride, pad;  /* k in {1,2,3,5}; Conv2d zero padding */
+    int h_out, w_out;
+    const void* wfrag;   /* [MT][KS][64][8] bf16 */
+    int mt, ks;
+    const float* bias;   /* [16*mt] natural channel order, zero padded; NULL = no bias */
+    int act;             /* 0 none, 1 PReLU with the single shared slope `prelu` (nn.PReLU(), :551,576) */
+    float prelu;
+    const void* res;     /* NHWC [T][h_out][w_out][cs_out] added after the activation, or NULL
+                            ("x = self.up(x); x = x + y" :348-349, "+ self.skip_conv(shortcut)" gshift_deblur2.py:611) */
+    void* out;
+    int cs_out;
+    int out_mode;        /* 0: NHWC; 1: F.pixel_shuffle(.,2) store -> [T][2h][2w][cs_out] (PixelShufflePack :277);
+                            2: NCHW [T][c_out][h][w] of `nchw_dtype` plus the NCHW shortcut `sc`
+                               ("return output_features + shortcut[...]" :791) */
+    int c_out;           /* logical out channels (mode 2 only) */
+    int nchw_dtype;
+    const void* sc;      /* mode 2: NCHW tensor of nchw_dtype, same shape as out */
+    float* pool;         /* NULL or [T][gridDim.y*gridDim.x][16*mt] f32 per-workgroup channel sums of the output
+                            (first half of AdaptiveAvgPool2d(1), CALayer :69); see sn_conv_pool_blocks */
+} sn_conv_desc;
+int sn_conv2d(const sn_conv_desc* d, void* stream);   /* d is a HOST pointer, read during the call */
+/* number of workgroups per frame sn_conv2d launches for this output size (= rows of `pool` per frame) */
+int sn_conv_pool_blocks(int h_out, int w_out, int stride);
+
+/* CALayer / CALayer2 squeeze-excite: mean -> 1x1 -> ReLU -> 1x1 -> sigmoid (gshift_deblur1.py:61-70,84-87).
+ * partial:[T][nblk][cpad] f32 sums, wa:[cr][c], wb:[c][cr] f32, ca:[T][cpad] f32 out (pad entries 0). */
+int sn_ca_mlp(const float* partial, int nblk, int cpad, int c, int cr, float inv_hw,
+              const float* wa, const float* wb, float* ca, int T, void* stream);
+
+/* CAB tail "res = self.CA(res); res += x" (gshift_deblur1.py:155-157): out = res * ca[t][c] + x. */
+int sn_scale_residual(const void* res, const void* x, const float* ca, int cpad, void* out,
+                      int T, int hw, int cs, void* stream);
+
+/* ---- grouped spatial-temporal shift unit: channel_shift -> CAB2 -> CAB1 (gshift_deblur1.py:504-547) ---- */
+typedef struct sn_unit_src {
+    const void* x;       /* [T][h][w][C] the unit's input */
+    int T, h, w, C;      /* C in {64, 80} */
+    int mode;            /* 0: CAB1 (no shift, u = x[t]); 1: CAB2 of a forward unit; 2: CAB2 of a reverse unit */
+    int wrap;            /* 1: circular temporal roll (gshift_deblur2.py:504-505); 0: boundary frame kept (:513,517) */
+} sn_unit_src;
+
+/* validation op: materialise u = cat(y, spatial_shift2(hw)) : [T][h][w][3C/2] exactly as channel_shift returns it
+ * (gshift_deblur1.py:504-528).  offs: int8 [C/2][2] (dy,dx) of the source pixel.  Pure index work: bit exact. */
+int sn_gsts_gather(const sn_unit_src* s, const int8_t* offs, void* u, void* stream);
+
+/* y = channel_shift(x) of Shift_CAB (gshift_denoise1.py:167-179): the temporal half-channel roll alone, materialised
+ * (the 24-/80-channel Shift_CAB encoders feed a dense 3x3 CAB, which reads y as an ordinary tensor).
+ * C any even channel count whose halves are whole elements; mode 1 forward / 2 reverse. */
+int sn_temporal_roll(const sn_unit_src* s, void* y, void* stream);
+
+/* hw = CAB2.conv1(spatial_shift2(borrowed half)) (gshift_deblur1.py:470-503,223,251): depthwise 3x3 of the
+ * zero-padded displaced neighbour-frame channels, never materialising the shifted tensor.  w1:[C/2][9] f32. */
+int sn_gsts_shiftconv(const sn_unit_src* s, const int8_t* offs, const float* w1, void* hw, void* stream);
+
+/* a = body[0](norm(cat(shortcut, hw))): LayerNorm2d over 3C/2 (CAB2) or C (CAB1) channels, eps 1e-6, affine folded
+ * into the 1x1 weights, then the 1x1 conv to 2C (gshift_deblur1.py:19-28,190,225,252).  a:[T][h][w][2C] in
+ * "gate-paired" position order (prep.py).  hw may be NULL for mode 0. */
+int sn_ln_gemm(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, void* a, void* stream);
+
+/* g1 = SimpleGate(RepConv2(a)) (gshift_deblur1.py:166-178): (a1 + dw3x3(a1)) * (a2 + dw3x3(a2)); w:[9][2C] f32 in
+ * a's position order with the identity folded into the centre tap.  g1:[T][h][w][C] natural order.
+ * pool: NULL, or [T][sn_dwgate_blocks][C] per-workgroup sums of g1 (denoise CALayer2, gshift_denoise1.py:224). */
+int sn_dw_gate(const void* a, const float* w, void* g1, float* pool, int T, int h, int w_, int C, void* stream);
+int sn_dwgate_blocks(int h, int w);
+
+/* g2 = SimpleGate2(body[4](RepConv(g1))) (gshift_deblur2.py:159-168,182-185,201): depthwise 5x5 + 3x3 + identity
+ * (folded into one 5x5, w5:[25][C] f32), 1x1 C->2C on MFMA, x1*sigmoid(x2); plus per-workgroup channel sums for
+ * the CALayer2 that follows.  ca_in: NULL or [T][C] f32 scale applied to g1 first (denoise).  g2:[T][h][w][C]. */
+int sn_dw_gemm_gate(const void* g1, const float* ca_in, const float* w5, const void* wfrag, void* g2, float* pool,
+                    int T, int h, int w, int C, void* stream);
+int sn_dwgemm_blocks(int h, int w);
+
+/* y = shortcut + beta * body[7](ca * g2) (gshift_deblur1.py:201,210,254): beta and the optional bias are folded
+ * into wfrag/bias; the shortcut is the ROLLED tensor for CAB2 (mode 1/2) and x for CAB1 (mode 0). */
+int sn_scale_gemm_res(const sn_unit_src* s, const void* g2, const float* ca, const void* wfrag, const float* bias,
+                      void* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

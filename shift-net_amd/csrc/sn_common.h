@@ -1,0 +1,64 @@
+// Shared device helpers for the Shift-Net gfx950 kernels (CDNA4, wave64).
+//
+// Conventions used by every kernel in this directory
+//   * activations live in HBM as NHWC bf16: [T][H][W][Cs], Cs a multiple of 8 (16 B), pad channels are zero;
+//   * every 1x1 / dense conv is an MFMA GEMM with the WEIGHTS as the A operand (M = out channels) and the
+//     ACTIVATIONS as the B operand (N = 16 pixels): v_mfma_f32_16x16x32_bf16.  For that instruction
+//       A: lane l holds A[m = l&15][k-slot (l>>4, j)], j = 0..7      (8 bf16 = 16 B)
+//       B: lane l holds B[k-slot (l>>4, j)][n = l&15]
+//       D: lane l, reg r holds D[m = (l>>4)*4 + r][n = l&15]
+//     The hardware pairs A's slot (g, j) with B's slot (g, j); which logical k a slot means is OUR choice, so
+//     a lane's B operand is simply 8 consecutive channels (16 B) of "its" pixel, straight from NHWC memory.
+//   * the host prepacks weights into A-fragment order [mt][ks][lane][8] (shiftnet_amd/prep.py), including any
+//     row permutation that makes a lane's D registers contiguous channels, so kernels never shuffle channels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef uint16_t bf16_t;  // storage type
+
+#define SN_OK 0
+#define SN_EINVAL (-22)
+#define SN_ELAUNCH (-5)
+
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ float bf_to_f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// round-to-nearest-even fp32 -> bf16 pair (v_cvt_pk_bf16_f32 on gfx950); lo goes to bits 0..15
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    f32x2_t v = {lo, hi};
+    bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ bf16_t f_to_bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
+
+__device__ __forceinline__ void unpack8(const uint4 q, float* v) {
+    v[0] = bf_lo(q.x); v[1] = bf_hi(q.x); v[2] = bf_lo(q.y); v[3] = bf_hi(q.y);
+    v[4] = bf_lo(q.z); v[5] = bf_hi(q.z); v[6] = bf_lo(q.w); v[7] = bf_hi(q.w);
+}
+__device__ __forceinline__ uint4 pack8(const float* v) {
+    uint4 q;
+    q.x = pack_bf2(v[0], v[1]); q.y = pack_bf2(v[2], v[3]); q.z = pack_bf2(v[4], v[5]); q.w = pack_bf2(v[6], v[7]);
+    return q;
+}
+__device__ __forceinline__ bf16x8_t as_frag(const uint4 q) { return __builtin_bit_cast(bf16x8_t, q); }
+
+__device__ __forceinline__ f32x4_t mfma16(const bf16x8_t a, const bf16x8_t b, const f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// wave-uniform wave index (threadIdx-derived values are "divergent" to the compiler; make it provably uniform)
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+static inline int sn_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SN_OK : SN_ELAUNCH;
+}

@@ -1,0 +1,356 @@
+// Dense convolutions of the Shift-Net encoder-decoder as implicit GEMMs on MFMA, plus the small kernels around
+// them (ingest, channel-attention MLP, CAB tail).  gfx950 only.
+//
+// sn_conv2d: one workgroup (4 waves) owns a TH x TW output tile of one frame.
+//   1. the input patch ((TH-1)*stride+k) x ((TW-1)*stride+k) x Cv is staged in LDS as [pixel][Cv] bf16 with the
+//      pixel stride padded to an odd multiple of 16 B (conflict-free ds_read_b128 for 16 consecutive pixels);
+//      up to three NHWC inputs are interleaved per pixel (torch.cat along channels is never materialised) and the
+//      bilinear x2 upsampling of SkipUpSample is done by the loader;
+//   2. K = k*k*Cv is walked in steps of 32: a lane's B operand is 8 consecutive channels of one tap of its pixel
+//      (one ds_read_b128 at a precomputed tap offset), its A operand one 16 B load of prepacked weights;
+//   3. the epilogue works on D registers directly: the host permutes weight rows so that lane (g,p) holds channels
+//      [g*4*MT, (g+1)*4*MT) of pixel p -> contiguous NHWC stores; bias, PReLU, residual, pixel-shuffle or NCHW
+//      stores and the per-workgroup channel sums for the following CALayer are all fused here.
+#include "sn_common.h"
+#include "../../include/shiftnet_hip.h"
+
+namespace {
+
+struct ConvK {
+    const bf16_t* in0; const bf16_t* in1; const bf16_t* in2;
+    int n_in, cs, cv;
+    int hin, win, in_mode, k, stride, pad, hout, wout;
+    const uint4* wfrag; int ks;
+    const float* bias; int act; float prelu;
+    const bf16_t* res; bf16_t* out; int cs_out, out_mode, c_out, nchw_dtype;
+    const void* sc; float* pool;
+    int rh, rw, ps;
+};
+
+__device__ __forceinline__ uint4 ld_bilinear(const bf16_t* src, int t, int hs, int ws, int cs, int cb, int gy, int gx) {
+    // nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False): src = dst*0.5 - 0.25 clamped at 0
+    float sy = gy * 0.5f - 0.25f; if (sy < 0.f) sy = 0.f;
+    float sx = gx * 0.5f - 0.25f; if (sx < 0.f) sx = 0.f;
+    int y0 = (int)sy, x0 = (int)sx;
+    int y1 = min(y0 + 1, hs - 1), x1 = min(x0 + 1, ws - 1);
+    float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    const bf16_t* b = src + (size_t)t * hs * ws * cs + cb * 8;
+    float v00[8], v01[8], v10[8], v11[8], o[8];
+    unpack8(*(const uint4*)(b + ((size_t)y0 * ws + x0) * cs), v00);
+    unpack8(*(const uint4*)(b + ((size_t)y0 * ws + x1) * cs), v01);
+    unpack8(*(const uint4*)(b + ((size_t)y1 * ws + x0) * cs), v10);
+    unpack8(*(const uint4*)(b + ((size_t)y1 * ws + x1) * cs), v11);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = hy * (hx * v00[j] + lx * v01[j]) + ly * (hx * v10[j] + lx * v11[j]);
+    return pack8(o);
+}
+
+template <int MT, int TH, int TW>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NTW = (TH * TW) / 64;      // N-tiles (16 pixels) per wave
+    constexpr int XB = TW / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
+    const int g = lane >> 4, p = lane & 15;
+    const int t = blockIdx.z, oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+    const int tile_bytes = P.rh * P.rw * P.ps;
+    int* tapoff = (int*)(smem + tile_bytes);
+    float* red = (float*)(smem + tile_bytes + ((P.ks * 4 * 4 + 15) & ~15));
+
+    for (int e = tid; e < P.ks * 4; e += 256) {
+        const int kk0 = e * 8, K = P.k * P.k * P.cv;
+        int off = 0;
+        if (kk0 < K) {
+            const int tap = kk0 / P.cv, cc0 = kk0 - tap * P.cv;
+            const int dy = tap / P.k, dx = tap - dy * P.k;
+            off = (dy * P.rw + dx) * P.ps + cc0 * 2;
+        }
+        tapoff[e] = off;
+    }
+    {
+        const int nblk8 = P.cv >> 3, csb = P.cs >> 3, total = P.rh * P.rw * nblk8;
+        const int iy0 = oy0 * P.stride - P.pad, ix0 = ox0 * P.stride - P.pad;
+        for (int idx = tid; idx < total; idx += 256) {
+            const int pix = idx / nblk8, blk = idx - pix * nblk8;
+            const int ry = pix / P.rw, rx = pix - ry * P.rw;
+            const int ii = blk / csb, cb = blk - ii * csb;
+            const bf16_t* src = ii == 0 ? P.in0 : (ii == 1 ? P.in1 : P.in2);
+            const int gy = iy0 + ry, gx = ix0 + rx;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gy >= 0 && gy < P.hin && gx >= 0 && gx < P.win) {
+                if (P.in_mode == 0) v = *(const uint4*)(src + (((size_t)t * P.hin + gy) * P.win + gx) * P.cs + cb * 8);
+                else v = ld_bilinear(src, t, P.hin >> 1, P.win >> 1, P.cs, cb, gy, gx);
+            }
+            *(uint4*)(smem + pix * P.ps + blk * 16) = v;
+        }
+    }
+    __syncthreads();
+
+    f32x4_t acc[MT][NTW];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    int pixbase[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        const int nn = wv * NTW + n, row = nn / XB, xb = nn - row * XB;
+        pixbase[n] = ((row * P.stride) * P.rw + (xb * 16 + p) * P.stride) * P.ps;
+    }
+    for (int s = 0; s < P.ks; ++s) {
+        const int toff = tapoff[s * 4 + g];
+        bf16x8_t b[NTW];
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) b[n] = as_frag(*(const uint4*)(smem + pixbase[n] + toff));
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const bf16x8_t a = as_frag(P.wfrag[(m * P.ks + s) * 64 + lane]);
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) acc[m][n] = mfma16(a, b[n], acc[m][n]);
+        }
+    }
+
+    // ---------------- epilogue: lane (g,p) owns channels [g*4*MT, (g+1)*4*MT) of pixel p of each N-tile ------------
+    float psum[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) psum[m][r] = 0.f;
+
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        const int nn = wv * NTW + n, row = nn / XB, xb = nn - row * XB;
+        const int oy = oy0 + row, ox = ox0 + xb * 16 + p;
+        const bool valid = (oy < P.hout) && (ox < P.wout);
+        const size_t opix = ((size_t)t * P.hout + oy) * P.wout + ox;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int co0 = g * 4 * MT + m * 4;
+            float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
+            if (P.bias) {
+                const float4 bb = *(const float4*)(P.bias + co0);
+                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            }
+            if (P.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : v[r] * P.prelu;
+            }
+            if (P.res && valid && co0 < P.cs_out) {
+                const uint2 rr = *(const uint2*)(P.res + opix * P.cs_out + co0);
+                v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
+            }
+            if (valid) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) psum[m][r] += v[r];
+                if (P.out_mode == 0) {
+                    if (co0 < P.cs_out) {
+                        uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+                        *(uint2*)(P.out + opix * P.cs_out + co0) = o;
+                    }
+                } else if (P.out_mode == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = co0 + r, c = co >> 2, i = (co >> 1) & 1, j = co & 1;
+                        if (c < P.cs_out)
+                            P.out[(((size_t)t * 2 * P.hout + 2 * oy + i) * (2 * P.wout) + 2 * ox + j) * P.cs_out + c] = f_to_bf(v[r]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = co0 + r;
+                        if (co < P.c_out) {
+                            const size_t oi = (((size_t)t * P.c_out + co) * P.hout + oy) * P.wout + ox;
+                            if (P.nchw_dtype == SN_F32) {
+                                ((float*)P.out)[oi] = v[r] + ((const float*)P.sc)[oi];
+                            } else if (P.nchw_dtype == SN_F16) {
+                                ((__half*)P.out)[oi] = __float2half(v[r] + __half2float(((const __half*)P.sc)[oi]));
+                            } else {
+                                ((bf16_t*)P.out)[oi] = f_to_bf(v[r] + bf_to_f(((const bf16_t*)P.sc)[oi]));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (P.pool) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = psum[m][r];
+                s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+                if (p == 0) red[wv * 16 * MT + g * 4 * MT + m * 4 + r] = s;
+            }
+        __syncthreads();
+        if (tid < 16 * MT) {
+            const float s = red[tid] + red[16 * MT + tid] + red[2 * 16 * MT + tid] + red[3 * 16 * MT + tid];
+            const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
+            P.pool[((size_t)t * nblk + blk) * (16 * MT) + tid] = s;
+        }
+    }
+}
+
+template <int TH, int TW>
+int launch_conv(const ConvK& K, int mt, int T, hipStream_t st) {
+    dim3 grid((K.wout + TW - 1) / TW, (K.hout + TH - 1) / TH, T);
+    const int rh = (TH - 1) * K.stride + K.k, rw = (TW - 1) * K.stride + K.k;
+    ConvK P = K; P.rh = rh; P.rw = rw;
+    const size_t lds = (size_t)rh * rw * P.ps + ((P.ks * 16 + 15) & ~15) + 4 * 16 * mt * sizeof(float);
+    if (lds > 160 * 1024) return SN_EINVAL;
+#define SN_CONV_CASE(M) case M: \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<M, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((conv_mfma_kernel<M, TH, TW>), grid, dim3(256), lds, st, P); break;
+    switch (mt) {
+        SN_CONV_CASE(1) SN_CONV_CASE(2) SN_CONV_CASE(3) SN_CONV_CASE(4) SN_CONV_CASE(5) SN_CONV_CASE(6)
+        default: return SN_EINVAL;
+    }
+#undef SN_CONV_CASE
+    return sn_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+__global__ void ingest_kernel(const void* src, int dt, const void* noise, uint4* dst, int C, int HW) {
+    const int t = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < C; ++c) {
+        const size_t idx = ((size_t)t * C + c) * HW + i;
+        v[c] = dt == SN_F32 ? ((const float*)src)[idx] : (dt == SN_F16 ? __half2float(((const __half*)src)[idx]) : bf_to_f(((const bf16_t*)src)[idx]));
+    }
+    if (noise) {
+        const size_t idx = (size_t)t * HW + i;
+        v[C] = dt == SN_F32 ? ((const float*)noise)[idx] : (dt == SN_F16 ? __half2float(((const __half*)noise)[idx]) : bf_to_f(((const bf16_t*)noise)[idx]));
+    }
+    dst[(size_t)t * HW + i] = pack8(v);
+}
+
+__global__ __launch_bounds__(256) void ca_mlp_kernel(const float* partial, int nblk, int cpad, int c, int cr, float inv_hw,
+                                                   const float* wa, const float* wb, float* ca) {
+    __shared__ float acc[256];
+    __shared__ float mean[128];
+    __shared__ float hid[128];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int nsplit = 256 / cpad;
+    const int ch = tid % cpad, part = tid / cpad;
+    float s = 0.f;
+    if (part < nsplit) {
+        const float* pp = partial + (size_t)t * nblk * cpad + ch;
+        for (int b = part; b < nblk; b += nsplit) s += pp[(size_t)b * cpad];
+    }
+    acc[tid] = s;
+    __syncthreads();
+    if (tid < cpad) {
+        float m = 0.f;
+        for (int q = 0; q < nsplit; ++q) m += acc[q * cpad + tid];
+        mean[tid] = m * inv_hw;
+    }
+    __syncthreads();
+    if (tid < cr) {
+        float h = 0.f;
+        for (int j = 0; j < c; ++j) h += wa[tid * c + j] * mean[j];
+        hid[tid] = h > 0.f ? h : 0.f;
+    }
+    __syncthreads();
+    if (tid < cpad) {
+        float o = 0.f;
+        if (tid < c) {
+            for (int j = 0; j < cr; ++j) o += wb[tid * cr + j] * hid[j];
+            o = sigmoidf_(o);
+        }
+        ca[(size_t)t * cpad + tid] = o;
+    }
+}
+
+__global__ void scale_residual_kernel(const uint4* res, const uint4* x, const float* ca, int cpad, uint4* out, int hw, int cs8) {
+    const int t = blockIdx.y;
+    const size_t n = (size_t)hw * cs8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int cb = (int)(i % cs8);
+        float r[8], xv[8];
+        unpack8(res[(size_t)t * n + i], r);
+        unpack8(x[(size_t)t * n + i], xv);
+        const float* s = ca + (size_t)t * cpad + cb * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = r[j] * s[j] + xv[j];
+        out[(size_t)t * n + i] = pack8(r);
+    }
+}
+
+__global__ void selftest_mfma_kernel(const float* a, const float* b, float* d) {
+    const int lane = threadIdx.x, g = lane >> 4, m = lane & 15;
+    float av[8], bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        av[j] = a[m * 32 + g * 8 + j];       // A[m][k], k-slot (g,j) := k = g*8+j
+        bv[j] = b[(g * 8 + j) * 16 + m];     // B[k][n = lane&15]
+    }
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    acc = mfma16(as_frag(pack8(av)), as_frag(pack8(bv)), acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[(g * 4 + r) * 16 + m] = acc[r];   // D[row = g*4+r][col = lane&15]
+}
+
+}  // namespace
+
+extern "C" {
+
+int sn_abi_version(void) { return SN_ABI_VERSION; }
+
+int sn_selftest_mfma(const float* a, const float* b, float* d, void* stream) {
+    hipLaunchKernelGGL(selftest_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, d);
+    return sn_check_launch();
+}
+
+int sn_ingest(const void* src, int dt, const void* noise, void* dst, int T, int C, int H, int W, void* stream) {
+    if (!src || !dst || C < 1 || C + (noise ? 1 : 0) > 8 || dt < 0 || dt > 2) return SN_EINVAL;
+    const int hw = H * W;
+    hipLaunchKernelGGL(ingest_kernel, dim3((hw + 255) / 256, T), dim3(256), 0, (hipStream_t)stream, src, dt, noise, (uint4*)dst, C, hw);
+    return sn_check_launch();
+}
+
+int sn_conv_pool_blocks(int h_out, int w_out, int stride) {
+    if (stride == 1) return ((h_out + 7) / 8) * ((w_out + 31) / 32);
+    return ((h_out + 3) / 4) * ((w_out + 15) / 16);
+}
+
+int sn_conv2d(const sn_conv_desc* d, void* stream) {
+    if (!d || d->n_in < 1 || d->n_in > 3 || (d->cs_in & 7) || (d->cs_out & 7) || !d->wfrag || !d->out) return SN_EINVAL;
+    if (d->k < 1 || d->k > 5 || (d->stride != 1 && d->stride != 2) || d->mt < 1 || d->mt > 6 || d->ks < 1) return SN_EINVAL;
+    if (d->in_mode == 1 && ((d->h_in | d->w_in) & 1)) return SN_EINVAL;
+    if (d->out_mode == 2 && (!d->sc || d->c_out > 4 * d->mt)) return SN_EINVAL;
+    if (d->ks * 32 < d->k * d->k * d->n_in * d->cs_in) return SN_EINVAL;
+    ConvK K;
+    K.in0 = (const bf16_t*)d->in[0]; K.in1 = (const bf16_t*)d->in[1]; K.in2 = (const bf16_t*)d->in[2];
+    K.n_in = d->n_in; K.cs = d->cs_in; K.cv = d->n_in * d->cs_in;
+    K.hin = d->h_in; K.win = d->w_in; K.in_mode = d->in_mode; K.k = d->k; K.stride = d->stride; K.pad = d->pad;
+    K.hout = d->h_out; K.wout = d->w_out;
+    K.wfrag = (const uint4*)d->wfrag; K.ks = d->ks; K.bias = d->bias; K.act = d->act; K.prelu = d->prelu;
+    K.res = (const bf16_t*)d->res; K.out = (bf16_t*)d->out; K.cs_out = d->cs_out; K.out_mode = d->out_mode;
+    K.c_out = d->c_out; K.nchw_dtype = d->nchw_dtype; K.sc = d->sc; K.pool = d->pool;
+    const int blocks = K.cv >> 3;
+    K.ps = (blocks & 1) ? K.cv * 2 : K.cv * 2 + 16;
+    K.rh = K.rw = 0;
+    if (d->stride == 1) return launch_conv<8, 32>(K, d->mt, d->T, (hipStream_t)stream);
+    return launch_conv<4, 16>(K, d->mt, d->T, (hipStream_t)stream);
+}
+
+int sn_ca_mlp(const float* partial, int nblk, int cpad, int c, int cr, float inv_hw,
+              const float* wa, const float* wb, float* ca, int T, void* stream) {
+    if (!partial || !wa || !wb || !ca || cpad < 16 || cpad > 128 || c > cpad || cr > 128 || cr < 1 || nblk < 1) return SN_EINVAL;
+    hipLaunchKernelGGL(ca_mlp_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, partial, nblk, cpad, c, cr, inv_hw, wa, wb, ca);
+    return sn_check_launch();
+}
+
+int sn_scale_residual(const void* res, const void* x, const float* ca, int cpad, void* out, int T, int hw, int cs, void* stream) {
+    if (!res || !x || !ca || !out || (cs & 7) || cs > cpad) return SN_EINVAL;
+    const size_t n = (size_t)hw * (cs >> 3);
+    int gx = (int)((n + 255) / 256); if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(scale_residual_kernel, dim3(gx, T), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)res, (const uint4*)x, ca, cpad, (uint4*)out, hw, cs >> 3);
+    return sn_check_launch();
+}
+
+}  // extern "C"

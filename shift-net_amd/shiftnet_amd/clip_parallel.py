@@ -1,0 +1,38 @@
+"""Clip-parallel inference: one sliding window per GPU, one exchange of the 2-frame temporal halo.
+
+The reference CLI restores frames ``[kL+2, kL+2+L)`` of a clip from input frames ``[kL, kL+L+4)`` (test_deblur.py:
+111-120).  Rank r therefore OWNS the L frames it restores and needs the last two owned frames of rank r-1 and the first
+two of rank r+1; rank 0 / the last rank additionally hold the clip's first / last two frames, which nobody restores.
+That is the only communication on the path: one all-gather of ``[4,3,H,W]`` raw input frames per rank over RCCL (xGMI);
+no feature map ever crosses GPUs, because the result must equal the single-GPU CLI run with the same ``one_len``.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def window_ranges(n_frames: int, one_len: int) -> List[Tuple[range, range]]:
+    """(input range, restored range) per window exactly as the CLI slices them; remainder frames are dropped."""
+    k_len = (n_frames - 4) // one_len
+    return [(range(k * one_len, k * one_len + one_len + 4), range(k * one_len + 2, k * one_len + 2 + one_len))
+            for k in range(k_len)]
+
+
+def assemble_window(own: torch.Tensor, first_edge: Optional[torch.Tensor], last_edge: Optional[torch.Tensor],
+                    rank: int = 0, world: int = 1, group=None) -> torch.Tensor:
+    """own:[L,3,H,W] -> this rank's input window [L+4,3,H,W].
+
+    ``first_edge`` ([2,3,H,W]) is required on rank 0, ``last_edge`` on rank world-1.  With world == 1 there is no
+    communication at all.
+    """
+    if world == 1:
+        return torch.cat((first_edge, own, last_edge), 0)
+    send = torch.cat((own[:2], own[-2:]), 0).contiguous()
+    bufs = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(bufs, send, group=group)
+    head = first_edge if rank == 0 else bufs[rank - 1][2:4]
+    tail = last_edge if rank == world - 1 else bufs[rank + 1][0:2]
+    return torch.cat((head, own, tail), 0)

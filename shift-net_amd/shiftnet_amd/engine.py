@@ -1,0 +1,446 @@
+"""Execution of GShiftNet.forward on the HIP kernels (one process = one GPU = one clip window).
+
+``Plan``   : checkpoint tensors prepared once per device into kernel layouts (prep.py).
+``Engine`` : the forward pass as a straight-line sequence of C-ABI calls on torch's current HIP stream.
+
+Activations are NHWC bf16 torch tensors ``[T, H, W, Cs]`` (PyTorch is only the allocator / stream owner here);
+no op below has a torch/ATen compute fallback.  The control flow mirrors the reference forward of each variant
+(file:line cited per method) so parity can be audited line by line against ``oracle/shiftnet_oracle.py``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import lib as L
+from . import prep
+from .spec import UNIT_NAMES, Variant, shift_table
+
+
+@dataclass
+class Act:
+    """NHWC bf16 activation: t [T,H,W,Cs] with c logical channels (pad channels are zero)."""
+    t: torch.Tensor
+    c: int
+
+    @property
+    def dims(self) -> Tuple[int, int, int, int]:
+        return tuple(self.t.shape)  # type: ignore[return-value]
+
+
+def _dtype_code(dt: torch.dtype) -> int:
+    return {torch.float32: L.SN_F32, torch.float16: L.SN_F16, torch.bfloat16: L.SN_BF16}[dt]
+
+
+class Plan:
+    """Device-resident prepared weights of one checkpoint."""
+
+    def __init__(self, V: Variant, sd: Dict[str, torch.Tensor], device: torch.device) -> None:
+        self.V = V
+        self.device = device
+        self.sd = {k: v.detach().float().cpu() for k, v in sd.items()}
+        self.convs: Dict[str, Dict[str, object]] = {}
+        self.cas: Dict[str, Dict[str, object]] = {}
+        self.units: Dict[str, Dict[str, object]] = {}
+        self.offs = prep.shift_offsets_i8(shift_table(V.c1)).to(device)
+        self._build()
+
+    # -- helpers ---------------------------------------------------------------------------------------------
+    def _dev(self, t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        return None if t is None else t.contiguous().to(self.device)
+
+    def add_conv(self, name: str, key: str, cins: Sequence[int], weight: Optional[torch.Tensor] = None) -> None:
+        w = self.sd[key + "weight"] if weight is None else weight
+        b = self.sd.get(key + "bias") if weight is None else None
+        cs_in = prep.ceil8(max(cins))
+        p = prep.pack_conv(w, b, cins, cs_in)
+        p["wfrag"] = self._dev(p["wfrag"])
+        p["bias"] = self._dev(p["bias"])
+        self.convs[name] = p
+
+    def add_ca(self, name: str, key: str) -> None:
+        wa = self.sd[key + "conv_du.0.weight"]
+        wb = self.sd[key + "conv_du.2.weight"]
+        cr, c = wa.shape[0], wa.shape[1]
+        self.cas[name] = {"wa": self._dev(wa.reshape(cr, c)), "wb": self._dev(wb.reshape(c, cr)), "c": c, "cr": cr}
+
+    def scalar(self, key: str) -> float:
+        return float(self.sd[key].reshape(-1)[0])
+
+    def add_cab(self, pre: str, c: int) -> None:
+        self.add_conv(pre + "body.0", pre + "body.0.", [c])
+        self.add_conv(pre + "body.2", pre + "body.2.", [c])
+        self.add_ca(pre + "CA", pre + "CA.")
+
+    def add_naf(self, pre: str, c: int, with_shift: bool) -> None:
+        V, sd = self.V, self.sd
+        u: Dict[str, object] = {}
+        i = 0
+        if with_shift:
+            u["w1"] = self._dev(sd[pre + "conv1.weight"].reshape(c // 2, 9))
+        g = prep.pack_ln_gemm(sd[f"{pre}body.{i}.weight"], sd[pre + "norm.weight"], sd[pre + "norm.bias"], c); i += 1
+        u["w_ln"], u["b_ln"] = self._dev(g["wfrag"]), self._dev(g["bias"])
+        u["w_dw3"] = self._dev(prep.pack_dw3_gate(sd[f"{pre}body.{i}.conv_2.weight"], c)); i += 1
+        i += 1
+        if V.denoise:
+            self.add_ca(f"{pre}ca1", f"{pre}body.{i}."); i += 1
+        if V.grouped_rep:
+            dense = prep.pack_grouped_rep(sd[f"{pre}body.{i}.conv_1.weight"], sd[f"{pre}body.{i}.conv_2.weight"])
+            self.add_conv(pre + "rep", "", [c], weight=dense)
+            u["w_dw5"] = self._dev(prep.identity_dw5(c))
+        else:
+            u["w_dw5"] = self._dev(prep.pack_dw5(sd[f"{pre}body.{i}.conv_1.weight"], sd[f"{pre}body.{i}.conv_2.weight"]))
+        i += 1
+        u["w_gate"] = self._dev(prep.pack_gate_gemm(sd[f"{pre}body.{i}.weight"], c)); i += 1
+        i += 1
+        self.add_ca(f"{pre}ca2", f"{pre}body.{i}."); i += 1
+        o = prep.pack_out_gemm(sd[f"{pre}body.{i}.weight"], sd[pre + "beta"], sd.get(f"{pre}body.{i}.bias"), c)
+        u["w_out"], u["b_out"] = self._dev(o["wfrag"]), self._dev(o["bias"])
+        self.units[pre] = u
+
+    def add_shift_block(self, pre: str, c: int) -> None:
+        for k in range(self.V.units):
+            self.add_naf(f"{pre}{UNIT_NAMES[k]}.0.", c, True)
+            self.add_naf(f"{pre}{UNIT_NAMES[k]}.1.", c, False)
+
+    def add_down(self, pre: str, cin: int) -> None:
+        self.add_conv(pre + "down", pre + ("down.0." if self.V.denoise else "down."), [cin])
+
+    def add_unet(self, pre: str) -> None:
+        V = self.V
+        c = [V.c0, V.c0 + V.unet_step, V.c0 + 2 * V.unet_step]
+        for lvl, n in ((1, 1), (2, 3), (3, 3)):
+            for i in range(n):
+                self.add_cab(f"{pre}encoder_level{lvl}.{i}.", c[lvl - 1])
+                self.add_cab(f"{pre}decoder_level{lvl}.{i}.", c[lvl - 1])
+        self.add_down(pre + "down12.", c[0])
+        self.add_down(pre + "down23.", c[1])
+        self.add_cab(pre + "skip_attn1.", c[0])
+        self.add_cab(pre + "skip_attn2.", c[1])
+        self.add_conv(pre + "up21", pre + "up21.up.1.", [c[1]])
+        self.add_conv(pre + "up32", pre + "up32.up.1.", [c[2]])
+
+    def _build(self) -> None:
+        V = self.V
+        c0, c1 = V.c0, V.c1
+        self.add_conv("feat_extract.0", "feat_extract.0.", [V.in_ch])
+        self.add_cab("feat_extract.1.", c0)
+        self.add_conv("conv_trans", "conv_trans.", [c0])
+        self.add_conv("conv_last", "conv_last.", [c0])
+        self.add_conv("rconcat", "rconcat.", [c0, c0, c0])
+        for i in range(1, V.n_orb + 1):
+            self.add_unet(f"orb{i}.")
+            self.add_unet(f"rorb{i}.")
+        p = "stage1."
+        self.add_cab(p + "concat.", c0)
+        self.add_conv(p + "down01", p + "down01.0.", [c0])
+        self.add_down(p + "down12.", c1)
+        if V.topo == "small":
+            blocks = ["encoder_level1", "encoder_level1_1", "encoder_level1_2", "encoder_level2", "encoder_level2_1",
+                      "encoder_level2_2", "decoder_level2", "decoder_level2_1", "decoder_level2_2",
+                      "decoder_level1", "decoder_level1_1", "decoder_level1_2"]
+        else:
+            self.add_down(p + "down23.", c1)
+            if V.shift_cab:
+                self.add_cab(p + "encoder_level0.", c0)
+                self.add_cab(p + "encoder_level0_1.", c0)
+            for n in ("encoder_level1", "encoder_level1_1", "encoder_level2", "encoder_level2_1",
+                      "encoder_level3", "encoder_level3_1"):
+                self.add_cab(f"{p}{n}.", c1)
+            self.add_cab(p + "skip_attn2.", c1)
+            self.add_conv(p + "up32", p + "up32.up.1.", [c1])
+            blocks = ["decoder_level3", "decoder_level3_1", "decoder_level2", "decoder_level2_1",
+                      "decoder_level1", "decoder_level1_1", "decoder_level1_2"]
+        for b in blocks:
+            self.add_shift_block(f"{p}{b}.", c1)
+        self.add_cab(p + "skip_attn1.", c1)
+        self.add_conv(p + "up21", p + "up21.up.1.", [c1])
+        self.add_conv(p + "upsample0", p + "upsample0.upsample_conv.", [c1])
+        self.add_cab(p + "skip_conv.", c0)
+        self.add_cab(p + "out_conv.", c0)
+        self.add_conv(p + "conv_hr0", p + "conv_hr0.", [c0, c0] if V.hr_cat else [c0])
+
+
+class Engine:
+    def __init__(self, plan: Plan) -> None:
+        self.P = plan
+        self.V = plan.V
+        self.lib = L.load()
+        self.dev = plan.device
+        self.prof: Optional[list] = None      # bench.py attaches a list to collect (fn, label, meta, ev0, ev1)
+        self._meta: Tuple = ()
+
+    # ---- low level wrappers --------------------------------------------------------------------------------
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def _call(self, fn: str, label: str, *args) -> None:
+        """One C-ABI launch on the current stream; with a profiler attached, bracketed by stream events."""
+        f = getattr(self.lib, fn)
+        if self.prof is None:
+            L.check(f(*args), label)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(f(*args), label)
+        e1.record()
+        self.prof.append((fn, label, self._meta, e0, e1))
+
+    def _new(self, T: int, h: int, w: int, cs: int) -> torch.Tensor:
+        return torch.empty((T, h, w, cs), dtype=torch.bfloat16, device=self.dev)
+
+    def conv(self, name: str, ins: Sequence[Act], *, stride: int = 1, pad: Optional[int] = None, prelu: Optional[float] = None,
+             res: Optional[Act] = None, out_mode: int = 0, pool: bool = False, in_mode: int = 0,
+             nchw_out: Optional[torch.Tensor] = None, nchw_sc: Optional[torch.Tensor] = None):
+        p = self.P.convs[name]
+        k, cout = int(p["k"]), int(p["cout"])
+        T, hs, ws, cs_in = ins[0].dims
+        assert cs_in == p["cs_in"] and len(ins) == p["n_in"], (name, cs_in, p["cs_in"])
+        h_in, w_in = (2 * hs, 2 * ws) if in_mode == 1 else (hs, ws)
+        if pad is None:
+            pad = k // 2
+        h_out = (h_in + 2 * pad - k) // stride + 1
+        w_out = (w_in + 2 * pad - k) // stride + 1
+        d = L.ConvDesc()
+        for i in range(3):
+            d.inp[i] = ins[i].t.data_ptr() if i < len(ins) else None
+        d.n_in, d.cs_in, d.T, d.h_in, d.w_in, d.in_mode = len(ins), cs_in, T, h_in, w_in, in_mode
+        d.k, d.stride, d.pad, d.h_out, d.w_out = k, stride, pad, h_out, w_out
+        d.wfrag, d.mt, d.ks = p["wfrag"].data_ptr(), int(p["mt"]), int(p["ks"])
+        d.bias = p["bias"].data_ptr() if p["bias"] is not None else None
+        d.act, d.prelu = (1, prelu) if prelu is not None else (0, 0.0)
+        pool_buf = None
+        out_act: Optional[Act] = None
+        if out_mode == 2:
+            assert nchw_out is not None and nchw_sc is not None
+            d.out, d.sc, d.cs_out = nchw_out.data_ptr(), nchw_sc.data_ptr(), 8
+            d.c_out, d.nchw_dtype = cout, _dtype_code(nchw_out.dtype)
+        else:
+            c_log = cout // 4 if out_mode == 1 else cout
+            cs_out = prep.ceil8(c_log)
+            o = self._new(T, 2 * h_out, 2 * w_out, cs_out) if out_mode == 1 else self._new(T, h_out, w_out, cs_out)
+            out_act = Act(o, c_log)
+            d.out, d.cs_out, d.c_out = o.data_ptr(), cs_out, cout
+        d.out_mode = out_mode
+        if res is not None:
+            assert out_mode == 0 and res.dims == out_act.dims
+            d.res = res.t.data_ptr()
+        if pool:
+            nblk = self.lib.sn_conv_pool_blocks(h_out, w_out, stride)
+            pool_buf = torch.empty((T, nblk, 16 * d.mt), dtype=torch.float32, device=self.dev)
+            d.pool = pool_buf.data_ptr()
+        self._meta = ("conv", T, h_out, w_out, len(ins) * cs_in, int(d.cs_out), k, stride, in_mode, out_mode)
+        self._call("sn_conv2d", f"sn_conv2d[{name}]", C.byref(d), self._stream())
+        if pool:
+            return out_act, pool_buf, h_out * w_out
+        return out_act
+
+    def ca_mlp(self, name: str, pool: torch.Tensor, npix: int) -> torch.Tensor:
+        p = self.P.cas[name]
+        T, nblk, cpad = pool.shape
+        ca = torch.empty((T, cpad), dtype=torch.float32, device=self.dev)
+        self._call("sn_ca_mlp", f"sn_ca_mlp[{name}]", pool.data_ptr(), nblk, cpad, p["c"], p["cr"], 1.0 / npix, p["wa"].data_ptr(),
+                                   p["wb"].data_ptr(), ca.data_ptr(), T, self._stream())
+        return ca
+
+    def scale_residual(self, r: Act, x: Act, ca: torch.Tensor) -> Act:
+        T, h, w, cs = r.dims
+        o = self._new(T, h, w, cs)
+        self._meta = ("ew", T, h, w, cs)
+        self._call("sn_scale_residual", "sn_scale_residual", r.t.data_ptr(), x.t.data_ptr(), ca.data_ptr(), ca.shape[1], o.data_ptr(),
+                                           T, h * w, cs, self._stream())
+        return Act(o, r.c)
+
+    # ---- blocks (oracle/shiftnet_oracle.py has the same names) ----------------------------------------------
+    def cab(self, pre: str, x: Act) -> Act:
+        """CAB: 3x3 -> PReLU -> 3x3 -> CALayer -> +x (gshift_deblur1.py:141-156)."""
+        r = self.conv(pre + "body.0", [x], prelu=self.P.scalar(pre + "body.1.weight"))
+        r, pool, npix = self.conv(pre + "body.2", [r], pool=True)
+        return self.scale_residual(r, x, self.ca_mlp(pre + "CA", pool, npix))
+
+    def _unit_src(self, x: Act, mode: int) -> L.UnitSrc:
+        T, h, w, cs = x.dims
+        assert cs == x.c
+        return L.UnitSrc(x.t.data_ptr(), T, h, w, x.c, mode, 1 if self.V.wrap else 0)
+
+    def temporal_roll(self, x: Act, reverse: bool) -> Act:
+        T, h, w, cs = x.dims
+        assert cs == x.c, "Shift_CAB widths (24, 80) are stored unpadded"
+        y = self._new(T, h, w, cs)
+        s = L.UnitSrc(x.t.data_ptr(), T, h, w, x.c, 2 if reverse else 1, 0)
+        self._call("sn_temporal_roll", "sn_temporal_roll", C.byref(s), y.data_ptr(), self._stream())
+        return Act(y, x.c)
+
+    def shift_cab(self, pre: str, x: Act, reverse: bool) -> Act:
+        """Shift_CAB (gshift_denoise1.py:157-186)."""
+        return self.cab(pre, self.temporal_roll(x, reverse))
+
+    def naf(self, pre: str, x: Act, mode: int) -> Act:
+        """CAB2 (mode 1/2, fed by the GSTS gather of x) or CAB1 (mode 0) (gshift_deblur1.py:183-255)."""
+        lib, st, V, P = self.lib, self._stream(), self.V, self.P
+        u = P.units[pre]
+        T, h, w, c = x.dims
+        self._meta = ("naf", T, h, w, c, mode)
+        src = self._unit_src(x, mode)
+        hw_ptr = None
+        if mode:
+            hwb = self._new(T, h, w, c // 2)
+            self._call("sn_gsts_shiftconv", "sn_gsts_shiftconv", C.byref(src), P.offs.data_ptr(), u["w1"].data_ptr(), hwb.data_ptr(), st)
+            hw_ptr = hwb.data_ptr()
+        a = self._new(T, h, w, 2 * c)
+        self._call("sn_ln_gemm", "sn_ln_gemm", C.byref(src), hw_ptr, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(), a.data_ptr(), st)
+        g1 = self._new(T, h, w, c)
+        ca1_ptr = None
+        if V.denoise:
+            nb = lib.sn_dwgate_blocks(h, w)
+            pool1 = torch.empty((T, nb, c), dtype=torch.float32, device=self.dev)
+            self._call("sn_dw_gate", "sn_dw_gate", a.data_ptr(), u["w_dw3"].data_ptr(), g1.data_ptr(), pool1.data_ptr(), T, h, w, c, st)
+            ca1 = self.ca_mlp(pre + "ca1", pool1, h * w)
+            ca1_ptr = ca1.data_ptr()
+        else:
+            self._call("sn_dw_gate", "sn_dw_gate", a.data_ptr(), u["w_dw3"].data_ptr(), g1.data_ptr(), None, T, h, w, c, st)
+        if V.grouped_rep:
+            # "+" RepConv is a grouped (8->8) 5x5: round 1 runs it as a block-diagonal dense conv on the MFMA conv kernel;
+            # the CALayer2 scale of the denoise variant must precede it, so it is applied by a scale pass first.
+            g1a = Act(g1, c)
+            if ca1_ptr is not None:
+                zero = torch.zeros_like(g1)
+                g1a = self.scale_residual(g1a, Act(zero, c), ca1)
+                ca1_ptr = None
+            g1 = self.conv(pre + "rep", [g1a]).t
+        g2 = self._new(T, h, w, c)
+        nb = lib.sn_dwgemm_blocks(h, w)
+        pool2 = torch.empty((T, nb, c), dtype=torch.float32, device=self.dev)
+        self._call("sn_dw_gemm_gate", "sn_dw_gemm_gate", g1.data_ptr(), ca1_ptr, u["w_dw5"].data_ptr(), u["w_gate"].data_ptr(), g2.data_ptr(),
+                                    pool2.data_ptr(), T, h, w, c, st)
+        ca2 = self.ca_mlp(pre + "ca2", pool2, h * w)
+        y = self._new(T, h, w, c)
+        b_out = u["b_out"].data_ptr() if u["b_out"] is not None else None
+        self._call("sn_scale_gemm_res", "sn_scale_gemm_res", C.byref(src), g2.data_ptr(), ca2.data_ptr(), u["w_out"].data_ptr(), b_out, y.data_ptr(), st)
+        return Act(y, c)
+
+    def gsts_unit(self, pre: str, x: Act, reverse: bool) -> Act:
+        return self.naf(pre + "1.", self.naf(pre + "0.", x, 2 if reverse else 1), 0)
+
+    def shift_block(self, pre: str, x: Act) -> Act:
+        """Encoder_shift_block.forward (gshift_deblur1.py:530-547 / gshift_deblur2.py:521-530)."""
+        for i in range(self.V.units):
+            x = self.gsts_unit(f"{pre}{UNIT_NAMES[i]}.", x, reverse=(i % 2 == 1))
+        return x
+
+    def down(self, pre: str, x: Act) -> Act:
+        """DownSample (gshift_deblur1.py:330-340 / gshift_denoise1.py:356-365)."""
+        if self.V.denoise:
+            return self.conv(pre + "down", [x], stride=2, prelu=self.P.scalar(pre + "down.1.weight"))
+        return self.conv(pre + "down", [x], stride=2)
+
+    def skip_up(self, name: str, x: Act, y: Act) -> Act:
+        """SkipUpSample: bilinear x2 -> 1x1 -> + y (gshift_deblur1.py:341-350), upsample fused into the conv loader."""
+        return self.conv(name, [x], in_mode=1, res=y)
+
+    def tfr_unet(self, pre: str, x: Act) -> Act:
+        """TFR_UNet.forward (gshift_deblur1.py:709-722)."""
+        def seq(nm: str, n: int, t: Act) -> Act:
+            for i in range(n):
+                t = self.cab(f"{pre}{nm}.{i}.", t)
+            return t
+        enc1 = seq("encoder_level1", 1, x)
+        enc2 = seq("encoder_level2", 3, self.down(pre + "down12.", enc1))
+        enc3 = seq("encoder_level3", 3, self.down(pre + "down23.", enc2))
+        dec3 = seq("decoder_level3", 3, enc3)
+        t = self.skip_up(pre + "up32", dec3, self.cab(pre + "skip_attn2.", enc2))
+        dec2 = seq("decoder_level2", 3, t)
+        t = self.skip_up(pre + "up21", dec2, self.cab(pre + "skip_attn1.", enc1))
+        return seq("decoder_level1", 1, t)
+
+    def stage1(self, x: Act) -> Act:
+        """Encoder2.forward (gshift_deblur1.py:613-642, gshift_deblur2.py:587-613, gshift_denoise1.py:640-670)."""
+        V, p = self.V, "stage1."
+        x = self.cab(p + "concat.", x)
+        shortcut = x
+        if V.shift_cab:
+            x = self.shift_cab(p + "encoder_level0.", x, False)
+            x = self.shift_cab(p + "encoder_level0_1.", x, True)
+        x = self.conv(p + "down01", [x], stride=2, pad=0, prelu=self.P.scalar(p + "down01.1.weight"))
+        if V.topo == "small":
+            e = self.shift_block(p + "encoder_level1.", x)
+            e = self.shift_block(p + "encoder_level1_1.", e)
+            enc11 = self.shift_block(p + "encoder_level1_2.", e)
+            e = self.down(p + "down12.", enc11)
+            for n in ("encoder_level2", "encoder_level2_1", "encoder_level2_2",
+                      "decoder_level2", "decoder_level2_1", "decoder_level2_2"):
+                e = self.shift_block(f"{p}{n}.", e)
+            x = self.skip_up(p + "up21", e, self.cab(p + "skip_attn1.", enc11))
+        else:
+            if V.shift_cab:
+                e = self.shift_cab(p + "encoder_level1.", x, False)
+                enc11 = self.shift_cab(p + "encoder_level1_1.", e, True)
+            else:
+                enc11 = self.cab(p + "encoder_level1_1.", self.cab(p + "encoder_level1.", x))
+            e = self.down(p + "down12.", enc11)
+            enc22 = self.cab(p + "encoder_level2_1.", self.cab(p + "encoder_level2.", e))
+            e = self.down(p + "down23.", enc22)
+            enc33 = self.cab(p + "encoder_level3_1.", self.cab(p + "encoder_level3.", e))
+            d = self.shift_block(p + "decoder_level3_1.", self.shift_block(p + "decoder_level3.", enc33))
+            x = self.skip_up(p + "up32", d, self.cab(p + "skip_attn2.", enc22))
+            d = self.shift_block(p + "decoder_level2_1.", self.shift_block(p + "decoder_level2.", x))
+            x = self.skip_up(p + "up21", d, self.cab(p + "skip_attn1.", enc11))
+        d = self.shift_block(p + "decoder_level1.", x)
+        d = self.shift_block(p + "decoder_level1_1.", d)
+        dec11 = self.shift_block(p + "decoder_level1_2.", d)
+        skip = self.cab(p + "skip_conv.", shortcut)
+        if V.hr_cat:
+            up = self.conv(p + "upsample0", [dec11], out_mode=1)
+            out = self.conv(p + "conv_hr0", [up, skip])
+        else:   # conv_hr0(act(upsample0(x))) + skip: the PReLU commutes with pixel_shuffle, so it is the conv epilogue
+            up = self.conv(p + "upsample0", [dec11], out_mode=1, prelu=self.P.scalar(p + "act.weight"))
+            out = self.conv(p + "conv_hr0", [up], res=skip)
+        return self.cab(p + "out_conv.", out)
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, noise_map: Optional[torch.Tensor], past: int, future: int) -> torch.Tensor:
+        """GShiftNet.forward; x:[T,C,H,W] (already x[0]) on this engine's device, any of fp32/fp16/bf16."""
+        V = self.V
+        x = x.contiguous()
+        T, cin, H, W = x.shape
+        div = 8 if V.topo == "plus" else 4
+        if H % div or W % div:
+            raise ValueError(f"{V.name}: H and W must be multiples of {div} (got {H}x{W})")
+        n_out = max(T - past - future, 0)
+        out = torch.empty((n_out, 3, H, W), dtype=x.dtype, device=x.device)
+        if n_out == 0:
+            return out                      # T <= past+future yields an empty tensor upstream as well
+        nm_ptr = None
+        if V.denoise:
+            noise_map = noise_map.to(x.dtype).expand(T, 1, H, W).contiguous()
+            nm_ptr = noise_map.data_ptr()
+        x8 = self._new(T, H, W, 8)
+        self._call("sn_ingest", "sn_ingest", x.data_ptr(), _dtype_code(x.dtype), nm_ptr, x8.data_ptr(), T, cin, H, W, self._stream())
+        x0 = self.cab("feat_extract.1.", self.conv("feat_extract.0", [Act(x8, V.in_ch)]))
+        t = x0
+        for i in range(1, V.n_orb + 1):
+            t = self.tfr_unet(f"orb{i}.", t)
+        if V.denoise:
+            res0 = t
+        else:           # res0 = orbN(..) + shortcut (gshift_deblur1.py:769)
+            ones = torch.ones((T, 16 * 6), dtype=torch.float32, device=self.dev)
+            res0 = self.scale_residual(t, x0, ones)
+        sam = self.conv("conv_trans", [res0])
+        dec = self.stage1(sam)
+        lo, hi = past, T - future
+        feats = sam if V.denoise else res0
+
+        def cut(a: Act) -> Act:
+            return Act(a.t[lo:hi], a.c)
+        y = self.conv("rconcat", [cut(x0), cut(feats), cut(dec)], prelu=self.P.scalar("lrelu.weight") if V.denoise else None)
+        sc = y
+        for i in range(1, V.n_orb + 1):
+            y = self.tfr_unet(f"rorb{i}.", y)
+        if not V.denoise:
+            ones = torch.ones((n_out, 16 * 6), dtype=torch.float32, device=self.dev)
+            y = self.scale_residual(y, sc, ones)
+        self.conv("conv_last", [y], out_mode=2, nchw_out=out, nchw_sc=x[lo:hi].contiguous())
+        return out

@@ -1,0 +1,89 @@
+"""ctypes binding of libshiftnet_hip.so (the C ABI in include/shiftnet_hip.h).
+
+There is deliberately NO fallback: if the shared object is missing or a symbol
+is absent, importing the product path fails loudly (the HIP kernels ARE the
+product; the CPU oracle under ``oracle/`` is test infrastructure only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libshiftnet_hip.so")
+
+SN_F32, SN_F16, SN_BF16 = 0, 1, 2
+
+SYMBOLS = [
+    "sn_abi_version", "sn_selftest_mfma", "sn_ingest", "sn_conv2d", "sn_conv_pool_blocks", "sn_ca_mlp",
+    "sn_scale_residual", "sn_gsts_gather", "sn_temporal_roll", "sn_gsts_shiftconv", "sn_ln_gemm", "sn_dw_gate",
+    "sn_dwgate_blocks", "sn_dw_gemm_gate", "sn_dwgemm_blocks", "sn_scale_gemm_res",
+]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("inp", C.c_void_p * 3), ("n_in", C.c_int), ("cs_in", C.c_int),
+        ("T", C.c_int), ("h_in", C.c_int), ("w_in", C.c_int), ("in_mode", C.c_int),
+        ("k", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("h_out", C.c_int), ("w_out", C.c_int),
+        ("wfrag", C.c_void_p), ("mt", C.c_int), ("ks", C.c_int), ("bias", C.c_void_p),
+        ("act", C.c_int), ("prelu", C.c_float), ("res", C.c_void_p), ("out", C.c_void_p),
+        ("cs_out", C.c_int), ("out_mode", C.c_int), ("c_out", C.c_int), ("nchw_dtype", C.c_int),
+        ("sc", C.c_void_p), ("pool", C.c_void_p),
+    ]
+
+
+class UnitSrc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("T", C.c_int), ("h", C.c_int), ("w", C.c_int), ("C", C.c_int),
+                ("mode", C.c_int), ("wrap", C.c_int)]
+
+
+class ShiftNetLibError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the library once; raise (never degrade) if it or any declared symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ShiftNetLibError(
+            f"{LIB_PATH} not found: build it with `python shift-net_amd/build.py` (hipcc, gfx950). "
+            "There is no CPU fallback for the Shift-Net HIP path.")
+    lib = C.CDLL(LIB_PATH)
+    missing = [s for s in SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise ShiftNetLibError(f"{LIB_PATH} lacks symbols {missing}")
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    lib.sn_abi_version.restype = ci
+    lib.sn_selftest_mfma.argtypes = [vp, vp, vp, vp]
+    lib.sn_ingest.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, vp]
+    lib.sn_conv2d.argtypes = [C.POINTER(ConvDesc), vp]
+    lib.sn_conv_pool_blocks.argtypes = [ci, ci, ci]
+    lib.sn_ca_mlp.argtypes = [vp, ci, ci, ci, ci, cf, vp, vp, vp, ci, vp]
+    lib.sn_scale_residual.argtypes = [vp, vp, vp, ci, vp, ci, ci, ci, vp]
+    lib.sn_gsts_gather.argtypes = [C.POINTER(UnitSrc), vp, vp, vp]
+    lib.sn_temporal_roll.argtypes = [C.POINTER(UnitSrc), vp, vp]
+    lib.sn_gsts_shiftconv.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp]
+    lib.sn_ln_gemm.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp]
+    lib.sn_dw_gate.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
+    lib.sn_dwgate_blocks.argtypes = [ci, ci]
+    lib.sn_dw_gemm_gate.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
+    lib.sn_dwgemm_blocks.argtypes = [ci, ci]
+    lib.sn_scale_gemm_res.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp, vp]
+    for s in SYMBOLS:
+        getattr(lib, s).restype = ci
+    if lib.sn_abi_version() != 1:
+        raise ShiftNetLibError("ABI version mismatch between shiftnet_amd/lib.py and libshiftnet_hip.so")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise ShiftNetLibError(f"{what} failed with code {rc}")

@@ -1,0 +1,170 @@
+"""Host-side weight preparation: checkpoint tensors -> the layouts the gfx950 kernels consume.
+
+All channel permutations of the HIP path live HERE, the kernels only ever see "positions":
+
+* MFMA A fragments ``[MT][KS][64][8]`` bf16 for ``v_mfma_f32_16x16x32_bf16`` with the weights as the A operand:
+  lane ``l`` holds ``Wp[mt*16 + (l & 15)][ks*32 + (l >> 4)*8 + j]`` (csrc/sn_common.h).
+* D registers: lane ``(g, p)`` reg ``r`` of M-tile ``mt`` is row ``mt*16 + g*4 + r``.  Rows are assigned to output
+  channels so that a lane's registers are CONTIGUOUS channels of its pixel:
+    - ``conv`` / ``out`` order:   channel = g*4*MT + mt*4 + r                       (natural NHWC store)
+    - ``gate`` order (2C rows):   mt even -> channel c, mt odd -> its gate partner C + c, c = g*2*MT + (mt//2)*4 + r,
+      so SimpleGate / SimpleGate2 are lane-local and the gated result comes out in natural order.
+* identity / 3x3 branches of RepConv / RepConv2 are folded into one stencil (gshift_deblur1.py:157-174),
+  LayerNorm affine into the following 1x1 (:27,190), beta (and the denoise bias) into the last 1x1 (:201,210).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+def ceil8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+def pack_frag(wp: np.ndarray) -> torch.Tensor:
+    """[16*MT, 32*KS] fp32 -> bf16 tensor [MT, KS, 64, 8] in A-fragment order."""
+    m, k = wp.shape
+    assert m % 16 == 0 and k % 32 == 0
+    mt, ks = m // 16, k // 32
+    a = wp.reshape(mt, 16, ks, 4, 8).transpose(0, 2, 3, 1, 4).reshape(mt, ks, 64, 8)
+    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16)
+
+
+def rows_natural(n_ch: int, mt: int) -> np.ndarray:
+    """row index (into the 16*MT padded matrix) of output channel co, 'conv' order."""
+    co = np.arange(n_ch)
+    g, rem = co // (4 * mt), co % (4 * mt)
+    return (rem // 4) * 16 + g * 4 + (rem % 4)
+
+
+def rows_gate(c: int) -> np.ndarray:
+    """row index of output channel o in [0, 2C) for the gate-paired order (MT = C/8 M-tiles)."""
+    mt = c // 8
+    o = np.arange(2 * c)
+    half, cc = o // c, o % c
+    g, rem = cc // (2 * mt), cc % (2 * mt)
+    q, r = rem // 4, rem % 4
+    return (2 * q + half) * 16 + g * 4 + r
+
+
+def pos_gate(c: int) -> np.ndarray:
+    """storage position (within a pixel's 2C values) of output channel o for the gate-paired order."""
+    mt = c // 8
+    o = np.arange(2 * c)
+    half, cc = o // c, o % c
+    g, rem = cc // (2 * mt), cc % (2 * mt)
+    q, r = rem // 4, rem % 4
+    return g * 4 * mt + (2 * q + half) * 4 + r
+
+
+def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], cins: Sequence[int], cs_in: int) -> Dict[str, object]:
+    """Dense conv weight [Cout, sum(cins), k, k] -> implicit-GEMM fragments.
+
+    K index = tap*(n_in*cs_in) + i*cs_in + c  (tap = ky*k + kx), rows in 'conv' order.
+    """
+    w = weight.detach().float().cpu().numpy()
+    cout, cin_tot, k, _ = w.shape
+    assert cin_tot == sum(cins)
+    n_in = len(cins)
+    cv = n_in * cs_in
+    mt = (cout + 15) // 16
+    kdim = k * k * cv
+    ks = (kdim + 31) // 32
+    wp = np.zeros((16 * mt, 32 * ks), np.float32)
+    rows = rows_natural(cout, mt)
+    base = 0
+    for i, ci in enumerate(cins):
+        for tap in range(k * k):
+            ky, kx = divmod(tap, k)
+            cols = tap * cv + i * cs_in + np.arange(ci)
+            wp[np.ix_(rows, cols)] = w[:, base:base + ci, ky, kx]
+        base += ci
+    b = None
+    if bias is not None:
+        b = np.zeros(16 * mt, np.float32)
+        b[:cout] = bias.detach().float().cpu().numpy()
+    return {"wfrag": pack_frag(wp), "mt": mt, "ks": ks, "bias": None if b is None else torch.from_numpy(b),
+            "k": k, "cout": cout, "n_in": n_in, "cs_in": cs_in}
+
+
+def pack_ln_gemm(w1: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, c: int) -> Dict[str, object]:
+    """body[0] (1x1, 2C x K) with the LayerNorm affine folded in; rows/bias in gate-paired order."""
+    w = w1.detach().float().cpu().numpy().reshape(2 * c, -1)
+    kdim = w.shape[1]
+    lw = ln_w.detach().float().cpu().numpy()
+    lb = ln_b.detach().float().cpu().numpy()
+    wf = w * lw[None, :]
+    bf = w @ lb
+    ks = (kdim + 31) // 32
+    mt = c // 8
+    wp = np.zeros((16 * mt, 32 * ks), np.float32)
+    wp[rows_gate(c), :kdim] = wf
+    bias = np.zeros(2 * c, np.float32)
+    bias[pos_gate(c)] = bf
+    return {"wfrag": pack_frag(wp), "bias": torch.from_numpy(bias)}
+
+
+def pack_dw3_gate(w: torch.Tensor, c: int) -> torch.Tensor:
+    """RepConv2 depthwise 3x3 [2C,1,3,3] (+identity) -> fp32 [9][2C] in a's storage-position order."""
+    wn = w.detach().float().cpu().numpy().reshape(2 * c, 9).copy()
+    wn[:, 4] += 1.0
+    out = np.zeros((9, 2 * c), np.float32)
+    out[:, pos_gate(c)] = wn.T
+    return torch.from_numpy(out)
+
+
+def pack_dw5(w5: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
+    """depthwise RepConv: conv_1 [C,1,5,5] + conv_2 [C,1,3,3] + identity -> fp32 [25][C]."""
+    a = w5.detach().float().cpu().numpy()[:, 0].copy()
+    a[:, 1:4, 1:4] += w3.detach().float().cpu().numpy()[:, 0]
+    a[:, 2, 2] += 1.0
+    return torch.from_numpy(np.ascontiguousarray(a.reshape(a.shape[0], 25).T))
+
+
+def pack_grouped_rep(w5: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
+    """grouped RepConv ("+", groups = C/8): fold 3x3 + identity, expand to a block-diagonal dense [C, C, 5, 5]."""
+    a = w5.detach().float().cpu().numpy().copy()          # [C, 8, 5, 5]
+    c = a.shape[0]
+    a[:, :, 1:4, 1:4] += w3.detach().float().cpu().numpy()
+    dense = np.zeros((c, c, 5, 5), np.float32)
+    for o in range(c):
+        g0 = (o // 8) * 8
+        dense[o, g0:g0 + 8] = a[o]
+        dense[o, o, 2, 2] += 1.0
+    return torch.from_numpy(dense)
+
+
+def identity_dw5(c: int) -> torch.Tensor:
+    w = np.zeros((25, c), np.float32)
+    w[12] = 1.0
+    return torch.from_numpy(w)
+
+
+def pack_gate_gemm(w2: torch.Tensor, c: int) -> torch.Tensor:
+    """body 1x1 C -> 2C before SimpleGate2; rows gate-paired, K natural."""
+    w = w2.detach().float().cpu().numpy().reshape(2 * c, c)
+    ks = (c + 31) // 32
+    wp = np.zeros((16 * (c // 8), 32 * ks), np.float32)
+    wp[rows_gate(c), :c] = w
+    return pack_frag(wp)
+
+
+def pack_out_gemm(w3: torch.Tensor, beta: torch.Tensor, bias3: Optional[torch.Tensor], c: int) -> Dict[str, object]:
+    """last 1x1 C -> C with beta (and beta*bias) folded; rows in natural 'conv' order (MT = C/16)."""
+    w = w3.detach().float().cpu().numpy().reshape(c, c)
+    b = beta.detach().float().cpu().numpy().reshape(c)
+    mt = c // 16
+    ks = (c + 31) // 32
+    wp = np.zeros((16 * mt, 32 * ks), np.float32)
+    wp[rows_natural(c, mt), :c] = w * b[:, None]
+    bias = None
+    if bias3 is not None:
+        bias = torch.from_numpy((bias3.detach().float().cpu().numpy() * b).astype(np.float32))
+    return {"wfrag": pack_frag(wp), "bias": bias}
+
+
+def shift_offsets_i8(table: List[Tuple[int, int]]) -> torch.Tensor:
+    return torch.tensor(table, dtype=torch.int8).reshape(-1, 2).contiguous()

@@ -1,0 +1,216 @@
+"""numpy emulation of the gfx950 kernels' data-flow conventions (runs on CPU, no GPU needed).
+
+Each function follows the indexing of the HIP kernel it names (csrc/*.hip) step by step -- MFMA lane/slot layout,
+tap-offset tables, D-register -> channel maps, storage positions -- but in plain numpy on small inputs.  Feeding it the
+host-prepared weights (shiftnet_amd/prep.py) and comparing with the oracle proves that the HOST packing and the KERNEL
+conventions agree, independently of a GPU.  (bf16 rounding is not emulated: everything here is fp32.)
+"""
+import numpy as np
+
+
+def frag_to_np(wfrag):
+    return wfrag.float().numpy()
+
+
+def mfma_tiles(wfrag, bfrag):
+    """wfrag [MT,KS,64,8], bfrag [KS,64,8] (one N-tile) -> D regs [MT, 64 lanes, 4]."""
+    MT, KS = wfrag.shape[:2]
+    A = wfrag.reshape(MT, KS, 4, 16, 8)          # [mt, s, g, m, j]   lane = g*16 + m
+    B = bfrag.reshape(KS, 4, 16, 8)              # [s, g, n, j]       lane = g*16 + n
+    D = np.einsum("tsgmj,sgnj->tmn", A, B)       # [mt, m, n]
+    regs = np.zeros((MT, 64, 4), np.float32)
+    for lane in range(64):
+        gD, n = lane >> 4, lane & 15
+        for r in range(4):
+            regs[:, lane, r] = D[:, gD * 4 + r, n]
+    return regs
+
+
+def conv2d(ins, p, stride=1, pad=None, bias=True, prelu=None, res=None, in_up=False):
+    """sn_conv2d: ins list of [T,H,W,Cs] fp32 arrays (NHWC, padded), p = prep.pack_conv dict -> [T,Ho,Wo,16*MT]."""
+    wfrag = frag_to_np(p["wfrag"]); MT, KS = wfrag.shape[:2]
+    k = p["k"]; cs = p["cs_in"]; n_in = len(ins); cv = n_in * cs
+    pad = k // 2 if pad is None else pad
+    x = np.concatenate(ins, axis=-1)              # per-pixel interleave [.., n_in*cs]
+    if in_up:
+        raise NotImplementedError
+    T, H, W, _ = x.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    xp = np.zeros((T, H + 2 * pad + 64, W + 2 * pad + 64, cv), np.float32)
+    xp[:, pad:pad + H, pad:pad + W] = x
+    K = k * k * cv
+    out = np.zeros((T, Ho, Wo, 16 * MT), np.float32)
+    bvec = p["bias"].numpy() if (bias and p["bias"] is not None) else np.zeros(16 * MT, np.float32)
+    for t in range(T):
+        for oy in range(Ho):
+            for ox0 in range(0, Wo, 16):
+                bfrag = np.zeros((KS, 64, 8), np.float32)
+                for lane in range(64):
+                    g, pp = lane >> 4, lane & 15
+                    ox = min(ox0 + pp, Wo - 1)
+                    for s in range(KS):
+                        kk0 = s * 32 + g * 8
+                        if kk0 < K:
+                            tap, cc0 = divmod(kk0, cv); dy, dx = divmod(tap, k)
+                        else:
+                            dy = dx = cc0 = 0
+                        bfrag[s, lane] = xp[t, oy * stride + dy, ox * stride + dx, cc0:cc0 + 8]
+                regs = mfma_tiles(wfrag, bfrag)
+                for lane in range(64):
+                    g, pp = lane >> 4, lane & 15
+                    if ox0 + pp >= Wo:
+                        continue
+                    for mt in range(MT):
+                        co0 = g * 4 * MT + mt * 4
+                        out[t, oy, ox0 + pp, co0:co0 + 4] = regs[mt, lane] + bvec[co0:co0 + 4]
+    if prelu is not None:
+        out = np.where(out >= 0, out, out * prelu)
+    if res is not None:
+        out[..., :res.shape[-1]] += res
+    return out
+
+
+def unit_slabs(T, C, t, mode, wrap):
+    Ch = C // 2
+    f0, o0, f1, o1, fb, ob = t, 0, t, Ch, t, 0
+    if mode == 1:
+        if t > 0 or wrap:
+            f0, o0, f1, o1 = (t - 1) % T, Ch, t, 0; fb, ob = f0, Ch
+        else:
+            fb, ob = t, 0
+    elif mode == 2:
+        if t < T - 1 or wrap:
+            f0, o0, f1, o1 = t, Ch, (t + 1) % T, 0; fb, ob = f1, 0
+        else:
+            fb, ob = t, Ch
+    return f0, o0, f1, o1, fb, ob
+
+
+def shiftconv(x, offs, w1, mode, wrap):
+    """sn_gsts_shiftconv: x [T,h,w,C] -> hw [T,h,w,C/2]."""
+    T, h, w, C = x.shape; Ch = C // 2
+    out = np.zeros((T, h, w, Ch), np.float32)
+    for t in range(T):
+        *_, fb, ob = unit_slabs(T, C, t, mode, wrap)
+        src = np.zeros((h + 20, w + 20, Ch), np.float32)
+        src[10:10 + h, 10:10 + w] = x[fb, :, :, ob:ob + Ch]
+        for k in range(Ch):
+            dy, dx = int(offs[k][0]), int(offs[k][1])
+            for ty in range(3):
+                for tx in range(3):
+                    m = np.zeros((h, w), np.float32)
+                    ys = np.arange(h) + ty - 1; xs = np.arange(w) + tx - 1
+                    m[np.ix_((ys >= 0) & (ys < h), (xs >= 0) & (xs < w))] = 1
+                    sh = src[10 + dy + ty - 1:10 + dy + ty - 1 + h, 10 + dx + tx - 1:10 + dx + tx - 1 + w, k]
+                    out[t, :, :, k] += w1[k, ty * 3 + tx] * m * sh
+    return out
+
+
+def ln_gemm(x, hwb, wfrag, bias, mode, wrap):
+    """sn_ln_gemm: -> a [T,h,w,2C] in storage-position order."""
+    wfrag = frag_to_np(wfrag); MT, KS = wfrag.shape[:2]
+    T, h, w, C = x.shape; Ch = C // 2
+    K = C + Ch if hwb is not None else C
+    a = np.zeros((T, h * w, 2 * C), np.float32)
+    xf = x.reshape(T, h * w, C)
+    hf = hwb.reshape(T, h * w, Ch) if hwb is not None else None
+    for t in range(T):
+        f0, o0, f1, o1, _, _ = unit_slabs(T, C, t, mode, wrap)
+        for i0 in range(0, h * w, 16):
+            bfrag = np.zeros((KS, 64, 8), np.float32)
+            for p in range(16):
+                i = min(i0 + p, h * w - 1)
+                u = np.concatenate([xf[f0, i, o0:o0 + Ch], xf[f1, i, o1:o1 + Ch]] + ([hf[t, i]] if hf is not None else []))
+                mean = u.mean(); var = ((u - mean) ** 2).mean()
+                v = (u - mean) / np.sqrt(var + 1e-6)
+                v = np.concatenate([v, np.zeros(KS * 32 - K, np.float32)])
+                for g in range(4):
+                    for s in range(KS):
+                        bfrag[s, g * 16 + p] = v[s * 32 + g * 8: s * 32 + g * 8 + 8]
+            regs = mfma_tiles(wfrag, bfrag)
+            for lane in range(64):
+                g, p = lane >> 4, lane & 15
+                if i0 + p >= h * w:
+                    continue
+                for mt in range(MT):
+                    pos = g * 4 * MT + mt * 4
+                    a[t, i0 + p, pos:pos + 4] = regs[mt, lane] + bias[pos:pos + 4]
+    return a.reshape(T, h, w, 2 * C)
+
+
+def dw_gate(a, wdw):
+    """sn_dw_gate: a [T,h,w,2C] positions, wdw [9][2C] -> g1 [T,h,w,C] natural."""
+    T, h, w, C2 = a.shape
+    ap = np.zeros((T, h + 2, w + 2, C2), np.float32); ap[:, 1:-1, 1:-1] = a
+    o = np.zeros_like(a)
+    for dy in range(3):
+        for dx in range(3):
+            o += wdw[dy * 3 + dx][None, None, None, :] * ap[:, dy:dy + h, dx:dx + w]
+    o = o.reshape(T, h, w, C2 // 8, 8)
+    return (o[..., :4] * o[..., 4:]).reshape(T, h, w, C2 // 2)
+
+
+def dw_gemm_gate(g1, w5, wfrag, ca_in=None):
+    """sn_dw_gemm_gate -> (g2 [T,h,w,C], channel sums [T,C])."""
+    wfrag = frag_to_np(wfrag); MT, KS = wfrag.shape[:2]
+    T, h, w, C = g1.shape
+    if ca_in is not None:
+        g1 = g1 * ca_in[:, None, None, :]
+    gp = np.zeros((T, h + 4, w + 4, C), np.float32); gp[:, 2:-2, 2:-2] = g1
+    r = np.zeros_like(g1)
+    for dy in range(5):
+        for dx in range(5):
+            r += w5[dy * 5 + dx][None, None, None, :] * gp[:, dy:dy + h, dx:dx + w]
+    rf = r.reshape(T, h * w, C)
+    g2 = np.zeros((T, h * w, C), np.float32)
+    for t in range(T):
+        for i0 in range(0, h * w, 16):
+            bfrag = np.zeros((KS, 64, 8), np.float32)
+            for lane in range(64):
+                g, p = lane >> 4, lane & 15
+                i = min(i0 + p, h * w - 1)
+                for s in range(KS):
+                    kk0 = s * 32 + g * 8
+                    if kk0 < C:
+                        bfrag[s, lane] = rf[t, i, kk0:kk0 + 8]
+            regs = mfma_tiles(wfrag, bfrag)
+            for lane in range(64):
+                g, p = lane >> 4, lane & 15
+                if i0 + p >= h * w:
+                    continue
+                for mp in range(MT // 2):
+                    b1, b2 = regs[2 * mp, lane], regs[2 * mp + 1, lane]
+                    c0 = g * 2 * MT + mp * 4
+                    g2[t, i0 + p, c0:c0 + 4] = b1 / (1.0 + np.exp(-b2))
+    return g2.reshape(T, h, w, C), g2.sum(1)
+
+
+def scale_gemm_res(x, g2, ca, wfrag, bias, mode, wrap):
+    """sn_scale_gemm_res -> y [T,h,w,C]."""
+    wfrag = frag_to_np(wfrag); MT, KS = wfrag.shape[:2]
+    T, h, w, C = x.shape; Ch = C // 2
+    xf = x.reshape(T, h * w, C); gf = g2.reshape(T, h * w, C)
+    y = np.zeros((T, h * w, C), np.float32)
+    for t in range(T):
+        f0, o0, f1, o1, _, _ = unit_slabs(T, C, t, mode, wrap)
+        for i0 in range(0, h * w, 16):
+            bfrag = np.zeros((KS, 64, 8), np.float32)
+            for lane in range(64):
+                g, p = lane >> 4, lane & 15
+                i = min(i0 + p, h * w - 1)
+                for s in range(KS):
+                    kk0 = s * 32 + g * 8
+                    if kk0 < C:
+                        bfrag[s, lane] = gf[t, i, kk0:kk0 + 8] * ca[t, kk0:kk0 + 8]
+            regs = mfma_tiles(wfrag, bfrag)
+            for lane in range(64):
+                g, p = lane >> 4, lane & 15
+                i = i0 + p
+                if i >= h * w:
+                    continue
+                for mt in range(MT):
+                    co0 = g * 4 * MT + mt * 4
+                    sc = xf[f0, i, o0 + co0:o0 + co0 + 4] if co0 < Ch else xf[f1, i, o1 + co0 - Ch:o1 + co0 - Ch + 4]
+                    b = bias[co0:co0 + 4] if bias is not None else 0.0
+                    y[t, i, co0:co0 + 4] = sc + regs[mt, lane] + b
+    return y.reshape(T, h, w, C)

@@ -1,0 +1,82 @@
+"""CPU tests of host logic: C-ABI library exports, drop-in class contract, clip-parallel halo exchange (gloo, world 2)."""
+import os
+import re
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sn_build", os.path.join(ROOT, "shift-net_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    mod.build()                                              # hipcc cross-compiles gfx950 without a GPU
+    from shiftnet_amd import lib as L
+    lib = L.load()
+    header = open(os.path.join(ROOT, "include", "shiftnet_hip.h")).read()
+    declared = sorted(set(re.findall(r"^int (sn_\w+)\(", header, flags=re.M)))
+    assert declared == sorted(L.SYMBOLS), (declared, sorted(L.SYMBOLS))
+    for s in declared:
+        assert hasattr(lib, s)
+    assert lib.sn_abi_version() == 1
+    # argument validation is host side and must not need a GPU
+    assert lib.sn_conv2d(None, None) == -22
+    assert lib.sn_conv_pool_blocks(720, 1280, 1) == 90 * 40
+
+
+def test_dropin_class_contract():
+    from basicsr.models.archs import gshift_deblur1, gshift_deblur2, gshift_denoise1, gshift_denoise2
+    from shiftnet_amd.weights import synth_state_dict
+    for mod, name, pf in ((gshift_deblur1, "gshift_deblur1", (1, 1)), (gshift_deblur2, "gshift_deblur2", (1, 1)),
+                          (gshift_denoise1, "gshift_denoise1", (0, 0)), (gshift_denoise2, "gshift_denoise2", (0, 0))):
+        net = mod.make_model({"pretrain_models_dir": "None"})
+        assert type(net).__name__ == "GShiftNet" and (net.num_fb, net.num_ff) == pf
+        net.load_state_dict(synth_state_dict(name), strict=True)
+        bad = dict(synth_state_dict(name)); bad.pop("conv_last.weight")
+        with pytest.raises(RuntimeError):
+            net.load_state_dict(bad, strict=True)
+        net2 = mod.GShiftNet(future_frames=2, past_frames=2).half()
+        assert next(net2.parameters()).dtype == torch.float16
+        # shared PReLU aliases stay shared through state_dict round trips
+        sd = net.state_dict()
+        assert sd["stage1.act.weight"].data_ptr() == sd["stage1.concat.body.1.weight"].data_ptr()
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            net(torch.zeros(1, 5, 3 if "deblur" in name else 3, 8, 8), *([torch.zeros(1, 5, 1, 8, 8)] if "denoise" in name else []))
+
+
+def test_window_ranges_match_cli_arithmetic():
+    from shiftnet_amd.clip_parallel import window_ranges
+    # test_deblur.py:111-120 with N=100, one_len=48: k_len = 96//48 = 2
+    r = window_ranges(100, 48)
+    assert [(a.start, a.stop, b.start, b.stop) for a, b in r] == [(0, 52, 2, 50), (48, 100, 50, 98)]
+    assert window_ranges(30, 16) == [(range(0, 20), range(2, 18))]      # remainder frames dropped
+    assert window_ranges(4, 16) == []
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _halo_worker(rank, world, port, L):
+    sys.path.insert(0, os.path.join(ROOT, "shift-net_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from shiftnet_amd.clip_parallel import assemble_window
+    n = world * L + 4
+    clip = torch.arange(n * 3 * 4 * 6, dtype=torch.float32).reshape(n, 3, 4, 6)      # frame f is identifiable
+    own = clip[rank * L + 2: rank * L + 2 + L]
+    win = assemble_window(own, clip[:2] if rank == 0 else None, clip[-2:] if rank == world - 1 else None, rank, world)
+    assert torch.equal(win, clip[rank * L: rank * L + L + 4]), rank
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_halo_exchange_world2_gloo():
+    port = _free_port()
+    mp.spawn(_halo_worker, args=(2, port, 5), nprocs=2, join=True)
