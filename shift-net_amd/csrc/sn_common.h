@@ -58,6 +58,9 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __ex
 // wave-uniform wave index (threadIdx-derived values are "divergent" to the compiler; make it provably uniform)
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
+// hipGetLastError() is per-thread sticky state that other libraries in the process (PyTorch's allocator polling
+// events, ...) may leave set; every entry point therefore clears it BEFORE launching and reads it right after.
+static inline void sn_clear_error() { (void)hipGetLastError(); }
 static inline int sn_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? SN_OK : SN_ELAUNCH;

@@ -300,11 +300,13 @@ extern "C" {
 int sn_abi_version(void) { return SN_ABI_VERSION; }
 
 int sn_selftest_mfma(const float* a, const float* b, float* d, void* stream) {
+    sn_clear_error();
     hipLaunchKernelGGL(selftest_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, d);
     return sn_check_launch();
 }
 
 int sn_ingest(const void* src, int dt, const void* noise, void* dst, int T, int C, int H, int W, void* stream) {
+    sn_clear_error();
     if (!src || !dst || C < 1 || C + (noise ? 1 : 0) > 8 || dt < 0 || dt > 2) return SN_EINVAL;
     const int hw = H * W;
     hipLaunchKernelGGL(ingest_kernel, dim3((hw + 255) / 256, T), dim3(256), 0, (hipStream_t)stream, src, dt, noise, (uint4*)dst, C, hw);
@@ -317,6 +319,7 @@ int sn_conv_pool_blocks(int h_out, int w_out, int stride) {
 }
 
 int sn_conv2d(const sn_conv_desc* d, void* stream) {
+    sn_clear_error();
     if (!d || d->n_in < 1 || d->n_in > 3 || (d->cs_in & 7) || (d->cs_out & 7) || !d->wfrag || !d->out) return SN_EINVAL;
     if (d->k < 1 || d->k > 5 || (d->stride != 1 && d->stride != 2) || d->mt < 1 || d->mt > 6 || d->ks < 1) return SN_EINVAL;
     if (d->in_mode == 1 && ((d->h_in | d->w_in) & 1)) return SN_EINVAL;
@@ -339,12 +342,14 @@ int sn_conv2d(const sn_conv_desc* d, void* stream) {
 
 int sn_ca_mlp(const float* partial, int nblk, int cpad, int c, int cr, float inv_hw,
               const float* wa, const float* wb, float* ca, int T, void* stream) {
+    sn_clear_error();
     if (!partial || !wa || !wb || !ca || cpad < 16 || cpad > 128 || c > cpad || cr > 128 || cr < 1 || nblk < 1) return SN_EINVAL;
     hipLaunchKernelGGL(ca_mlp_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, partial, nblk, cpad, c, cr, inv_hw, wa, wb, ca);
     return sn_check_launch();
 }
 
 int sn_scale_residual(const void* res, const void* x, const float* ca, int cpad, void* out, int T, int hw, int cs, void* stream) {
+    sn_clear_error();
     if (!res || !x || !ca || !out || (cs & 7) || cs > cpad) return SN_EINVAL;
     const size_t n = (size_t)hw * (cs >> 3);
     int gx = (int)((n + 255) / 256); if (gx > 2048) gx = 2048;

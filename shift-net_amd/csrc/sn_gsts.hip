@@ -435,18 +435,21 @@ bool unit_ok(const sn_unit_src* s) {
 extern "C" {
 
 int sn_gsts_gather(const sn_unit_src* s, const int8_t* offs, void* u, void* stream) {
+    sn_clear_error();
     if (!unit_ok(s) || !offs || !u || s->mode == 0) return SN_EINVAL;
     hipLaunchKernelGGL(gather_kernel, dim3(1024, s->T), dim3(256), 0, (hipStream_t)stream, to_k(s), offs, (bf16_t*)u, s->C + s->C / 2);
     return sn_check_launch();
 }
 
 int sn_temporal_roll(const sn_unit_src* s, void* y, void* stream) {
+    sn_clear_error();
     if (!s || !s->x || !y || y == s->x || (s->C & 1) || s->mode < 1 || s->mode > 2 || s->T < 1) return SN_EINVAL;
     hipLaunchKernelGGL(gather_kernel, dim3(1024, s->T), dim3(256), 0, (hipStream_t)stream, to_k(s), (const int8_t*)nullptr, (bf16_t*)y, s->C);
     return sn_check_launch();
 }
 
 int sn_gsts_shiftconv(const sn_unit_src* s, const int8_t* offs, const float* w1, void* hw, void* stream) {
+    sn_clear_error();
     if (!unit_ok(s) || !offs || !w1 || !hw || s->mode == 0) return SN_EINVAL;
     dim3 grid((s->w + 15) / 16, (s->h + 15) / 16, s->T);
     if (s->C == 64) {
@@ -462,6 +465,7 @@ int sn_gsts_shiftconv(const sn_unit_src* s, const int8_t* offs, const float* w1,
 }
 
 int sn_ln_gemm(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, void* a, void* stream) {
+    sn_clear_error();
     if (!unit_ok(s) || !wfrag || !bias || !a || (s->mode != 0 && !hw)) return SN_EINVAL;
     const int npx = s->h * s->w;
     dim3 grid((npx + 255) / 256, s->T);
@@ -480,6 +484,7 @@ int sn_ln_gemm(const sn_unit_src* s, const void* hw, const void* wfrag, const fl
 int sn_dwgate_blocks(int h, int w) { return ((h + 7) / 8) * ((w + 63) / 64); }
 
 int sn_dw_gate(const void* a, const float* w, void* g1, float* pool, int T, int h, int w_, int C, void* stream) {
+    sn_clear_error();
     if (!a || !w || !g1 || (C != 64 && C != 80)) return SN_EINVAL;
     dim3 grid((w_ + 63) / 64, (h + 7) / 8, T);
     if (C == 64) hipLaunchKernelGGL(dw_gate_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, w, (bf16_t*)g1, pool, h, w_);
@@ -491,6 +496,7 @@ int sn_dwgemm_blocks(int h, int w) { return ((h + 3) / 4) * ((w + 63) / 64); }
 
 int sn_dw_gemm_gate(const void* g1, const float* ca_in, const float* w5, const void* wfrag, void* g2, float* pool,
                     int T, int h, int w, int C, void* stream) {
+    sn_clear_error();
     if (!g1 || !w5 || !wfrag || !g2 || (C != 64 && C != 80)) return SN_EINVAL;
     dim3 grid((w + 63) / 64, (h + 3) / 4, T);
     const size_t lds = 256 * (C * 2 + 16) + 4 * C * sizeof(float);
@@ -501,6 +507,7 @@ int sn_dw_gemm_gate(const void* g1, const float* ca_in, const float* w5, const v
 
 int sn_scale_gemm_res(const sn_unit_src* s, const void* g2, const float* ca, const void* wfrag, const float* bias,
                       void* y, void* stream) {
+    sn_clear_error();
     if (!unit_ok(s) || !g2 || !ca || !wfrag || !y || y == s->x) return SN_EINVAL;
     const int npx = s->h * s->w;
     dim3 grid((npx + 255) / 256, s->T);

@@ -51,6 +51,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own libamdhip64; it must be mapped BEFORE our library so that both bind to the same HIP
+    # runtime (a second runtime in the process owns different streams/contexts and every launch fails).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ShiftNetLibError(
             f"{LIB_PATH} not found: build it with `python shift-net_amd/build.py` (hipcc, gfx950). "

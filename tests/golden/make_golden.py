@@ -51,6 +51,19 @@ def clip_tensor(frames_u8):
     return torch.stack(ts).unsqueeze(0)
 
 
+def psnr(a, b):
+    mse = (a.float() - b.float()).pow(2).mean().item()
+    return 99.0 if mse == 0 else 10 * np.log10(1.0 / mse)
+
+
+def bf16_run(mod, name, pf, x, nm):
+    """The reference's OWN CPU bf16 run (net.bfloat16()): the precision yardstick for the bf16 HIP path."""
+    nb = mod.GShiftNet(future_frames=pf[1], past_frames=pf[0])
+    nb.load_state_dict(synth_state_dict(name, SEED), strict=True)
+    nb = nb.eval().bfloat16()
+    return (nb(x.bfloat16(), nm.bfloat16()) if nm is not None else nb(x.bfloat16())).float()
+
+
 def main():
     torch.set_grad_enabled(False)
     torch.manual_seed(0)
@@ -126,6 +139,7 @@ def main():
             else:
                 y = net(xin)
             res[tag] = y.numpy()
+            res[tag + "_ref_bf16_psnr"] = np.float32(psnr(bf16_run(mod, name, pf, xin, nm if V.denoise else None), y))
         np.savez_compressed(f"{HERE}/net_{name}.npz", **res)
         print(name, "done", {k: getattr(v, "shape", v) for k, v in res.items()})
 
@@ -135,20 +149,24 @@ def main():
     net.load_state_dict(synth_state_dict(name, SEED), strict=True)
     net.eval()
     blur, sharp = synth.blurred_clip(5, 256, 256, seed=5)
+    mod2 = load_ref(name)
     y = net(clip_tensor(blur))
-    np.savez_compressed(f"{HERE}/config1_{name}.npz", in_crc=np.uint32(synth.crc(blur)), out=y.numpy())
+    np.savez_compressed(f"{HERE}/config1_{name}.npz", in_crc=np.uint32(synth.crc(blur)), out=y.numpy(),
+                        ref_bf16_psnr=np.float32(psnr(bf16_run(mod2, name, (2, 2), clip_tensor(blur), None), y)))
 
     # ---- F. CLI windowing: 12 frames, one_len=4 (test_deblur.py:111-137) -------------
     blur, sharp = synth.blurred_clip(12, 32, 40, seed=7)
     one_len = 4
     k_len = (12 - 4) // one_len
-    outs, win = [], []
+    outs, win, outs_b = [], [], []
     for kk in range(k_len):
         lo, hi = kk * one_len, kk * one_len + one_len + 4
         win.append([lo, hi, kk * one_len + 2, kk * one_len + 2 + one_len])
         outs.append(net(clip_tensor(blur[lo:hi])).numpy())
+        outs_b.append(bf16_run(mod2, name, (2, 2), clip_tensor(blur[lo:hi]), None).numpy())
     np.savez_compressed(f"{HERE}/windows_{name}.npz", in_crc=np.uint32(synth.crc(blur)),
-                        windows=np.array(win, np.int32), out=np.concatenate(outs, 0))
+                        windows=np.array(win, np.int32), out=np.concatenate(outs, 0),
+                        ref_bf16_psnr=np.float32(psnr(torch.from_numpy(np.concatenate(outs_b, 0)), torch.from_numpy(np.concatenate(outs, 0)))))
     print("all fixtures written to", HERE)
 
 
