@@ -120,6 +120,17 @@ int sn_dw_gemm_gate(const void* g1, const float* ca_in, const float* w5, const v
                     int T, int h, int w, int C, void* stream);
 int sn_dwgemm_blocks(int h, int w);
 
+/* Fused sn_ln_gemm + sn_dw_gate: g1 = SimpleGate(RepConv2(body[0](norm(cat(shortcut, hw))))) with the 2C-channel
+ * intermediate kept in LDS (gshift_deblur1.py:190-198,225-233).  Same weight layouts as the two kernels it replaces.
+ * pool: NULL or [T][sn_lngate_blocks][C]. */
+int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, const float* wdw,
+                    void* g1, float* pool, void* stream);
+int sn_lngate_blocks(int h, int w);
+
+/* sn_dw_gemm_gate for the depthwise variants (C = 64) with the g1 tile staged through LDS; pool: [T][sn_dwgemm_blocks][C]. */
+int sn_dw5_gemm_gate(const void* g1, const float* ca_in, const float* w5, const void* wfrag, void* g2, float* pool,
+                     int T, int h, int w, int C, void* stream);
+
 /* y = shortcut + beta * body[7](ca * g2) (gshift_deblur1.py:201,210,254): beta and the optional bias are folded
  * into wfrag/bias; the shortcut is the ROLLED tensor for CAB2 (mode 1/2) and x for CAB1 (mode 0). */
 int sn_scale_gemm_res(const sn_unit_src* s, const void* g2, const float* ca, const void* wfrag, const float* bias,

@@ -53,7 +53,8 @@ __device__ __forceinline__ f32x4_t mfma16(const bf16x8_t a, const bf16x8_t b, co
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each): the IEEE division sequence costs ~10 VALU instructions per element
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // wave-uniform wave index (threadIdx-derived values are "divergent" to the compiler; make it provably uniform)
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }

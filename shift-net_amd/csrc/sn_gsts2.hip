@@ -1,0 +1,325 @@
+// Second-generation GSTS kernels (gfx950): fewer passes over HBM, stencils fed from LDS.
+//
+//   sn_ln_gemm_gate   (K12): g1 = SimpleGate(RepConv2(body[0](norm(u))))  -- LayerNorm + 1x1 (MFMA) + depthwise 3x3 +
+//                      gate in ONE kernel; the 2C-channel tensor `a` (the widest tensor of the block) never reaches HBM.
+//                      One workgroup owns an 8x32 output tile; LN+GEMM run on the tile plus a 1-pixel ring (340 px,
+//                      1.33x recompute); `a` goes to LDS 32 channels at a time (gate-paired chunks), the normalised
+//                      operands stay in registers as MFMA B fragments for the whole chunk loop.
+//   sn_dw5_gemm_gate  (K3'): g2 = SimpleGate2(body[4](RepConv(g1))) for the depthwise variants (C = 64): the g1 tile
+//                      (+2 ring) is staged in LDS 32 channels at a time, the 5x5 stencil runs with lane = pixel column
+//                      and a wave-uniform channel block (weights are scalar loads), its output feeds the MFMA k-step
+//                      of those 32 channels straight from LDS; accumulators persist across the two passes.
+#include "sn_common.h"
+#include "../../include/shiftnet_hip.h"
+
+namespace {
+
+struct UnitK2 {
+    const bf16_t* x;
+    int T, h, w, C, mode, wrap;
+};
+
+struct Slabs2 { int f0, o0, f1, o1; };
+
+__device__ __forceinline__ Slabs2 unit_slabs2(const UnitK2& U, int t) {
+    const int Ch = U.C >> 1;
+    Slabs2 s; s.f0 = t; s.o0 = 0; s.f1 = t; s.o1 = Ch;
+    if (U.mode == 1) { if (t > 0 || U.wrap) { s.f0 = (t - 1 + U.T) % U.T; s.o0 = Ch; s.f1 = t; s.o1 = 0; } }
+    else if (U.mode == 2) { if (t < U.T - 1 || U.wrap) { s.f0 = t; s.o0 = Ch; s.f1 = (t + 1) % U.T; s.o1 = 0; } }
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+template <int C, bool WITH_HW>
+__global__ __launch_bounds__(256) void ln_gemm_gate_kernel(const UnitK2 U, const bf16_t* __restrict__ hwb, const uint4* __restrict__ wfrag,
+                                                         const float* __restrict__ bias, const float* __restrict__ wdw,
+                                                         bf16_t* g1, float* pool) {
+    constexpr int CH = C / 2, K = WITH_HW ? C + CH : C, KS = (K + 31) / 32, MT = C / 8, NCHK = MT / 2;
+    constexpr int TH = 8, TW = 32, RH = TH + 2, RW = TW + 2, NPX = RH * RW;        // 340 pixels incl. the 1-pixel ring
+    constexpr int NTILES = (NPX + 15) / 16, NTW = (NTILES + 3) / 4;                // 22 N-tiles, <= 6 per wave
+    constexpr int PSA = 80;                                                        // LDS bytes per pixel of an a-chunk (64 + 16 pad)
+    __shared__ __attribute__((aligned(16))) char lds_a[NPX * PSA];
+    const int lane = threadIdx.x & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
+    const int t = blockIdx.z, oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+    const int hw = U.h * U.w;
+    const Slabs2 sl = unit_slabs2(U, t);
+
+    // ---- LayerNorm of every pixel of the ring-extended tile; results stay in registers as MFMA B fragments ----
+    bf16x8_t B[NTW][KS];
+    bool inimg[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        const int tile = wv + 4 * n;
+        const int rp = tile * 16 + p;                         // pixel index inside the region
+        const int ry = rp / RW, rx = rp - ry * RW;
+        const int gy = oy0 - 1 + ry, gx = ox0 - 1 + rx;
+        const bool in = (tile < NTILES) && (rp < NPX) && gy >= 0 && gy < U.h && gx >= 0 && gx < U.w;
+        inimg[n] = in;
+        const int ii = in ? gy * U.w + gx : 0;
+        float xv[KS][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int kk0 = s * 32 + g * 8;
+            const bf16_t* src = nullptr;
+            if (kk0 < CH) src = U.x + ((size_t)sl.f0 * hw + ii) * C + sl.o0 + kk0;
+            else if (kk0 < C) src = U.x + ((size_t)sl.f1 * hw + ii) * C + sl.o1 + kk0 - CH;
+            else if (WITH_HW && kk0 < K) src = hwb + ((size_t)t * hw + ii) * CH + kk0 - C;
+            if (src) {
+                unpack8(*(const uint4*)src, xv[s]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum += xv[s][j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[s][j] = 0.f;
+            }
+        }
+        sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / K);
+        float sq = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bool has = (s * 32 + g * 8) < K;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = has ? xv[s][j] - mean : 0.f;
+                xv[s][j] = d; sq += d * d;
+            }
+        }
+        sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / K) + 1e-6f);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[s][j] *= rstd;
+            B[n][s] = as_frag(pack8(xv[s]));
+        }
+    }
+
+    float psum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int q = 0; q < NCHK; ++q) {
+        // ---- GEMM chunk q: rows 2q (first-half channels) and 2q+1 (their gate partners) -> LDS, zero outside the image
+        {
+            f32x4_t acc0[NTW], acc1[NTW];
+            const float4 b0 = *(const float4*)(bias + g * 4 * MT + (2 * q) * 4);
+            const float4 b1 = *(const float4*)(bias + g * 4 * MT + (2 * q + 1) * 4);
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) { acc0[n] = (f32x4_t){b0.x, b0.y, b0.z, b0.w}; acc1[n] = (f32x4_t){b1.x, b1.y, b1.z, b1.w}; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8_t a0 = as_frag(wfrag[((2 * q) * KS + s) * 64 + lane]);
+                const bf16x8_t a1 = as_frag(wfrag[((2 * q + 1) * KS + s) * 64 + lane]);
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) { acc0[n] = mfma16(a0, B[n][s], acc0[n]); acc1[n] = mfma16(a1, B[n][s], acc1[n]); }
+            }
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const int rp = (wv + 4 * n) * 16 + p;
+                if (rp < NPX && (wv + 4 * n) < NTILES) {
+                    uint4 o = make_uint4(0, 0, 0, 0);
+                    if (inimg[n]) {
+                        o.x = pack_bf2(acc0[n][0], acc0[n][1]); o.y = pack_bf2(acc0[n][2], acc0[n][3]);
+                        o.z = pack_bf2(acc1[n][0], acc1[n][1]); o.w = pack_bf2(acc1[n][2], acc1[n][3]);
+                    }
+                    *(uint4*)(lds_a + rp * PSA + g * 16) = o;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- depthwise 3x3 (+identity) and gate: wave wv owns lane-group slot wv of the chunk, lanes are pixels ----
+        {
+            float wt[9][8];
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wt[tp][j] = wdw[tp * (2 * C) + wv * 4 * MT + q * 8 + j];
+#pragma unroll
+            for (int it = 0; it < (TH * TW) / 64; ++it) {
+                const int op = it * 64 + lane, oy = op / TW, ox = op - oy * TW;
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll
+                for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx) {
+                        float v[8];
+                        unpack8(*(const uint4*)(lds_a + ((oy + ty) * RW + ox + tx) * PSA + wv * 16), v);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] += wt[ty * 3 + tx][j] * v[j];
+                    }
+                const int gy = oy0 + oy, gx = ox0 + ox;
+                if (gy < U.h && gx < U.w) {
+                    const float r0 = o[0] * o[4], r1 = o[1] * o[5], r2 = o[2] * o[6], r3 = o[3] * o[7];
+                    uint2 qv; qv.x = pack_bf2(r0, r1); qv.y = pack_bf2(r2, r3);
+                    *(uint2*)(g1 + ((size_t)t * hw + (size_t)gy * U.w + gx) * C + wv * 2 * MT + q * 4) = qv;
+                    psum[0] += r0; psum[1] += r1; psum[2] += r2; psum[3] += r3;
+                }
+            }
+            if (pool) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float s = psum[j];
+                    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+                    s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+                    if (lane == 0) {
+                        const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
+                        pool[((size_t)t * nblk + blk) * C + wv * 2 * MT + q * 4 + j] = s;
+                    }
+                    psum[j] = 0.f;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K3' (C = 64, depthwise RepConv): tile 64 x 4 pixels, two passes of 32 channels.
+__global__ __launch_bounds__(256) void dw5_gemm_gate_kernel(const bf16_t* __restrict__ g1, const float* __restrict__ ca_in,
+                                                          const float* __restrict__ w5, const uint4* __restrict__ wfrag,
+                                                          bf16_t* g2, float* pool, int h, int w) {
+    constexpr int C = 64, TY = 4, TXW = 64, RH = TY + 4, RW = TXW + 4, PS = 80, MT = 8, NT = 4;
+    __shared__ __attribute__((aligned(16))) char lds_g[RH * RW * PS];      // 43520 B: g1 region, 32 channels
+    __shared__ __attribute__((aligned(16))) char lds_r[TY * TXW * PS];     // 20480 B: stencil output, 32 channels
+    __shared__ float red[4 * C];
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
+    const int t = blockIdx.z, y0 = blockIdx.y * TY, x0 = blockIdx.x * TXW;
+    const bf16_t* gt = g1 + (size_t)t * h * w * C;
+
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        // ---- stage g1[region][pass*32 .. +32) ----
+        for (int idx = tid; idx < RH * RW * 4; idx += 256) {
+            const int pix = idx >> 2, pc = idx & 3;
+            const int ry = pix / RW, rx = pix - ry * RW;
+            const int gy = y0 - 2 + ry, gx = x0 - 2 + rx;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gy >= 0 && gy < h && gx >= 0 && gx < w) v = *(const uint4*)(gt + ((size_t)gy * w + gx) * C + pass * 32 + pc * 8);
+            *(uint4*)(lds_g + pix * PS + pc * 16) = v;
+        }
+        __syncthreads();
+        // ---- 5x5 stencil: wave wv owns channels [pass*32 + wv*8, +8), lane = pixel column, 4 output rows ----
+        {
+            const int cb = pass * 4 + wv;
+            float sc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sc[j] = ca_in ? ca_in[(size_t)t * C + cb * 8 + j] : 1.f;
+            float r[TY][8];
+#pragma unroll
+            for (int oy = 0; oy < TY; ++oy)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[oy][j] = 0.f;
+            // dx outermost: only the 5 x 8 weights of one kernel column are live at a time (40 SGPRs, no spills),
+            // each staged value is read and unpacked once per dx and feeds up to 4 output rows.
+#pragma unroll 1
+            for (int dx = 0; dx < 5; ++dx) {
+                float wcol[5][8];
+#pragma unroll
+                for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) wcol[dy][j] = w5[(dy * 5 + dx) * C + cb * 8 + j];
+#pragma unroll
+                for (int iy = 0; iy < RH; ++iy) {
+                    float v[8];
+                    unpack8(*(const uint4*)(lds_g + (iy * RW + lane + dx) * PS + wv * 16), v);
+#pragma unroll
+                    for (int oy = 0; oy < TY; ++oy) {
+                        const int dy = iy - oy;
+                        if (dy >= 0 && dy < 5) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) r[oy][j] += wcol[dy][j] * v[j];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int oy = 0; oy < TY; ++oy) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[oy][j] *= sc[j];
+                *(uint4*)(lds_r + (oy * TXW + lane) * PS + wv * 16) = pack8(r[oy]);
+            }
+        }
+        __syncthreads();
+        // ---- MFMA k-step `pass`: wave wv owns tile row wv (4 N-tiles of 16 pixels) ----
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const bf16x8_t b = as_frag(*(const uint4*)(lds_r + (wv * TXW + n * 16 + p) * PS + g * 16));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const bf16x8_t a = as_frag(wfrag[(m * 2 + pass) * 64 + lane]);
+                acc[m][n] = mfma16(a, b, acc[m][n]);
+            }
+        }
+        // the next pass's staging writes lds_g only; lds_r is rewritten after the next __syncthreads()
+    }
+
+    const int oy = y0 + wv;
+#pragma unroll
+    for (int mp = 0; mp < MT / 2; ++mp) {
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int ox = x0 + n * 16 + p;
+            if (oy < h && ox < w) {
+                float v[4];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) { v[rr] = acc[2 * mp][n][rr] * sigmoidf_(acc[2 * mp + 1][n][rr]); ps[rr] += v[rr]; }
+                uint2 qv; qv.x = pack_bf2(v[0], v[1]); qv.y = pack_bf2(v[2], v[3]);
+                *(uint2*)(g2 + (((size_t)t * h + oy) * w + ox) * C + g * 2 * MT + mp * 4) = qv;
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            float s = ps[rr];
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+            if (p == 0) red[wv * C + g * 2 * MT + mp * 4 + rr] = s;
+        }
+    }
+    __syncthreads();
+    if (pool && tid < C) {
+        const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
+        pool[((size_t)t * nblk + blk) * C + tid] = red[tid] + red[C + tid] + red[2 * C + tid] + red[3 * C + tid];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int sn_lngate_blocks(int h, int w) { return ((h + 7) / 8) * ((w + 31) / 32); }
+
+int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, const float* wdw,
+                    void* g1, float* pool, void* stream) {
+    sn_clear_error();
+    if (!s || !s->x || (s->C != 64 && s->C != 80) || s->mode < 0 || s->mode > 2 || !wfrag || !bias || !wdw || !g1 ||
+        (s->mode != 0 && !hw)) return SN_EINVAL;
+    UnitK2 u; u.x = (const bf16_t*)s->x; u.T = s->T; u.h = s->h; u.w = s->w; u.C = s->C; u.mode = s->mode; u.wrap = s->wrap;
+    dim3 grid((s->w + 31) / 32, (s->h + 7) / 8, s->T);
+    hipStream_t st = (hipStream_t)stream;
+#define SN_LAUNCH_K12(CC, HW_) hipLaunchKernelGGL((ln_gemm_gate_kernel<CC, HW_>), grid, dim3(256), 0, st, u, (const bf16_t*)hw, \
+        (const uint4*)wfrag, bias, wdw, (bf16_t*)g1, pool)
+    if (s->C == 64) { if (s->mode) SN_LAUNCH_K12(64, true); else SN_LAUNCH_K12(64, false); }
+    else { if (s->mode) SN_LAUNCH_K12(80, true); else SN_LAUNCH_K12(80, false); }
+#undef SN_LAUNCH_K12
+    return sn_check_launch();
+}
+
+int sn_dw5_gemm_gate(const void* g1, const float* ca_in, const float* w5, const void* wfrag, void* g2, float* pool,
+                     int T, int h, int w, int C, void* stream) {
+    sn_clear_error();
+    if (!g1 || !w5 || !wfrag || !g2 || C != 64) return SN_EINVAL;
+    dim3 grid((w + 63) / 64, (h + 3) / 4, T);
+    hipLaunchKernelGGL(dw5_gemm_gate_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g1, ca_in, w5,
+                       (const uint4*)wfrag, (bf16_t*)g2, pool, h, w);
+    return sn_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,240 @@
+"""The reference's inference CLIs (inference/test_{deblur,deblur_small,denoise,denoise_small}.py) on the HIP path.
+
+Same flags, directory layout, window arithmetic, metric definitions and log line formats as upstream
+(test_deblur.py:91-177,271-291 ; test_denoise.py:91-232,318-351), plus:
+  --synthetic H W N   run on an in-memory synthetic clip (no dataset ships with the reference, none can be fetched here)
+  --checkpoint PATH   override the checkpoint; 'synthetic' uses the deterministic synthetic weights
+  --dtype {fp16,bf16,fp32}  I/O dtype of the module (upstream: fp16 except the "+" denoiser); kernels store bf16 either way
+Image I/O uses PIL (imageio / cv2 / skimage are not in this image); PSNR / SSIM restate the upstream formulas.
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import math
+import os
+import time
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import synth
+from .arch import CLASSES
+from .clip_parallel import window_ranges
+from .weights import synth_state_dict
+
+DTYPES = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}
+
+
+class TraverseLogger:
+    def __init__(self, result_dir: str, filename: str) -> None:
+        self.path = os.path.join(result_dir, filename)
+        self.f = open(self.path, "a" if os.path.exists(self.path) else "w")
+
+    def write_log(self, log: str) -> None:
+        print(log)
+        self.f.write(log + "\n")
+        self.f.flush()
+
+
+def read_image(path: str) -> np.ndarray:
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("RGB"))
+
+
+def write_image(path: str, img_rgb_float: np.ndarray) -> None:
+    from PIL import Image
+    Image.fromarray(np.clip(img_rgb_float, 0, 255).astype(np.uint8)).save(path)      # cv2.imwrite truncates floats
+
+
+def psnr_255(img: np.ndarray, gt: np.ndarray) -> float:
+    """skimage PSNR with data_range=255 on an un-rounded float image vs the uint8 GT (test_deblur.py:142)."""
+    mse = float(np.mean((img.astype(np.float64) - gt.astype(np.float64)) ** 2))
+    return float("inf") if mse == 0 else 10.0 * math.log10(255.0 ** 2 / mse)
+
+
+def ssim_calculate(img1: np.ndarray, img2: np.ndarray, sd: float = 1.5, c1: float = 0.01 ** 2, c2: float = 0.03 ** 2) -> float:
+    """The CLI's own SSIM (test_deblur.py:25-49): Gaussian statistics over the (C,H,W) volume, inputs / 255."""
+    from scipy.ndimage import gaussian_filter
+    a = np.array(img1, dtype=np.float32).transpose(2, 0, 1) / 255
+    b = np.array(img2, dtype=np.float32).transpose(2, 0, 1) / 255
+    mu1, mu2 = gaussian_filter(a, sd), gaussian_filter(b, sd)
+    s1 = gaussian_filter(a * a, sd) - mu1 * mu1
+    s2 = gaussian_filter(b * b, sd) - mu2 * mu2
+    s12 = gaussian_filter(a * b, sd) - mu1 * mu2
+    return float(np.mean(((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 * mu1 + mu2 * mu2 + c1) * (s1 + s2 + c2))))
+
+
+def numpy2tensor(frames: Sequence[np.ndarray]) -> torch.Tensor:
+    """uint8 HWC frames -> [1,T,3,H,W] float32 in [0,1] (numpy2tensor, test_deblur.py:191-200)."""
+    ts = [torch.from_numpy(np.ascontiguousarray(np.asarray(f).astype("float64").transpose(2, 0, 1))).float().mul_(1.0 / 255)
+          for f in frames]
+    return torch.stack(ts).unsqueeze(0)
+
+
+def denoise_windows(n_frames: int) -> List[Tuple[int, int, int]]:
+    """(first input frame, number of restored frames, residual appended) per window (test_denoise.py:111-133)."""
+    one_len = n_frames - 4
+    if one_len > 100:
+        one_len //= 2
+    k_len = (n_frames - 4) // one_len
+    k_res = (n_frames - 4) % one_len
+    return [(kk * one_len, one_len + (k_res if kk == k_len - 1 else 0), k_res if kk == k_len - 1 else 0) for kk in range(k_len)]
+
+
+def quadrant_forward(net, x: torch.Tensor, sigma: float) -> torch.Tensor:
+    """The denoise CLI's 4 overlapping quadrants (test_denoise.py:153-173); x:[1,N,3,H,W] on device."""
+    B, N, _, H, W = x.shape
+    pad_h, pad = 32 - (H // 2 % 16), 32 - (W // 2 % 16)
+    hh, ww = H // 2 + pad_h, W // 2 + pad
+    std = torch.full((1, 1, 1, 1, 1), sigma, dtype=x.dtype, device=x.device).expand(B, N, 1, hh, ww)
+    out = torch.zeros(N - 4, 3, H, W)
+    o1 = net(x[:, :, :, 0:hh, 0:ww].contiguous(), std).float().cpu()
+    o2 = net(x[:, :, :, 0:hh, W // 2 - pad:].contiguous(), std).float().cpu()
+    o3 = net(x[:, :, :, H // 2 - pad_h:, 0:ww].contiguous(), std).float().cpu()
+    o4 = net(x[:, :, :, H // 2 - pad_h:, W // 2 - pad:].contiguous(), std).float().cpu()
+    out[..., 0:H // 2, 0:W // 2] = o1[..., 0:-pad_h, 0:-pad]
+    out[..., 0:H // 2, W // 2:] = o2[..., 0:-pad_h, pad:]
+    out[..., H // 2:, 0:W // 2] = o3[..., pad_h:, 0:-pad]
+    out[..., H // 2:, W // 2:] = o4[..., pad_h:, pad:]
+    return out
+
+
+class Inference:
+    def __init__(self, args, variant: str) -> None:
+        self.args = args
+        self.variant = variant
+        self.denoise = "denoise" in variant
+        self.result_path = args.result_path
+        os.makedirs(self.result_path, exist_ok=True)
+        now = time.strftime("%Y-%m-%d %H:%M:%S", time.localtime())
+        self.logger = TraverseLogger(self.result_path, "inference_log_{}.txt".format(now))
+        for k, v in (("Inference -", now), ("save_image:", args.save_image), ("border:", args.border), ("model_path:", args.model_path),
+                     ("data_path:", args.data_path), ("result_path:", args.result_path), ("n_seq:", 4 if self.denoise else 5),
+                     ("size_must_mode:", 4), ("device:", "cuda")):
+            self.logger.write_log("{} {}".format(k, v))
+        self.net = CLASSES[variant](future_frames=2, past_frames=2)
+        if args.model_path == "synthetic":
+            self.net.load_state_dict(synth_state_dict(variant), strict=True)
+        else:
+            self.net.load_state_dict(torch.load(args.model_path, map_location="cpu")["params"])
+        self.dtype = DTYPES[args.dtype]
+        self.net = self.net.to(self.dtype).to("cuda").eval()
+        self.logger.write_log("Loading model from {}".format(args.model_path))
+
+    # --- clip sources ---------------------------------------------------------------------------------------
+    def videos(self):
+        a = self.args
+        if a.synthetic:
+            h, w, n = a.synthetic
+            blur, sharp = synth.blurred_clip(n, h, w, seed=0)
+            yield "synthetic", (list(sharp) if self.denoise else list(blur)), list(sharp)
+            return
+        in_dir = a.data_path if self.denoise else os.path.join(a.data_path, "blur")
+        for v in sorted(os.listdir(in_dir)):
+            ins = sorted(glob.glob(os.path.join(in_dir, v, "*")))
+            gts = ins if self.denoise else sorted(glob.glob(os.path.join(a.data_path, "gt", v, "*")))
+            yield v, ins, gts
+
+    @staticmethod
+    def _load(items):
+        return [read_image(p) if isinstance(p, str) else p for p in items]
+
+    # --- main loop (test_deblur.py:91-177 / test_denoise.py:91-232) ---------------------------------------------
+    @torch.no_grad()
+    def infer(self) -> Tuple[float, float]:
+        a = self.args
+        total_psnr, total_ssim = {}, {}
+        for v, ins, gts in self.videos():
+            vp, vs = [], []
+            index = 0
+            if self.denoise:
+                wins = [(s, n, s + 2) for s, n, _ in denoise_windows(len(ins))]
+            else:
+                wins = [(r_in.start, len(r_out), r_out.start) for r_in, r_out in window_ranges(len(ins), a.one_len)]
+            for start, n_out, gt0 in wins:
+                t0 = time.time()
+                inputs = self._load(ins[start:start + n_out + 4])
+                gtf = self._load(gts[gt0:gt0 + n_out])
+                h, w, _ = inputs[2].shape
+                nh, nw = h - h % 4, w - w % 4
+                inputs = [im[:nh, :nw] for im in inputs]
+                gtf = [im[:nh, :nw] for im in gtf]
+                x = numpy2tensor(inputs)
+                name = os.path.basename(ins[start + 2]).split(".")[0] if isinstance(ins[start + 2], str) else "%05d" % (start + 2)
+                if self.denoise:
+                    sigma = a.sigma / 255.0
+                    x = x + torch.empty_like(x).normal_(mean=0, std=sigma)
+                    x = x.to("cuda").to(self.dtype)
+                    t1 = time.time()
+                    output = quadrant_forward(self.net, x, sigma)
+                else:
+                    x = x.to("cuda").to(self.dtype)
+                    t1 = time.time()
+                    output = self.net(x).float()
+                torch.cuda.synchronize()
+                t2 = time.time()
+                psnr = ssim = float("nan")
+                for e in range(n_out):
+                    img = output[e].clamp(0, 1.0).permute(1, 2, 0).cpu().numpy() * 255
+                    psnr, ssim = psnr_255(img, gtf[e]), ssim_calculate(img, gtf[e])
+                    vp.append(psnr); vs.append(ssim)
+                    if a.save_image:
+                        os.makedirs(os.path.join(self.result_path, v), exist_ok=True)
+                        write_image(os.path.join(self.result_path, v, "%03d.png" % index), img)
+                    index += 1
+                t3 = time.time()
+                del output, x
+                torch.cuda.empty_cache()
+                self.logger.write_log(
+                    "> {}-{} PSNR={:.5}, SSIM={:.4} pre_time:{:.3}s, forward_time:{:.3}s, post_time:{:.3}s, total_time:{:.3}s"
+                    .format(v, name, psnr, ssim, t1 - t0, t2 - t1, t3 - t2, t3 - t0))
+            if vp:
+                total_psnr[v], total_ssim[v] = vp, vs
+        sp = ss = 0.0
+        n = 0
+        for k in total_psnr:
+            self.logger.write_log("# Video:{} AVG-PSNR={:.5}, AVG-SSIM={:.4}".format(
+                k, sum(total_psnr[k]) / len(total_psnr[k]), sum(total_ssim[k]) / len(total_ssim[k])))
+            sp += sum(total_psnr[k]); ss += sum(total_ssim[k]); n += len(total_psnr[k])
+        if n:
+            self.logger.write_log("# Total AVG-PSNR={:.5}, AVG-SSIM={:.4}".format(sp / n, ss / n))
+        return (sp / n, ss / n) if n else (float("nan"), float("nan"))
+
+
+def main(variant: str, argv: Optional[Sequence[str]] = None) -> Tuple[float, float]:
+    denoise = "denoise" in variant
+    small = variant.endswith("2")
+    ap = argparse.ArgumentParser(description="Inference")
+    ap.add_argument("--save_image", action="store_true", default=False, help="save image if true")
+    ap.add_argument("--border", action="store_true", help="restore border images of video if true")
+    ap.add_argument("--default_data", type=str, default=".", help="quick test, optional: " + ("DAVIS, Set8" if denoise else "DVD, GOPRO"))
+    if denoise:
+        ap.add_argument("--sigma", type=int, default=10, help="sigma")
+        ap.add_argument("--one", type=int, default=10, help="unused upstream")
+    else:
+        ap.add_argument("--one_len", type=int, default=96 if small else 48)
+    ap.add_argument("--synthetic", type=int, nargs=3, metavar=("H", "W", "N"), default=None)
+    ap.add_argument("--checkpoint", type=str, default=None)
+    ap.add_argument("--dtype", choices=list(DTYPES), default="fp32" if variant == "gshift_denoise1" else "fp16")
+    ap.add_argument("--result_path", type=str, default=None)
+    a = ap.parse_args(argv)
+    sfx = "_small" if small else ""
+    a.data_path, a.model_path, rp = ".", "synthetic" if a.synthetic else "", "infer_results/synthetic"
+    if denoise:
+        if a.default_data in ("DAVIS", "Set8"):
+            a.data_path = "./dataset/DAVIS-test" if a.default_data == "DAVIS" else "./dataset/Set8"
+            a.model_path = "pretrained_models/net_denoise%s.pth" % sfx
+            rp = "infer_results/%s%s/sigma%d" % (a.default_data, "_2" if small else "", a.sigma)
+    else:
+        if a.default_data == "DVD":
+            a.data_path, a.model_path, rp = "./dataset/DVD/test", "pretrained_models/net_dvd_deblur%s.pth" % sfx, "infer_results/DVD"
+        elif a.default_data == "GOPRO":
+            a.data_path, a.model_path, rp = "./dataset/GOPRO/test", "pretrained_models/net_gopro_deblur%s.pth" % sfx, "infer_results/gopro"
+    if a.checkpoint:
+        a.model_path = a.checkpoint
+    a.result_path = a.result_path or rp
+    if not a.model_path:
+        ap.error("choose --default_data, or --synthetic H W N, or give --checkpoint")
+    return Inference(a, variant).infer()

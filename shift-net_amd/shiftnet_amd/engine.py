@@ -10,6 +10,7 @@ no op below has a torch/ATen compute fallback.  The control flow mirrors the ref
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -170,6 +171,7 @@ class Engine:
         self.V = plan.V
         self.lib = L.load()
         self.dev = plan.device
+        self.gsts_v = int(os.environ.get("SN_GSTS_V", "1"))   # 0 = round-1 five-kernel chain, 1 = fused K12 + LDS-staged K3
         self.prof: Optional[list] = None      # bench.py attaches a list to collect (fn, label, meta, ev0, ev1)
         self._meta: Tuple = ()
 
@@ -290,18 +292,24 @@ class Engine:
             hwb = self._new(T, h, w, c // 2)
             self._call("sn_gsts_shiftconv", "sn_gsts_shiftconv", C.byref(src), P.offs.data_ptr(), u["w1"].data_ptr(), hwb.data_ptr(), st)
             hw_ptr = hwb.data_ptr()
-        a = self._new(T, h, w, 2 * c)
-        self._call("sn_ln_gemm", "sn_ln_gemm", C.byref(src), hw_ptr, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(), a.data_ptr(), st)
         g1 = self._new(T, h, w, c)
         ca1_ptr = None
+        pool1 = None
+        if self.gsts_v >= 1:      # fused LN + 1x1 + dw3x3 + gate: the 2C tensor stays in LDS
+            if V.denoise:
+                pool1 = torch.empty((T, lib.sn_lngate_blocks(h, w), c), dtype=torch.float32, device=self.dev)
+            self._call("sn_ln_gemm_gate", "sn_ln_gemm_gate", C.byref(src), hw_ptr, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(),
+                       u["w_dw3"].data_ptr(), g1.data_ptr(), pool1.data_ptr() if pool1 is not None else None, st)
+        else:
+            a = self._new(T, h, w, 2 * c)
+            self._call("sn_ln_gemm", "sn_ln_gemm", C.byref(src), hw_ptr, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(), a.data_ptr(), st)
+            if V.denoise:
+                pool1 = torch.empty((T, lib.sn_dwgate_blocks(h, w), c), dtype=torch.float32, device=self.dev)
+            self._call("sn_dw_gate", "sn_dw_gate", a.data_ptr(), u["w_dw3"].data_ptr(), g1.data_ptr(),
+                       pool1.data_ptr() if pool1 is not None else None, T, h, w, c, st)
         if V.denoise:
-            nb = lib.sn_dwgate_blocks(h, w)
-            pool1 = torch.empty((T, nb, c), dtype=torch.float32, device=self.dev)
-            self._call("sn_dw_gate", "sn_dw_gate", a.data_ptr(), u["w_dw3"].data_ptr(), g1.data_ptr(), pool1.data_ptr(), T, h, w, c, st)
             ca1 = self.ca_mlp(pre + "ca1", pool1, h * w)
             ca1_ptr = ca1.data_ptr()
-        else:
-            self._call("sn_dw_gate", "sn_dw_gate", a.data_ptr(), u["w_dw3"].data_ptr(), g1.data_ptr(), None, T, h, w, c, st)
         if V.grouped_rep:
             # "+" RepConv is a grouped (8->8) 5x5: round 1 runs it as a block-diagonal dense conv on the MFMA conv kernel;
             # the CALayer2 scale of the denoise variant must precede it, so it is applied by a scale pass first.
@@ -314,7 +322,8 @@ class Engine:
         g2 = self._new(T, h, w, c)
         nb = lib.sn_dwgemm_blocks(h, w)
         pool2 = torch.empty((T, nb, c), dtype=torch.float32, device=self.dev)
-        self._call("sn_dw_gemm_gate", "sn_dw_gemm_gate", g1.data_ptr(), ca1_ptr, u["w_dw5"].data_ptr(), u["w_gate"].data_ptr(), g2.data_ptr(),
+        k3 = "sn_dw5_gemm_gate" if (self.gsts_v >= 1 and c == 64 and not V.grouped_rep) else "sn_dw_gemm_gate"
+        self._call(k3, k3, g1.data_ptr(), ca1_ptr, u["w_dw5"].data_ptr(), u["w_gate"].data_ptr(), g2.data_ptr(),
                                     pool2.data_ptr(), T, h, w, c, st)
         ca2 = self.ca_mlp(pre + "ca2", pool2, h * w)
         y = self._new(T, h, w, c)

@@ -207,11 +207,15 @@ def test_cab(name, pre, c, engines):
     check(f"cab_{name}_{pre}", to_cpu(out.t, c), O.cab(sd, pre, x), 4e-2)
 
 
+@pytest.mark.parametrize("gsts_v", [1, 0])
 @pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_denoise2", "gshift_deblur1", "gshift_denoise1"])
-def test_gsts_pieces(name, engines):
-    """shiftconv alone, then CAB2 (both directions), CAB1, a whole unit and a whole Encoder_shift_block."""
+def test_gsts_pieces(name, gsts_v, engines):
+    """shiftconv alone, then CAB2 (both directions), CAB1, a whole unit and a whole Encoder_shift_block.
+
+    gsts_v = 1: fused LN+1x1+dw3x3+gate and LDS-staged dw5x5+1x1+gate kernels; 0: the five-kernel chain."""
     from shiftnet_amd import lib as L
     eng, sd = engines(name)
+    eng.gsts_v = gsts_v
     V = O.VARIANTS[name]
     C, T, h, w = V.c1, 4, 20, 44
     x = bf(torch.from_numpy(synth.unit_noise((T, C, h, w), seed=81)))
@@ -227,14 +231,19 @@ def test_gsts_pieces(name, engines):
         hw_ref = torch.nn.functional.conv2d(O.spatial_shift(hw_ref.contiguous()), sd[pre + "conv1.weight"], padding=1, groups=C // 2)
         check(f"shiftconv_{name}_{mode}", to_cpu(hwb, C // 2), hw_ref, 1.5e-2)
         out = eng.naf(pre, xd, mode)
-        check(f"cab2_{name}_{mode}", to_cpu(out.t, C), O.cab2(sd, pre, O.gsts_gather(x, rev, V.wrap), V), 4e-2)
+        check(f"cab2_v{gsts_v}_{name}_{mode}", to_cpu(out.t, C), O.cab2(sd, pre, O.gsts_gather(x, rev, V.wrap), V), 4e-2)
     pre = blk + "encoder_level1.1."
     out = eng.naf(pre, xd, 0)
-    check(f"cab1_{name}", to_cpu(out.t, C), O.cab1(sd, pre, x, V), 4e-2)
+    check(f"cab1_v{gsts_v}_{name}", to_cpu(out.t, C), O.cab1(sd, pre, x, V), 4e-2)
     out = eng.gsts_unit(blk + "encoder_level1_1.", xd, True)
-    check(f"unit_rev_{name}", to_cpu(out.t, C), O.gsts_unit(sd, blk + "encoder_level1_1.", x, True, V), 4e-2)
+    check(f"unit_rev_v{gsts_v}_{name}", to_cpu(out.t, C), O.gsts_unit(sd, blk + "encoder_level1_1.", x, True, V), 4e-2)
     out = eng.shift_block(blk, xd)
-    check(f"shift_block_{name}", to_cpu(out.t, C), O.shift_block(sd, blk, x, V), 6e-2)
+    check(f"shift_block_v{gsts_v}_{name}", to_cpu(out.t, C), O.shift_block(sd, blk, x, V), 6e-2)
+    # ragged sizes: partial tiles in both kernels' tilings
+    x2 = bf(torch.from_numpy(synth.unit_noise((2, C, 13, 70), seed=82)))
+    out = eng.gsts_unit(blk + "encoder_level1.", act(to_dev(x2), C), False)
+    check(f"unit_fwd_ragged_v{gsts_v}_{name}", to_cpu(out.t, C), O.gsts_unit(sd, blk + "encoder_level1.", x2, False, V), 4e-2)
+    eng.gsts_v = 1
 
 
 def C_byref(s):
@@ -352,3 +361,14 @@ def test_full_size_properties():
     assert torch.equal(y1, y2)
     assert torch.equal(yr[1:], y1[:-1])                      # out(roll(x))[i] == out(x)[i-1]
     assert (y1.float() - x[0, 2:18].float()).abs().max().item() < 1.0
+
+
+def test_cli_synthetic_runs(tmp_path):
+    """The drop-in CLIs end to end on a synthetic clip with the synthetic checkpoint (deblur-small and denoise-small)."""
+    from shiftnet_amd import cli
+    p, s = cli.main("gshift_deblur2", ["--synthetic", "64", "96", "12", "--one_len", "4", "--dtype", "bf16",
+                                       "--result_path", str(tmp_path / "d"), "--save_image"])
+    assert np.isfinite(p) and 0 < s <= 1
+    assert len(list((tmp_path / "d" / "synthetic").glob("*.png"))) == 8
+    p, s = cli.main("gshift_denoise2", ["--synthetic", "96", "128", "9", "--sigma", "30", "--result_path", str(tmp_path / "n")])
+    assert np.isfinite(p) and p > 15

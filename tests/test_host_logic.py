@@ -80,3 +80,16 @@ def _halo_worker(rank, world, port, L):
 def test_halo_exchange_world2_gloo():
     port = _free_port()
     mp.spawn(_halo_worker, args=(2, port, 5), nprocs=2, join=True)
+
+
+def test_cli_window_arithmetic_and_metrics():
+    import numpy as np
+    from shiftnet_amd import cli
+    # denoise: whole clip minus 4 in one window; > 100 frames -> halved, residual appended to the last window
+    assert cli.denoise_windows(54) == [(0, 50, 0)]
+    assert cli.denoise_windows(131) == [(0, 63, 0), (63, 64, 1)]          # 127 -> one_len 63, k_len 2, residual 1
+    a = np.full((8, 8, 3), 100.0); b = np.full((8, 8, 3), 110, np.uint8)
+    assert abs(cli.psnr_255(a, b) - 10 * np.log10(255.0 ** 2 / 100.0)) < 1e-9
+    assert abs(cli.ssim_calculate(b.astype(np.float64), b) - 1.0) < 1e-6
+    x = cli.numpy2tensor([b, b])
+    assert x.shape == (1, 2, 3, 8, 8) and abs(float(x.max()) - 110 / 255) < 1e-7
