@@ -122,12 +122,16 @@ int sn_dwgemm_blocks(int h, int w);
 
 /* Fused sn_ln_gemm + sn_dw_gate: g1 = SimpleGate(RepConv2(body[0](norm(cat(shortcut, hw))))) with the 2C-channel
  * intermediate kept in LDS (gshift_deblur1.py:190-198,225-233).  Same weight layouts as the two kernels it replaces.
+ * g1_blocked != 0 (C = 64 only): g1 is written channel-blocked [T][4][h][w][16], the layout sn_dw5_gemm_gate reads.
  * pool: NULL or [T][sn_lngate_blocks][C]. */
 int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, const float* wdw,
-                    void* g1, float* pool, void* stream);
+                    void* g1, float* pool, int g1_blocked, void* stream);
 int sn_lngate_blocks(int h, int w);
 
-/* sn_dw_gemm_gate for the depthwise variants (C = 64) with the g1 tile staged through LDS; pool: [T][sn_dwgemm_blocks][C]. */
+/* sn_dw_gemm_gate for the depthwise variants (C = 64) with the channel-blocked g1 tile staged through LDS; pool: [T][sn_dw5_blocks][C]. */
+int sn_dw5_blocks(int h, int w);
+/* profiling aid: bit mask of kernel phases to skip in sn_dw5_gemm_gate (results are then wrong); default 0 */
+int sn_debug_set(int v);
 int sn_dw5_gemm_gate(const void* g1, const float* ca_in, const float* w5, const void* wfrag, void* g2, float* pool,
                      int T, int h, int w, int C, void* stream);
 

@@ -408,17 +408,23 @@ __global__ __launch_bounds__(256) void scale_gemm_res_kernel(const UnitK U, cons
     for (int n = 0; n < NT; ++n) {
         const int i = ibase + n * 16 + p;
         if (i >= hw) continue;
+        // lane (g,p) owns channels [g*4*MT, (g+1)*4*MT): one contiguous 8*MT-byte run of the shortcut and of y
+        uint32_t sc[2 * MT], o[2 * MT];
+        const int c0 = g * 4 * MT;
+        const bf16_t* sp = c0 < CH ? U.x + ((size_t)sl.f0 * hw + i) * C + sl.o0 + c0
+                                   : U.x + ((size_t)sl.f1 * hw + i) * C + sl.o1 + c0 - CH;
+#pragma unroll
+        for (int m = 0; m + 1 < MT; m += 2) { const uint4 q = *(const uint4*)(sp + m * 4); sc[2 * m] = q.x; sc[2 * m + 1] = q.y; sc[2 * m + 2] = q.z; sc[2 * m + 3] = q.w; }
+        if (MT & 1) { const uint2 q = *(const uint2*)(sp + (MT - 1) * 4); sc[2 * MT - 2] = q.x; sc[2 * MT - 1] = q.y; }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const int co0 = g * 4 * MT + m * 4;
-            const bf16_t* sp = co0 < CH ? U.x + ((size_t)sl.f0 * hw + i) * C + sl.o0 + co0
-                                        : U.x + ((size_t)sl.f1 * hw + i) * C + sl.o1 + co0 - CH;
-            const uint2 sq = *(const uint2*)sp;
-            uint2 o;
-            o.x = pack_bf2(bf_lo(sq.x) + acc[m][n][0], bf_hi(sq.x) + acc[m][n][1]);
-            o.y = pack_bf2(bf_lo(sq.y) + acc[m][n][2], bf_hi(sq.y) + acc[m][n][3]);
-            *(uint2*)(y + ((size_t)t * hw + i) * C + co0) = o;
+            o[2 * m] = pack_bf2(bf_lo(sc[2 * m]) + acc[m][n][0], bf_hi(sc[2 * m]) + acc[m][n][1]);
+            o[2 * m + 1] = pack_bf2(bf_lo(sc[2 * m + 1]) + acc[m][n][2], bf_hi(sc[2 * m + 1]) + acc[m][n][3]);
         }
+        bf16_t* yp = y + ((size_t)t * hw + i) * C + c0;
+#pragma unroll
+        for (int m = 0; m + 1 < MT; m += 2) *(uint4*)(yp + m * 4) = make_uint4(o[2 * m], o[2 * m + 1], o[2 * m + 2], o[2 * m + 3]);
+        if (MT & 1) *(uint2*)(yp + (MT - 1) * 4) = make_uint2(o[2 * MT - 2], o[2 * MT - 1]);
     }
 }
 

@@ -31,12 +31,13 @@ __device__ __forceinline__ Slabs2 unit_slabs2(const UnitK2& U, int t) {
 
 // ------------------------------------------------------------------------------------------------------------
 template <int C, bool WITH_HW>
-__global__ __launch_bounds__(256) void ln_gemm_gate_kernel(const UnitK2 U, const bf16_t* __restrict__ hwb, const uint4* __restrict__ wfrag,
+__global__ __launch_bounds__(512) void ln_gemm_gate_kernel(const UnitK2 U, const bf16_t* __restrict__ hwb, const uint4* __restrict__ wfrag,
                                                          const float* __restrict__ bias, const float* __restrict__ wdw,
-                                                         bf16_t* g1, float* pool) {
+                                                         bf16_t* g1, float* pool, const int blocked) {
     constexpr int CH = C / 2, K = WITH_HW ? C + CH : C, KS = (K + 31) / 32, MT = C / 8, NCHK = MT / 2;
     constexpr int TH = 8, TW = 32, RH = TH + 2, RW = TW + 2, NPX = RH * RW;        // 340 pixels incl. the 1-pixel ring
-    constexpr int NTILES = (NPX + 15) / 16, NTW = (NTILES + 3) / 4;                // 22 N-tiles, <= 6 per wave
+    constexpr int NWV = 8;                                                         // 512 threads: 8 waves
+    constexpr int NTILES = (NPX + 15) / 16, NTW = (NTILES + NWV - 1) / NWV;        // 22 N-tiles, <= 3 per wave
     constexpr int PSA = 80;                                                        // LDS bytes per pixel of an a-chunk (64 + 16 pad)
     __shared__ __attribute__((aligned(16))) char lds_a[NPX * PSA];
     const int lane = threadIdx.x & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void ln_gemm_gate_kernel(const UnitK2 U, const
     bool inimg[NTW];
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
-        const int tile = wv + 4 * n;
+        const int tile = wv + NWV * n;
         const int rp = tile * 16 + p;                         // pixel index inside the region
         const int ry = rp / RW, rx = rp - ry * RW;
         const int gy = oy0 - 1 + ry, gx = ox0 - 1 + rx;
@@ -115,8 +116,8 @@ __global__ __launch_bounds__(256) void ln_gemm_gate_kernel(const UnitK2 U, const
             }
 #pragma unroll
             for (int n = 0; n < NTW; ++n) {
-                const int rp = (wv + 4 * n) * 16 + p;
-                if (rp < NPX && (wv + 4 * n) < NTILES) {
+                const int rp = (wv + NWV * n) * 16 + p;
+                if (rp < NPX && (wv + NWV * n) < NTILES) {
                     uint4 o = make_uint4(0, 0, 0, 0);
                     if (inimg[n]) {
                         o.x = pack_bf2(acc0[n][0], acc0[n][1]); o.y = pack_bf2(acc0[n][2], acc0[n][3]);
@@ -127,16 +128,18 @@ __global__ __launch_bounds__(256) void ln_gemm_gate_kernel(const UnitK2 U, const
             }
         }
         __syncthreads();
-        // ---- depthwise 3x3 (+identity) and gate: wave wv owns lane-group slot wv of the chunk, lanes are pixels ----
+        // ---- depthwise 3x3 (+identity) and gate: waves (gs, gs+4) share lane-group slot gs of the chunk and split the
+        //      tile's pixels in halves; lanes are pixels, the slot's weights are wave-uniform (scalar loads) ----
         {
+            const int gs = wv & 3, half = wv >> 2;
             float wt[9][8];
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) wt[tp][j] = wdw[tp * (2 * C) + wv * 4 * MT + q * 8 + j];
+                for (int j = 0; j < 8; ++j) wt[tp][j] = wdw[tp * (2 * C) + gs * 4 * MT + q * 8 + j];
 #pragma unroll
-            for (int it = 0; it < (TH * TW) / 64; ++it) {
-                const int op = it * 64 + lane, oy = op / TW, ox = op - oy * TW;
+            for (int it = 0; it < (TH * TW) / 128; ++it) {
+                const int op = (half * ((TH * TW) / 128) + it) * 64 + lane, oy = op / TW, ox = op - oy * TW;
                 float o[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = 0.f;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void ln_gemm_gate_kernel(const UnitK2 U, const
 #pragma unroll
                     for (int tx = 0; tx < 3; ++tx) {
                         float v[8];
-                        unpack8(*(const uint4*)(lds_a + ((oy + ty) * RW + ox + tx) * PSA + wv * 16), v);
+                        unpack8(*(const uint4*)(lds_a + ((oy + ty) * RW + ox + tx) * PSA + gs * 16), v);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) o[j] += wt[ty * 3 + tx][j] * v[j];
                     }
@@ -153,7 +156,10 @@ __global__ __launch_bounds__(256) void ln_gemm_gate_kernel(const UnitK2 U, const
                 if (gy < U.h && gx < U.w) {
                     const float r0 = o[0] * o[4], r1 = o[1] * o[5], r2 = o[2] * o[6], r3 = o[3] * o[7];
                     uint2 qv; qv.x = pack_bf2(r0, r1); qv.y = pack_bf2(r2, r3);
-                    *(uint2*)(g1 + ((size_t)t * hw + (size_t)gy * U.w + gx) * C + wv * 2 * MT + q * 4) = qv;
+                    // natural NHWC, or (C = 64 only) channel-blocked [T][4][h][w][16] (block = this wave's 16 channels) so
+                    // that sn_dw5_gemm_gate stages 16 channels of a pixel row as one contiguous run
+                    if (blocked) *(uint2*)(g1 + (((size_t)t * 4 + gs) * hw + (size_t)gy * U.w + gx) * 16 + q * 4) = qv;
+                    else *(uint2*)(g1 + ((size_t)t * hw + (size_t)gy * U.w + gx) * C + gs * 2 * MT + q * 4) = qv;
                     psum[0] += r0; psum[1] += r1; psum[2] += r2; psum[3] += r3;
                 }
             }
@@ -164,8 +170,8 @@ __global__ __launch_bounds__(256) void ln_gemm_gate_kernel(const UnitK2 U, const
                     s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
                     s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
                     if (lane == 0) {
-                        const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
-                        pool[((size_t)t * nblk + blk) * C + wv * 2 * MT + q * 4 + j] = s;
+                        const int nblk = 2 * gridDim.x * gridDim.y, blk = 2 * (blockIdx.y * gridDim.x + blockIdx.x) + half;
+                        pool[((size_t)t * nblk + blk) * C + gs * 2 * MT + q * 4 + j] = s;
                     }
                     psum[j] = 0.f;
                 }
@@ -176,113 +182,141 @@ __global__ __launch_bounds__(256) void ln_gemm_gate_kernel(const UnitK2 U, const
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K3' (C = 64, depthwise RepConv): tile 64 x 4 pixels, two passes of 32 channels.
+// K3' (C = 64, depthwise RepConv): tile 64 x 4 pixels.  Four passes of 16 channels: stage the g1 region (+2 ring),
+// run the 5x5 stencil (wave = 4-channel block, lane = pixel column, 4 output rows with full vertical reuse, one kernel
+// column of weights (20 SGPRs) live at a time), write r[px][64ch] to LDS; then one MFMA sweep over the finished r tile.
+// Nothing persists in registers across passes, so the kernel fits 2-3 waves per SIMD.
+template <int TY>
 __global__ __launch_bounds__(256) void dw5_gemm_gate_kernel(const bf16_t* __restrict__ g1, const float* __restrict__ ca_in,
                                                           const float* __restrict__ w5, const uint4* __restrict__ wfrag,
-                                                          bf16_t* g2, float* pool, int h, int w) {
-    constexpr int C = 64, TY = 4, TXW = 64, RH = TY + 4, RW = TXW + 4, PS = 80, MT = 8, NT = 4;
-    __shared__ __attribute__((aligned(16))) char lds_g[RH * RW * PS];      // 43520 B: g1 region, 32 channels
-    __shared__ __attribute__((aligned(16))) char lds_r[TY * TXW * PS];     // 20480 B: stencil output, 32 channels
+                                                          bf16_t* g2, float* pool, int h, int w, const int dbg) {
+    constexpr int C = 64, TXW = 64, RH = TY + 4, RW = TXW + 4, PSG = 40, PSR = 144, MT = 8, NT = TY, KS = 2;
+    __shared__ __attribute__((aligned(16))) char lds_g[RH * RW * PSG];      // 21760 B: g1 region, 16 channels (32 B + 8 pad)
+    __shared__ __attribute__((aligned(16))) char lds_r[TY * TXW * PSR];     // 36864 B: stencil output, all 64 channels
     __shared__ float red[4 * C];
     const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
     const int t = blockIdx.z, y0 = blockIdx.y * TY, x0 = blockIdx.x * TXW;
-    const bf16_t* gt = g1 + (size_t)t * h * w * C;
+    const size_t hwp = (size_t)h * w;
 
-    f32x4_t acc[MT][NT];
+    // staging plan of this thread: the same (region pixel, 16-byte piece) items in every pass, only the block base moves
+    constexpr int NITEM = (RH * RW * 2 + 255) / 256;
+    int gofs[NITEM], lofs[NITEM];
+#pragma unroll
+    for (int k = 0; k < NITEM; ++k) {
+        const int idx = tid + k * 256, pix = idx >> 1, pc = idx & 1;
+        const int ry = pix / RW, rx = pix - ry * RW;
+        const int gy = y0 - 2 + ry, gx = x0 - 2 + rx;
+        const bool ok = idx < RH * RW * 2;
+        lofs[k] = ok ? pix * PSG + pc * 16 : -1;
+        gofs[k] = (ok && gy >= 0 && gy < h && gx >= 0 && gx < w && !(dbg & 1)) ? (gy * w + gx) * 16 + pc * 8 : -1;
+    }
+    // MFMA weights are fetched now and arrive long before the GEMM phase
+    bf16x8_t A[MT][KS];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < KS; ++s) A[m][s] = as_frag(wfrag[(m * KS + s) * 64 + lane]);
 
+    uint4 stg[NITEM];
+    auto issue_loads = [&](int pass) {        // g1 is channel-blocked [T][4][h][w][16]: one pass = one block
+        const bf16_t* gt = g1 + ((size_t)t * 4 + pass) * hwp * 16;
+#pragma unroll
+        for (int k = 0; k < NITEM; ++k) stg[k] = gofs[k] >= 0 ? *(const uint4*)(gt + gofs[k]) : make_uint4(0, 0, 0, 0);
+    };
+    issue_loads(0);
 #pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-        // ---- stage g1[region][pass*32 .. +32) ----
-        for (int idx = tid; idx < RH * RW * 4; idx += 256) {
-            const int pix = idx >> 2, pc = idx & 3;
-            const int ry = pix / RW, rx = pix - ry * RW;
-            const int gy = y0 - 2 + ry, gx = x0 - 2 + rx;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (gy >= 0 && gy < h && gx >= 0 && gx < w) v = *(const uint4*)(gt + ((size_t)gy * w + gx) * C + pass * 32 + pc * 8);
-            *(uint4*)(lds_g + pix * PS + pc * 16) = v;
-        }
+    for (int pass = 0; pass < 4; ++pass) {
+        if (pass) __syncthreads();                 // every wave finished reading lds_g of the previous pass
+#pragma unroll
+        for (int k = 0; k < NITEM; ++k)
+            if (lofs[k] >= 0) {
+                uint2* d = (uint2*)(lds_g + lofs[k]);
+                d[0] = make_uint2(stg[k].x, stg[k].y); d[1] = make_uint2(stg[k].z, stg[k].w);
+            }
         __syncthreads();
-        // ---- 5x5 stencil: wave wv owns channels [pass*32 + wv*8, +8), lane = pixel column, 4 output rows ----
-        {
-            const int cb = pass * 4 + wv;
-            float sc[8];
+        if (pass < 3) issue_loads(pass + 1);       // in flight while this pass's stencil runs
+        const int cb = pass * 4 + wv;              // 4-channel block: channels [cb*4, cb*4+4)
+        float r[TY][4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sc[j] = ca_in ? ca_in[(size_t)t * C + cb * 8 + j] : 1.f;
-            float r[TY][8];
+        for (int oy = 0; oy < TY; ++oy)
 #pragma unroll
-            for (int oy = 0; oy < TY; ++oy)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) r[oy][j] = 0.f;
-            // dx outermost: only the 5 x 8 weights of one kernel column are live at a time (40 SGPRs, no spills),
-            // each staged value is read and unpacked once per dx and feeds up to 4 output rows.
+            for (int j = 0; j < 4; ++j) r[oy][j] = 0.f;
 #pragma unroll 1
-            for (int dx = 0; dx < 5; ++dx) {
-                float wcol[5][8];
+        for (int dx = (dbg & 2) ? 5 : 0; dx < 5; ++dx) {
+            float wcol[5][4];
 #pragma unroll
-                for (int dy = 0; dy < 5; ++dy)
+            for (int dy = 0; dy < 5; ++dy)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) wcol[dy][j] = w5[(dy * 5 + dx) * C + cb * 8 + j];
+                for (int j = 0; j < 4; ++j) wcol[dy][j] = w5[(dy * 5 + dx) * C + cb * 4 + j];
 #pragma unroll
-                for (int iy = 0; iy < RH; ++iy) {
-                    float v[8];
-                    unpack8(*(const uint4*)(lds_g + (iy * RW + lane + dx) * PS + wv * 16), v);
+            for (int iy = 0; iy < RH; ++iy) {
+                const uint2 q = *(const uint2*)(lds_g + (iy * RW + lane + dx) * PSG + wv * 8);
+                const float v0 = bf_lo(q.x), v1 = bf_hi(q.x), v2 = bf_lo(q.y), v3 = bf_hi(q.y);
 #pragma unroll
-                    for (int oy = 0; oy < TY; ++oy) {
-                        const int dy = iy - oy;
-                        if (dy >= 0 && dy < 5) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) r[oy][j] += wcol[dy][j] * v[j];
-                        }
+                for (int oy = 0; oy < TY; ++oy) {
+                    const int dy = iy - oy;
+                    if (dy >= 0 && dy < 5) {
+                        r[oy][0] += wcol[dy][0] * v0; r[oy][1] += wcol[dy][1] * v1;
+                        r[oy][2] += wcol[dy][2] * v2; r[oy][3] += wcol[dy][3] * v3;
                     }
                 }
             }
-#pragma unroll
-            for (int oy = 0; oy < TY; ++oy) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) r[oy][j] *= sc[j];
-                *(uint4*)(lds_r + (oy * TXW + lane) * PS + wv * 16) = pack8(r[oy]);
-            }
         }
-        __syncthreads();
-        // ---- MFMA k-step `pass`: wave wv owns tile row wv (4 N-tiles of 16 pixels) ----
+        float sc[4];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const bf16x8_t b = as_frag(*(const uint4*)(lds_r + (wv * TXW + n * 16 + p) * PS + g * 16));
+        for (int j = 0; j < 4; ++j) sc[j] = ca_in ? ca_in[(size_t)t * C + cb * 4 + j] : 1.f;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const bf16x8_t a = as_frag(wfrag[(m * 2 + pass) * 64 + lane]);
-                acc[m][n] = mfma16(a, b, acc[m][n]);
-            }
+        for (int oy = 0; oy < TY; ++oy) {
+            uint2 o;
+            o.x = pack_bf2(r[oy][0] * sc[0], r[oy][1] * sc[1]); o.y = pack_bf2(r[oy][2] * sc[2], r[oy][3] * sc[3]);
+            *(uint2*)(lds_r + (oy * TXW + lane) * PSR + cb * 8) = o;
         }
-        // the next pass's staging writes lds_g only; lds_r is rewritten after the next __syncthreads()
     }
+    __syncthreads();
 
-    const int oy = y0 + wv;
+    // ---- GEMM over the finished r tile: wave wv owns NT N-tiles (16 pixels each); per N-tile all 8 M-tiles are
+    // accumulated, so a lane ends up with its pixel's 16 consecutive g2 channels = one 32-byte store.
+    float ps[MT / 2][4];
 #pragma unroll
-    for (int mp = 0; mp < MT / 2; ++mp) {
-        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int mp = 0; mp < MT / 2; ++mp)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int ox = x0 + n * 16 + p;
-            if (oy < h && ox < w) {
+        for (int rr = 0; rr < 4; ++rr) ps[mp][rr] = 0.f;
+#pragma unroll 1
+    for (int n = (dbg & 4) ? NT : 0; n < NT; ++n) {
+        const int tp = (wv * NT + n) * 16 + p;
+        bf16x8_t Bf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) Bf[s] = as_frag(*(const uint4*)(lds_r + tp * PSR + (s * 32 + g * 8) * 2));
+        f32x4_t acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc[m] = mfma16(A[m][s], Bf[s], acc[m]);
+        }
+        const int oy = y0 + tp / TXW, ox = x0 + (tp % TXW);
+        if (oy < h && ox < w) {
+            uint32_t o[MT];
+#pragma unroll
+            for (int mp = 0; mp < MT / 2; ++mp) {
                 float v[4];
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) { v[rr] = acc[2 * mp][n][rr] * sigmoidf_(acc[2 * mp + 1][n][rr]); ps[rr] += v[rr]; }
-                uint2 qv; qv.x = pack_bf2(v[0], v[1]); qv.y = pack_bf2(v[2], v[3]);
-                *(uint2*)(g2 + (((size_t)t * h + oy) * w + ox) * C + g * 2 * MT + mp * 4) = qv;
+                for (int rr = 0; rr < 4; ++rr) { v[rr] = acc[2 * mp][rr] * sigmoidf_(acc[2 * mp + 1][rr]); ps[mp][rr] += v[rr]; }
+                o[2 * mp] = pack_bf2(v[0], v[1]); o[2 * mp + 1] = pack_bf2(v[2], v[3]);
             }
-        }
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            float s = ps[rr];
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-            if (p == 0) red[wv * C + g * 2 * MT + mp * 4 + rr] = s;
+            uint4* dst = (uint4*)(g2 + (((size_t)t * h + oy) * w + ox) * C + g * 2 * MT);
+            dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+            dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
         }
     }
+#pragma unroll
+    for (int mp = 0; mp < MT / 2; ++mp)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            float sm = ps[mp][rr];
+            sm += __shfl_xor(sm, 1); sm += __shfl_xor(sm, 2); sm += __shfl_xor(sm, 4); sm += __shfl_xor(sm, 8);
+            if (p == 0) red[wv * C + g * 2 * MT + mp * 4 + rr] = sm;
+        }
     __syncthreads();
     if (pool && tid < C) {
         const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
@@ -294,18 +328,26 @@ __global__ __launch_bounds__(256) void dw5_gemm_gate_kernel(const bf16_t* __rest
 
 extern "C" {
 
-int sn_lngate_blocks(int h, int w) { return ((h + 7) / 8) * ((w + 31) / 32); }
+static int g_sn_debug = 0;
+int sn_debug_set(int v) { g_sn_debug = v; return 0; }   /* profiling ablations only (tools/); 0 in production */
+
+#ifndef SN_DW5_TY
+#define SN_DW5_TY 4
+#endif
+int sn_dw5_blocks(int h, int w) { return ((h + SN_DW5_TY - 1) / SN_DW5_TY) * ((w + 63) / 64); }
+
+int sn_lngate_blocks(int h, int w) { return 2 * ((h + 7) / 8) * ((w + 31) / 32); }   /* two pixel halves per tile */
 
 int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, const float* wdw,
-                    void* g1, float* pool, void* stream) {
+                    void* g1, float* pool, int g1_blocked, void* stream) {
     sn_clear_error();
     if (!s || !s->x || (s->C != 64 && s->C != 80) || s->mode < 0 || s->mode > 2 || !wfrag || !bias || !wdw || !g1 ||
-        (s->mode != 0 && !hw)) return SN_EINVAL;
+        (s->mode != 0 && !hw) || (g1_blocked && s->C != 64)) return SN_EINVAL;
     UnitK2 u; u.x = (const bf16_t*)s->x; u.T = s->T; u.h = s->h; u.w = s->w; u.C = s->C; u.mode = s->mode; u.wrap = s->wrap;
     dim3 grid((s->w + 31) / 32, (s->h + 7) / 8, s->T);
     hipStream_t st = (hipStream_t)stream;
-#define SN_LAUNCH_K12(CC, HW_) hipLaunchKernelGGL((ln_gemm_gate_kernel<CC, HW_>), grid, dim3(256), 0, st, u, (const bf16_t*)hw, \
-        (const uint4*)wfrag, bias, wdw, (bf16_t*)g1, pool)
+#define SN_LAUNCH_K12(CC, HW_) hipLaunchKernelGGL((ln_gemm_gate_kernel<CC, HW_>), grid, dim3(512), 0, st, u, (const bf16_t*)hw, \
+        (const uint4*)wfrag, bias, wdw, (bf16_t*)g1, pool, g1_blocked)
     if (s->C == 64) { if (s->mode) SN_LAUNCH_K12(64, true); else SN_LAUNCH_K12(64, false); }
     else { if (s->mode) SN_LAUNCH_K12(80, true); else SN_LAUNCH_K12(80, false); }
 #undef SN_LAUNCH_K12
@@ -316,9 +358,9 @@ int sn_dw5_gemm_gate(const void* g1, const float* ca_in, const float* w5, const 
                      int T, int h, int w, int C, void* stream) {
     sn_clear_error();
     if (!g1 || !w5 || !wfrag || !g2 || C != 64) return SN_EINVAL;
-    dim3 grid((w + 63) / 64, (h + 3) / 4, T);
-    hipLaunchKernelGGL(dw5_gemm_gate_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g1, ca_in, w5,
-                       (const uint4*)wfrag, (bf16_t*)g2, pool, h, w);
+    dim3 grid((w + 63) / 64, (h + SN_DW5_TY - 1) / SN_DW5_TY, T);
+    hipLaunchKernelGGL(dw5_gemm_gate_kernel<SN_DW5_TY>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g1, ca_in, w5,
+                       (const uint4*)wfrag, (bf16_t*)g2, pool, h, w, g_sn_debug);
     return sn_check_launch();
 }
 

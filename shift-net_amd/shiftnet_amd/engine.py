@@ -295,11 +295,12 @@ class Engine:
         g1 = self._new(T, h, w, c)
         ca1_ptr = None
         pool1 = None
+        blocked = 1 if (self.gsts_v >= 1 and c == 64 and not V.grouped_rep) else 0   # g1 layout [T][4][h][w][16] for K3'
         if self.gsts_v >= 1:      # fused LN + 1x1 + dw3x3 + gate: the 2C tensor stays in LDS
             if V.denoise:
                 pool1 = torch.empty((T, lib.sn_lngate_blocks(h, w), c), dtype=torch.float32, device=self.dev)
             self._call("sn_ln_gemm_gate", "sn_ln_gemm_gate", C.byref(src), hw_ptr, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(),
-                       u["w_dw3"].data_ptr(), g1.data_ptr(), pool1.data_ptr() if pool1 is not None else None, st)
+                       u["w_dw3"].data_ptr(), g1.data_ptr(), pool1.data_ptr() if pool1 is not None else None, blocked, st)
         else:
             a = self._new(T, h, w, 2 * c)
             self._call("sn_ln_gemm", "sn_ln_gemm", C.byref(src), hw_ptr, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(), a.data_ptr(), st)
@@ -320,9 +321,9 @@ class Engine:
                 ca1_ptr = None
             g1 = self.conv(pre + "rep", [g1a]).t
         g2 = self._new(T, h, w, c)
-        nb = lib.sn_dwgemm_blocks(h, w)
-        pool2 = torch.empty((T, nb, c), dtype=torch.float32, device=self.dev)
         k3 = "sn_dw5_gemm_gate" if (self.gsts_v >= 1 and c == 64 and not V.grouped_rep) else "sn_dw_gemm_gate"
+        nb = lib.sn_dw5_blocks(h, w) if k3 == "sn_dw5_gemm_gate" else lib.sn_dwgemm_blocks(h, w)
+        pool2 = torch.empty((T, nb, c), dtype=torch.float32, device=self.dev)
         self._call(k3, k3, g1.data_ptr(), ca1_ptr, u["w_dw5"].data_ptr(), u["w_gate"].data_ptr(), g2.data_ptr(),
                                     pool2.data_ptr(), T, h, w, c, st)
         ca2 = self.ca_mlp(pre + "ca2", pool2, h * w)

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--w", type=int, default=640)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--gsts-v", type=int, default=1)
+    ap.add_argument("--dbg", type=int, default=0)
     args = ap.parse_args()
     from shiftnet_amd.engine import Act, Engine, Plan
     from shiftnet_amd.spec import VARIANTS
@@ -26,6 +27,7 @@ def main():
     V = VARIANTS[args.variant]
     eng = Engine(Plan(V, synth_state_dict(args.variant), dev))
     eng.gsts_v = args.gsts_v
+    eng.lib.sn_debug_set(args.dbg)
     x = Act(torch.randn(args.t, args.h, args.w, V.c1, device=dev).to(torch.bfloat16), V.c1)
     pre = "stage1.decoder_level1."
     for _ in range(2):
