@@ -66,11 +66,11 @@ typedef struct sn_conv_desc {
     int nchw_dtype;
     const void* sc;      /* mode 2: NCHW tensor of nchw_dtype, same shape as out */
     float* pool;         /* NULL or [T][gridDim.y*gridDim.x][16*mt] f32 per-workgroup channel sums of the output
-                            (first half of AdaptiveAvgPool2d(1), CALayer :69); see sn_conv_pool_blocks */
+                            (first half of AdaptiveAvgPool2d(1), CALayer :69); rows per frame = sn_conv_pool_blocks(d) */
 } sn_conv_desc;
 int sn_conv2d(const sn_conv_desc* d, void* stream);   /* d is a HOST pointer, read during the call */
-/* number of workgroups per frame sn_conv2d launches for this output size (= rows of `pool` per frame) */
-int sn_conv_pool_blocks(int h_out, int w_out, int stride);
+/* number of workgroups per frame sn_conv2d launches for this descriptor (= rows of `pool` per frame); host only */
+int sn_conv_pool_blocks(const sn_conv_desc* d);
 
 /* CALayer / CALayer2 squeeze-excite: mean -> 1x1 -> ReLU -> 1x1 -> sigmoid (gshift_deblur1.py:61-70,84-87).
  * partial:[T][nblk][cpad] f32 sums, wa:[cr][c], wb:[c][cr] f32, ca:[T][cpad] f32 out (pad entries 0). */

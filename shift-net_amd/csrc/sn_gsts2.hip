@@ -33,7 +33,7 @@ __device__ __forceinline__ Slabs2 unit_slabs2(const UnitK2& U, int t) {
 template <int C, bool WITH_HW>
 __global__ __launch_bounds__(512) void ln_gemm_gate_kernel(const UnitK2 U, const bf16_t* __restrict__ hwb, const uint4* __restrict__ wfrag,
                                                          const float* __restrict__ bias, const float* __restrict__ wdw,
-                                                         bf16_t* g1, float* pool, const int blocked) {
+                                                         bf16_t* g1, float* pool, const int blocked, const int dbg) {
     constexpr int CH = C / 2, K = WITH_HW ? C + CH : C, KS = (K + 31) / 32, MT = C / 8, NCHK = MT / 2;
     constexpr int TH = 8, TW = 32, RH = TH + 2, RW = TW + 2, NPX = RH * RW;        // 340 pixels incl. the 1-pixel ring
     constexpr int NWV = 8;                                                         // 512 threads: 8 waves
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(512) void ln_gemm_gate_kernel(const UnitK2 U, const
             if (kk0 < CH) src = U.x + ((size_t)sl.f0 * hw + ii) * C + sl.o0 + kk0;
             else if (kk0 < C) src = U.x + ((size_t)sl.f1 * hw + ii) * C + sl.o1 + kk0 - CH;
             else if (WITH_HW && kk0 < K) src = hwb + ((size_t)t * hw + ii) * CH + kk0 - C;
-            if (src) {
+            if (src && !(dbg & 8)) {
                 unpack8(*(const uint4*)src, xv[s]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) sum += xv[s][j];
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(512) void ln_gemm_gate_kernel(const UnitK2 U, const
 #pragma unroll
             for (int n = 0; n < NTW; ++n) { acc0[n] = (f32x4_t){b0.x, b0.y, b0.z, b0.w}; acc1[n] = (f32x4_t){b1.x, b1.y, b1.z, b1.w}; }
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
+            for (int s = (dbg & 16) ? KS : 0; s < KS; ++s) {
                 const bf16x8_t a0 = as_frag(wfrag[((2 * q) * KS + s) * 64 + lane]);
                 const bf16x8_t a1 = as_frag(wfrag[((2 * q + 1) * KS + s) * 64 + lane]);
 #pragma unroll
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(512) void ln_gemm_gate_kernel(const UnitK2 U, const
 #pragma unroll
                 for (int j = 0; j < 8; ++j) wt[tp][j] = wdw[tp * (2 * C) + gs * 4 * MT + q * 8 + j];
 #pragma unroll
-            for (int it = 0; it < (TH * TW) / 128; ++it) {
+            for (int it = (dbg & 32) ? (TH * TW) / 128 : 0; it < (TH * TW) / 128; ++it) {
                 const int op = (half * ((TH * TW) / 128) + it) * 64 + lane, oy = op / TW, ox = op - oy * TW;
                 float o[8];
 #pragma unroll
@@ -347,7 +347,7 @@ int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, con
     dim3 grid((s->w + 31) / 32, (s->h + 7) / 8, s->T);
     hipStream_t st = (hipStream_t)stream;
 #define SN_LAUNCH_K12(CC, HW_) hipLaunchKernelGGL((ln_gemm_gate_kernel<CC, HW_>), grid, dim3(512), 0, st, u, (const bf16_t*)hw, \
-        (const uint4*)wfrag, bias, wdw, (bf16_t*)g1, pool, g1_blocked)
+        (const uint4*)wfrag, bias, wdw, (bf16_t*)g1, pool, g1_blocked, g_sn_debug)
     if (s->C == 64) { if (s->mode) SN_LAUNCH_K12(64, true); else SN_LAUNCH_K12(64, false); }
     else { if (s->mode) SN_LAUNCH_K12(80, true); else SN_LAUNCH_K12(80, false); }
 #undef SN_LAUNCH_K12

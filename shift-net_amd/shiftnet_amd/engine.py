@@ -231,7 +231,7 @@ class Engine:
             assert out_mode == 0 and res.dims == out_act.dims
             d.res = res.t.data_ptr()
         if pool:
-            nblk = self.lib.sn_conv_pool_blocks(h_out, w_out, stride)
+            nblk = self.lib.sn_conv_pool_blocks(C.byref(d))
             pool_buf = torch.empty((T, nblk, 16 * d.mt), dtype=torch.float32, device=self.dev)
             d.pool = pool_buf.data_ptr()
         self._meta = ("conv", T, h_out, w_out, len(ins) * cs_in, int(d.cs_out), k, stride, in_mode, out_mode)

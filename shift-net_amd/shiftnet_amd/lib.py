@@ -68,7 +68,7 @@ def load() -> C.CDLL:
     lib.sn_selftest_mfma.argtypes = [vp, vp, vp, vp]
     lib.sn_ingest.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, vp]
     lib.sn_conv2d.argtypes = [C.POINTER(ConvDesc), vp]
-    lib.sn_conv_pool_blocks.argtypes = [ci, ci, ci]
+    lib.sn_conv_pool_blocks.argtypes = [C.POINTER(ConvDesc)]
     lib.sn_ca_mlp.argtypes = [vp, ci, ci, ci, ci, cf, vp, vp, vp, ci, vp]
     lib.sn_scale_residual.argtypes = [vp, vp, vp, ci, vp, ci, ci, ci, vp]
     lib.sn_gsts_gather.argtypes = [C.POINTER(UnitSrc), vp, vp, vp]

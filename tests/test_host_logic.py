@@ -1,4 +1,5 @@
 """CPU tests of host logic: C-ABI library exports, drop-in class contract, clip-parallel halo exchange (gloo, world 2)."""
+import ctypes
 import os
 import re
 import socket
@@ -27,7 +28,10 @@ def test_library_exports_every_declared_symbol():
     assert lib.sn_abi_version() == 1
     # argument validation is host side and must not need a GPU
     assert lib.sn_conv2d(None, None) == -22
-    assert lib.sn_conv_pool_blocks(720, 1280, 1) == 90 * 40
+    d = L.ConvDesc(); d.stride, d.mt, d.n_in, d.cs_in, d.h_out, d.w_out = 1, 1, 1, 16, 720, 1280
+    assert lib.sn_conv_pool_blocks(ctypes.byref(d)) == 90 * 40
+    d.cs_in, d.mt = 64, 4
+    assert lib.sn_conv_pool_blocks(ctypes.byref(d)) == 90 * 40            # 8x32 tiles
 
 
 def test_dropin_class_contract():
