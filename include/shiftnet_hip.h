@@ -122,9 +122,10 @@ int sn_dwgemm_blocks(int h, int w);
 
 /* Fused sn_ln_gemm + sn_dw_gate: g1 = SimpleGate(RepConv2(body[0](norm(cat(shortcut, hw))))) with the 2C-channel
  * intermediate kept in LDS (gshift_deblur1.py:190-198,225-233).  Same weight layouts as the two kernels it replaces.
+ * wdw: [9][2C] u32, the bf16 weight of position j in half (j & 1) of its word, other half zero (v_dot2c operand).
  * g1_blocked != 0 (C = 64 only): g1 is written channel-blocked [T][4][h][w][16], the layout sn_dw5_gemm_gate reads.
  * pool: NULL or [T][sn_lngate_blocks][C]. */
-int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, const float* wdw,
+int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, const uint32_t* wdw,
                     void* g1, float* pool, int g1_blocked, void* stream);
 int sn_lngate_blocks(int h, int w);
 
@@ -132,7 +133,7 @@ int sn_lngate_blocks(int h, int w);
 int sn_dw5_blocks(int h, int w);
 /* profiling aid: bit mask of kernel phases to skip in sn_dw5_gemm_gate (results are then wrong); default 0 */
 int sn_debug_set(int v);
-int sn_dw5_gemm_gate(const void* g1, const float* ca_in, const float* w5, const void* wfrag, void* g2, float* pool,
+int sn_dw5_gemm_gate(const void* g1, const float* ca_in, const uint32_t* w5, const void* wfrag, void* g2, float* pool,
                      int T, int h, int w, int C, void* stream);
 
 /* y = shortcut + beta * body[7](ca * g2) (gshift_deblur1.py:201,210,254): beta and the optional bias are folded

@@ -54,6 +54,12 @@ __device__ __forceinline__ f32x4_t mfma16(const bf16x8_t a, const bf16x8_t b, co
 }
 
 // v_exp_f32 + v_rcp_f32 (1 ulp each): the IEEE division sequence costs ~10 VALU instructions per element
+// acc + a.lo*b.lo + a.hi*b.hi on packed bf16 pairs (v_dot2c_f32_bf16).  With a weight word that has ONE non-zero half
+// this is "fma on one bf16 lane of a packed pair" without unpacking the data: the stencil kernels use it that way.
+__device__ __forceinline__ float dot2bf(uint32_t a, uint32_t b, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), acc, false);
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // wave-uniform wave index (threadIdx-derived values are "divergent" to the compiler; make it provably uniform)

@@ -32,7 +32,7 @@ __device__ __forceinline__ Slabs2 unit_slabs2(const UnitK2& U, int t) {
 // ------------------------------------------------------------------------------------------------------------
 template <int C, bool WITH_HW>
 __global__ __launch_bounds__(512) void ln_gemm_gate_kernel(const UnitK2 U, const bf16_t* __restrict__ hwb, const uint4* __restrict__ wfrag,
-                                                         const float* __restrict__ bias, const float* __restrict__ wdw,
+                                                         const float* __restrict__ bias, const uint32_t* __restrict__ wdw,
                                                          bf16_t* g1, float* pool, const int blocked, const int dbg) {
     constexpr int CH = C / 2, K = WITH_HW ? C + CH : C, KS = (K + 31) / 32, MT = C / 8, NCHK = MT / 2;
     constexpr int TH = 8, TW = 32, RH = TH + 2, RW = TW + 2, NPX = RH * RW;        // 340 pixels incl. the 1-pixel ring
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(512) void ln_gemm_gate_kernel(const UnitK2 U, const
         //      tile's pixels in halves; lanes are pixels, the slot's weights are wave-uniform (scalar loads) ----
         {
             const int gs = wv & 3, half = wv >> 2;
-            float wt[9][8];
+            uint32_t wt[9][8];            // weight of position j as bf16 in half (j & 1) of its word, other half zero
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
@@ -147,10 +147,10 @@ __global__ __launch_bounds__(512) void ln_gemm_gate_kernel(const UnitK2 U, const
                 for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
                     for (int tx = 0; tx < 3; ++tx) {
-                        float v[8];
-                        unpack8(*(const uint4*)(lds_a + ((oy + ty) * RW + ox + tx) * PSA + gs * 16), v);
+                        const uint4 v = *(const uint4*)(lds_a + ((oy + ty) * RW + ox + tx) * PSA + gs * 16);
+                        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) o[j] += wt[ty * 3 + tx][j] * v[j];
+                        for (int j = 0; j < 8; ++j) o[j] = dot2bf(d[j >> 1], wt[ty * 3 + tx][j], o[j]);
                     }
                 const int gy = oy0 + oy, gx = ox0 + ox;
                 if (gy < U.h && gx < U.w) {
@@ -188,139 +188,169 @@ __global__ __launch_bounds__(512) void ln_gemm_gate_kernel(const UnitK2 U, const
 // Nothing persists in registers across passes, so the kernel fits 2-3 waves per SIMD.
 template <int TY>
 __global__ __launch_bounds__(256) void dw5_gemm_gate_kernel(const bf16_t* __restrict__ g1, const float* __restrict__ ca_in,
-                                                          const float* __restrict__ w5, const uint4* __restrict__ wfrag,
-                                                          bf16_t* g2, float* pool, int h, int w, const int dbg) {
+                                                          const uint32_t* __restrict__ w5, const uint4* __restrict__ wfrag,
+                                                          bf16_t* g2, float* pool, int T, int h, int w, const int dbg) {
+    // PERSISTENT: gridDim.x workgroups walk the (frame, tile) list; the stencil weight words (6.4 KB) and the MFMA A
+    // fragments (64 VGPRs) are loaded once, and the staging loads of the NEXT pass / NEXT tile are always in flight
+    // while the current stencil or GEMM runs, so no global-memory latency is exposed inside the loop.
     constexpr int C = 64, TXW = 64, RH = TY + 4, RW = TXW + 4, PSG = 40, PSR = 144, MT = 8, NT = TY, KS = 2;
     __shared__ __attribute__((aligned(16))) char lds_g[RH * RW * PSG];      // 21760 B: g1 region, 16 channels (32 B + 8 pad)
     __shared__ __attribute__((aligned(16))) char lds_r[TY * TXW * PSR];     // 36864 B: stencil output, all 64 channels
     __shared__ float red[4 * C];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_w[25 * C];         // stencil weight words [tap][64 ch]
     const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
-    const int t = blockIdx.z, y0 = blockIdx.y * TY, x0 = blockIdx.x * TXW;
     const size_t hwp = (size_t)h * w;
+    const int tiles_x = (w + TXW - 1) / TXW, tiles_y = (h + TY - 1) / TY, tpf = tiles_x * tiles_y, ntiles = T * tpf;
 
-    // staging plan of this thread: the same (region pixel, 16-byte piece) items in every pass, only the block base moves
-    constexpr int NITEM = (RH * RW * 2 + 255) / 256;
-    int gofs[NITEM], lofs[NITEM];
-#pragma unroll
-    for (int k = 0; k < NITEM; ++k) {
-        const int idx = tid + k * 256, pix = idx >> 1, pc = idx & 1;
-        const int ry = pix / RW, rx = pix - ry * RW;
-        const int gy = y0 - 2 + ry, gx = x0 - 2 + rx;
-        const bool ok = idx < RH * RW * 2;
-        lofs[k] = ok ? pix * PSG + pc * 16 : -1;
-        gofs[k] = (ok && gy >= 0 && gy < h && gx >= 0 && gx < w && !(dbg & 1)) ? (gy * w + gx) * 16 + pc * 8 : -1;
-    }
-    // MFMA weights are fetched now and arrive long before the GEMM phase
+    for (int e = tid; e < 25 * C; e += 256) lds_w[e] = w5[e];
     bf16x8_t A[MT][KS];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int s = 0; s < KS; ++s) A[m][s] = as_frag(wfrag[(m * KS + s) * 64 + lane]);
 
+    // staging plan: the same (region pixel, 16-byte piece) items for every tile and pass
+    constexpr int NITEM = (RH * RW * 2 + 255) / 256;
+    int iry[NITEM], irx[NITEM], lofs[NITEM];
+#pragma unroll
+    for (int k = 0; k < NITEM; ++k) {
+        const int idx = tid + k * 256, pix = idx >> 1, pc = idx & 1;
+        iry[k] = pix / RW; irx[k] = pix - iry[k] * RW;
+        lofs[k] = idx < RH * RW * 2 ? pix * PSG + pc * 16 : -1;
+    }
     uint4 stg[NITEM];
-    auto issue_loads = [&](int pass) {        // g1 is channel-blocked [T][4][h][w][16]: one pass = one block
-        const bf16_t* gt = g1 + ((size_t)t * 4 + pass) * hwp * 16;
+    int gofs[NITEM];                                   // element offset of each item inside one channel block, or -1
+    auto plan_tile = [&](int tile) {                    // once per tile: validity and offsets are the same for all 4 passes
+        const int t = tile / tpf, rem = tile - t * tpf, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int y0 = ty * TY, x0 = tx * TXW;
 #pragma unroll
-        for (int k = 0; k < NITEM; ++k) stg[k] = gofs[k] >= 0 ? *(const uint4*)(gt + gofs[k]) : make_uint4(0, 0, 0, 0);
+        for (int k = 0; k < NITEM; ++k) {
+            const int gy = y0 - 2 + iry[k], gx = x0 - 2 + irx[k];
+            const bool ok = lofs[k] >= 0 && gy >= 0 && gy < h && gx >= 0 && gx < w && !(dbg & 1);
+            gofs[k] = ok ? (gy * w + gx) * 16 + (tid & 1) * 8 : -1;
+        }
+        return t;
     };
-    issue_loads(0);
-#pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {
-        if (pass) __syncthreads();                 // every wave finished reading lds_g of the previous pass
+    auto issue_loads = [&](int t, int pass) {          // g1 is channel-blocked [T][4][h][w][16]: one pass = one block
+        const bf16_t* gt = g1 + ((size_t)t * 4 + pass) * hwp * 16;
+        // UNCONDITIONAL loads (offset clamped to 0, masked when written to LDS): a branch around a load makes the compiler
+        // wait for it right away (phi copies behind s_waitcnt vmcnt(0)) and the prefetch would not be asynchronous
 #pragma unroll
-        for (int k = 0; k < NITEM; ++k)
-            if (lofs[k] >= 0) {
-                uint2* d = (uint2*)(lds_g + lofs[k]);
-                d[0] = make_uint2(stg[k].x, stg[k].y); d[1] = make_uint2(stg[k].z, stg[k].w);
+        for (int k = 0; k < NITEM; ++k) stg[k] = *(const uint4*)(gt + (gofs[k] < 0 ? 0 : gofs[k]));
+    };
+
+    int gofs_cur[NITEM];                                // plan of the tile whose data currently sits in stg
+    int tile = blockIdx.x;
+    issue_loads(plan_tile(tile < ntiles ? tile : 0), 0);
+    __syncthreads();                                    // lds_w ready
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int t = tile / tpf, rem = tile - t * tpf, tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
+        const int y0 = tyi * TY, x0 = txi * TXW;
+#pragma unroll 1
+        for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+            for (int k = 0; k < NITEM; ++k) gofs_cur[k] = gofs[k];
+#pragma unroll
+            for (int k = 0; k < NITEM; ++k)
+                if (lofs[k] >= 0) {
+                    const bool z = gofs_cur[k] < 0;
+                    uint2* d = (uint2*)(lds_g + lofs[k]);
+                    d[0] = z ? make_uint2(0, 0) : make_uint2(stg[k].x, stg[k].y);
+                    d[1] = z ? make_uint2(0, 0) : make_uint2(stg[k].z, stg[k].w);
+                }
+            __syncthreads();
+            {   // prefetch the next (tile, pass) in STRAIGHT-LINE code: no branch around the loads, otherwise the
+                // compiler joins the paths behind an s_waitcnt vmcnt(0) and the loads stop being asynchronous.
+                // Past the last tile the current tile is re-read (harmless).
+                const int ntile = pass == 3 ? tile + (int)gridDim.x : tile;
+                issue_loads(plan_tile(ntile < ntiles ? ntile : tile), (pass + 1) & 3);
             }
-        __syncthreads();
-        if (pass < 3) issue_loads(pass + 1);       // in flight while this pass's stencil runs
-        const int cb = pass * 4 + wv;              // 4-channel block: channels [cb*4, cb*4+4)
-        float r[TY][4];
+            const int cb = pass * 4 + wv;              // 4-channel block: channels [cb*4, cb*4+4)
+            float r[TY][4];
 #pragma unroll
-        for (int oy = 0; oy < TY; ++oy)
+            for (int oy = 0; oy < TY; ++oy)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r[oy][j] = 0.f;
+                for (int j = 0; j < 4; ++j) r[oy][j] = 0.f;
 #pragma unroll 1
-        for (int dx = (dbg & 2) ? 5 : 0; dx < 5; ++dx) {
-            float wcol[5][4];
+            for (int dx = (dbg & 2) ? 5 : 0; dx < 5; ++dx) {
+                uint32_t wcol[5][4];                   // bf16 weight of channel j in half (j & 1) of its word, other half zero
 #pragma unroll
-            for (int dy = 0; dy < 5; ++dy)
+                for (int dy = 0; dy < 5; ++dy) {
+                    const uint4 ww = *(const uint4*)(lds_w + (dy * 5 + dx) * C + cb * 4);     // broadcast read
+                    wcol[dy][0] = ww.x; wcol[dy][1] = ww.y; wcol[dy][2] = ww.z; wcol[dy][3] = ww.w;
+                }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) wcol[dy][j] = w5[(dy * 5 + dx) * C + cb * 4 + j];
+                for (int iy = 0; iy < RH; ++iy) {
+                    const uint2 q = *(const uint2*)(lds_g + (iy * RW + lane + dx) * PSG + wv * 8);
 #pragma unroll
-            for (int iy = 0; iy < RH; ++iy) {
-                const uint2 q = *(const uint2*)(lds_g + (iy * RW + lane + dx) * PSG + wv * 8);
-                const float v0 = bf_lo(q.x), v1 = bf_hi(q.x), v2 = bf_lo(q.y), v3 = bf_hi(q.y);
-#pragma unroll
-                for (int oy = 0; oy < TY; ++oy) {
-                    const int dy = iy - oy;
-                    if (dy >= 0 && dy < 5) {
-                        r[oy][0] += wcol[dy][0] * v0; r[oy][1] += wcol[dy][1] * v1;
-                        r[oy][2] += wcol[dy][2] * v2; r[oy][3] += wcol[dy][3] * v3;
+                    for (int oy = 0; oy < TY; ++oy) {
+                        const int dy = iy - oy;
+                        if (dy >= 0 && dy < 5) {
+                            r[oy][0] = dot2bf(q.x, wcol[dy][0], r[oy][0]); r[oy][1] = dot2bf(q.x, wcol[dy][1], r[oy][1]);
+                            r[oy][2] = dot2bf(q.y, wcol[dy][2], r[oy][2]); r[oy][3] = dot2bf(q.y, wcol[dy][3], r[oy][3]);
+                        }
                     }
                 }
             }
-        }
-        float sc[4];
+            float sc[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sc[j] = ca_in ? ca_in[(size_t)t * C + cb * 4 + j] : 1.f;
+            for (int j = 0; j < 4; ++j) sc[j] = ca_in ? ca_in[(size_t)t * C + cb * 4 + j] : 1.f;
 #pragma unroll
-        for (int oy = 0; oy < TY; ++oy) {
-            uint2 o;
-            o.x = pack_bf2(r[oy][0] * sc[0], r[oy][1] * sc[1]); o.y = pack_bf2(r[oy][2] * sc[2], r[oy][3] * sc[3]);
-            *(uint2*)(lds_r + (oy * TXW + lane) * PSR + cb * 8) = o;
-        }
-    }
-    __syncthreads();
-
-    // ---- GEMM over the finished r tile: wave wv owns NT N-tiles (16 pixels each); per N-tile all 8 M-tiles are
-    // accumulated, so a lane ends up with its pixel's 16 consecutive g2 channels = one 32-byte store.
-    float ps[MT / 2][4];
-#pragma unroll
-    for (int mp = 0; mp < MT / 2; ++mp)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) ps[mp][rr] = 0.f;
-#pragma unroll 1
-    for (int n = (dbg & 4) ? NT : 0; n < NT; ++n) {
-        const int tp = (wv * NT + n) * 16 + p;
-        bf16x8_t Bf[KS];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) Bf[s] = as_frag(*(const uint4*)(lds_r + tp * PSR + (s * 32 + g * 8) * 2));
-        f32x4_t acc[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < KS; ++s) acc[m] = mfma16(A[m][s], Bf[s], acc[m]);
-        }
-        const int oy = y0 + tp / TXW, ox = x0 + (tp % TXW);
-        if (oy < h && ox < w) {
-            uint32_t o[MT];
-#pragma unroll
-            for (int mp = 0; mp < MT / 2; ++mp) {
-                float v[4];
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) { v[rr] = acc[2 * mp][rr] * sigmoidf_(acc[2 * mp + 1][rr]); ps[mp][rr] += v[rr]; }
-                o[2 * mp] = pack_bf2(v[0], v[1]); o[2 * mp + 1] = pack_bf2(v[2], v[3]);
+            for (int oy = 0; oy < TY; ++oy) {
+                uint2 o;
+                o.x = pack_bf2(r[oy][0] * sc[0], r[oy][1] * sc[1]); o.y = pack_bf2(r[oy][2] * sc[2], r[oy][3] * sc[3]);
+                *(uint2*)(lds_r + (oy * TXW + lane) * PSR + cb * 8) = o;
             }
-            uint4* dst = (uint4*)(g2 + (((size_t)t * h + oy) * w + ox) * C + g * 2 * MT);
-            dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
-            dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+            __syncthreads();                           // lds_g free for the next pass, lds_r complete after pass 3
         }
-    }
+
+        // ---- GEMM over the finished r tile: wave wv owns NT N-tiles (16 pixels each); per N-tile all 8 M-tiles are
+        // accumulated, so a lane ends up with its pixel's 16 consecutive g2 channels = one 32-byte store.
+        float ps[MT / 2][4];
 #pragma unroll
-    for (int mp = 0; mp < MT / 2; ++mp)
+        for (int mp = 0; mp < MT / 2; ++mp)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            float sm = ps[mp][rr];
-            sm += __shfl_xor(sm, 1); sm += __shfl_xor(sm, 2); sm += __shfl_xor(sm, 4); sm += __shfl_xor(sm, 8);
-            if (p == 0) red[wv * C + g * 2 * MT + mp * 4 + rr] = sm;
+            for (int rr = 0; rr < 4; ++rr) ps[mp][rr] = 0.f;
+#pragma unroll 1
+        for (int n = (dbg & 4) ? NT : 0; n < NT; ++n) {
+            const int tp = (wv * NT + n) * 16 + p;
+            bf16x8_t Bf[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) Bf[s] = as_frag(*(const uint4*)(lds_r + tp * PSR + (s * 32 + g * 8) * 2));
+            f32x4_t acc[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) acc[m] = mfma16(A[m][s], Bf[s], acc[m]);
+            }
+            const int oy = y0 + tp / TXW, ox = x0 + (tp % TXW);
+            if (oy < h && ox < w) {
+                uint32_t o[MT];
+#pragma unroll
+                for (int mp = 0; mp < MT / 2; ++mp) {
+                    float v[4];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) { v[rr] = acc[2 * mp][rr] * sigmoidf_(acc[2 * mp + 1][rr]); ps[mp][rr] += v[rr]; }
+                    o[2 * mp] = pack_bf2(v[0], v[1]); o[2 * mp + 1] = pack_bf2(v[2], v[3]);
+                }
+                uint4* dst = (uint4*)(g2 + (((size_t)t * h + oy) * w + ox) * C + g * 2 * MT);
+                dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+                dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+            }
         }
-    __syncthreads();
-    if (pool && tid < C) {
-        const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
-        pool[((size_t)t * nblk + blk) * C + tid] = red[tid] + red[C + tid] + red[2 * C + tid] + red[3 * C + tid];
+#pragma unroll
+        for (int mp = 0; mp < MT / 2; ++mp)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                float sm = ps[mp][rr];
+                sm += __shfl_xor(sm, 1); sm += __shfl_xor(sm, 2); sm += __shfl_xor(sm, 4); sm += __shfl_xor(sm, 8);
+                if (p == 0) red[wv * C + g * 2 * MT + mp * 4 + rr] = sm;
+            }
+        __syncthreads();
+        if (pool && tid < C)
+            pool[((size_t)t * tpf + rem) * C + tid] = red[tid] + red[C + tid] + red[2 * C + tid] + red[3 * C + tid];
+        // red / lds_r are rewritten only after the next tile's first __syncthreads()
     }
 }
 
@@ -338,7 +368,7 @@ int sn_dw5_blocks(int h, int w) { return ((h + SN_DW5_TY - 1) / SN_DW5_TY) * ((w
 
 int sn_lngate_blocks(int h, int w) { return 2 * ((h + 7) / 8) * ((w + 31) / 32); }   /* two pixel halves per tile */
 
-int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, const float* wdw,
+int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, const uint32_t* wdw,
                     void* g1, float* pool, int g1_blocked, void* stream) {
     sn_clear_error();
     if (!s || !s->x || (s->C != 64 && s->C != 80) || s->mode < 0 || s->mode > 2 || !wfrag || !bias || !wdw || !g1 ||
@@ -354,13 +384,14 @@ int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, con
     return sn_check_launch();
 }
 
-int sn_dw5_gemm_gate(const void* g1, const float* ca_in, const float* w5, const void* wfrag, void* g2, float* pool,
+int sn_dw5_gemm_gate(const void* g1, const float* ca_in, const uint32_t* w5, const void* wfrag, void* g2, float* pool,
                      int T, int h, int w, int C, void* stream) {
     sn_clear_error();
     if (!g1 || !w5 || !wfrag || !g2 || C != 64) return SN_EINVAL;
-    dim3 grid((w + 63) / 64, (h + SN_DW5_TY - 1) / SN_DW5_TY, T);
-    hipLaunchKernelGGL(dw5_gemm_gate_kernel<SN_DW5_TY>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g1, ca_in, w5,
-                       (const uint4*)wfrag, (bf16_t*)g2, pool, h, w, g_sn_debug);
+    const int ntiles = T * ((w + 63) / 64) * ((h + SN_DW5_TY - 1) / SN_DW5_TY);
+    const int nwg = ntiles < 512 ? ntiles : 512;            // 2 resident workgroups per CU x 256 CUs, persistent
+    hipLaunchKernelGGL(dw5_gemm_gate_kernel<SN_DW5_TY>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g1, ca_in, w5,
+                       (const uint4*)wfrag, (bf16_t*)g2, pool, T, h, w, g_sn_debug);
     return sn_check_launch();
 }
 

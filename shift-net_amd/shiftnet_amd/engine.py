@@ -84,7 +84,9 @@ class Plan:
             u["w1"] = self._dev(sd[pre + "conv1.weight"].reshape(c // 2, 9))
         g = prep.pack_ln_gemm(sd[f"{pre}body.{i}.weight"], sd[pre + "norm.weight"], sd[pre + "norm.bias"], c); i += 1
         u["w_ln"], u["b_ln"] = self._dev(g["wfrag"]), self._dev(g["bias"])
-        u["w_dw3"] = self._dev(prep.pack_dw3_gate(sd[f"{pre}body.{i}.conv_2.weight"], c)); i += 1
+        w3 = prep.pack_dw3_gate(sd[f"{pre}body.{i}.conv_2.weight"], c); i += 1
+        u["w_dw3"] = self._dev(w3)
+        u["w_dw3_d2"] = self._dev(prep.dot2_words(w3))
         i += 1
         if V.denoise:
             self.add_ca(f"{pre}ca1", f"{pre}body.{i}."); i += 1
@@ -93,7 +95,9 @@ class Plan:
             self.add_conv(pre + "rep", "", [c], weight=dense)
             u["w_dw5"] = self._dev(prep.identity_dw5(c))
         else:
-            u["w_dw5"] = self._dev(prep.pack_dw5(sd[f"{pre}body.{i}.conv_1.weight"], sd[f"{pre}body.{i}.conv_2.weight"]))
+            w5 = prep.pack_dw5(sd[f"{pre}body.{i}.conv_1.weight"], sd[f"{pre}body.{i}.conv_2.weight"])
+            u["w_dw5"] = self._dev(w5)
+            u["w_dw5_d2"] = self._dev(prep.dot2_words(w5))
         i += 1
         u["w_gate"] = self._dev(prep.pack_gate_gemm(sd[f"{pre}body.{i}.weight"], c)); i += 1
         i += 1
@@ -300,7 +304,7 @@ class Engine:
             if V.denoise:
                 pool1 = torch.empty((T, lib.sn_lngate_blocks(h, w), c), dtype=torch.float32, device=self.dev)
             self._call("sn_ln_gemm_gate", "sn_ln_gemm_gate", C.byref(src), hw_ptr, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(),
-                       u["w_dw3"].data_ptr(), g1.data_ptr(), pool1.data_ptr() if pool1 is not None else None, blocked, st)
+                       u["w_dw3_d2"].data_ptr(), g1.data_ptr(), pool1.data_ptr() if pool1 is not None else None, blocked, st)
         else:
             a = self._new(T, h, w, 2 * c)
             self._call("sn_ln_gemm", "sn_ln_gemm", C.byref(src), hw_ptr, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(), a.data_ptr(), st)
@@ -324,7 +328,7 @@ class Engine:
         k3 = "sn_dw5_gemm_gate" if (self.gsts_v >= 1 and c == 64 and not V.grouped_rep) else "sn_dw_gemm_gate"
         nb = lib.sn_dw5_blocks(h, w) if k3 == "sn_dw5_gemm_gate" else lib.sn_dwgemm_blocks(h, w)
         pool2 = torch.empty((T, nb, c), dtype=torch.float32, device=self.dev)
-        self._call(k3, k3, g1.data_ptr(), ca1_ptr, u["w_dw5"].data_ptr(), u["w_gate"].data_ptr(), g2.data_ptr(),
+        self._call(k3, k3, g1.data_ptr(), ca1_ptr, u["w_dw5_d2" if k3 == "sn_dw5_gemm_gate" else "w_dw5"].data_ptr(), u["w_gate"].data_ptr(), g2.data_ptr(),
                                     pool2.data_ptr(), T, h, w, c, st)
         ca2 = self.ca_mlp(pre + "ca2", pool2, h * w)
         y = self._new(T, h, w, c)

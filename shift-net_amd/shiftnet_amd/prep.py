@@ -168,3 +168,11 @@ def pack_out_gemm(w3: torch.Tensor, beta: torch.Tensor, bias3: Optional[torch.Te
 
 def shift_offsets_i8(table: List[Tuple[int, int]]) -> torch.Tensor:
     return torch.tensor(table, dtype=torch.int8).reshape(-1, 2).contiguous()
+
+
+def dot2_words(w: torch.Tensor) -> torch.Tensor:
+    """fp32 [..., N] -> int32 words for v_dot2c_f32_bf16: bf16(w[..., j]) in half (j & 1) of word j, other half zero."""
+    bits = w.to(torch.bfloat16).view(torch.int16).to(torch.int32) & 0xFFFF
+    n = w.shape[-1]
+    shift = (torch.arange(n) & 1) * 16
+    return (bits << shift).to(torch.int32).contiguous()
