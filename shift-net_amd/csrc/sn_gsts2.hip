@@ -30,16 +30,21 @@ __device__ __forceinline__ Slabs2 unit_slabs2(const UnitK2& U, int t) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+#ifndef SN_K12_TH
+#define SN_K12_TH 8
+#define SN_K12_NWV 8
+#endif
 template <int C, bool WITH_HW>
-__global__ __launch_bounds__(512) void ln_gemm_gate_kernel(const UnitK2 U, const bf16_t* __restrict__ hwb, const uint4* __restrict__ wfrag,
+__global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const UnitK2 U, const bf16_t* __restrict__ hwb, const uint4* __restrict__ wfrag,
                                                          const float* __restrict__ bias, const uint32_t* __restrict__ wdw,
                                                          bf16_t* g1, float* pool, const int blocked, const int dbg) {
     constexpr int CH = C / 2, K = WITH_HW ? C + CH : C, KS = (K + 31) / 32, MT = C / 8, NCHK = MT / 2;
-    constexpr int TH = 8, TW = 32, RH = TH + 2, RW = TW + 2, NPX = RH * RW;        // 340 pixels incl. the 1-pixel ring
-    constexpr int NWV = 8;                                                         // 512 threads: 8 waves
+    constexpr int TH = SN_K12_TH, TW = 32, RH = TH + 2, RW = TW + 2, NPX = RH * RW;  // tile + 1-pixel ring (8x32: 340 px, 16x32: 612 px)
+    constexpr int NWV = SN_K12_NWV;                                                // waves per workgroup
+    constexpr int NSPLIT = NWV / 4, ITERS = (TH * TW) / (64 * NSPLIT);             // stencil: 4 lane-group slots x NSPLIT pixel ranges
     constexpr int NTILES = (NPX + 15) / 16, NTW = (NTILES + NWV - 1) / NWV;        // 22 N-tiles, <= 3 per wave
     constexpr int PSA = 80;                                                        // LDS bytes per pixel of an a-chunk (64 + 16 pad)
-    __shared__ __attribute__((aligned(16))) char lds_a[NPX * PSA];
+    __shared__ __attribute__((aligned(16))) char lds_a2[2][NPX * PSA];           // double-buffered a-chunk: one barrier per chunk
     const int lane = threadIdx.x & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
     const int t = blockIdx.z, oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
     const int hw = U.h * U.w;
@@ -98,36 +103,41 @@ __global__ __launch_bounds__(512) void ln_gemm_gate_kernel(const UnitK2 U, const
     }
 
     float psum[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int q = 0; q < NCHK; ++q) {
-        // ---- GEMM chunk q: rows 2q (first-half channels) and 2q+1 (their gate partners) -> LDS, zero outside the image
-        {
-            f32x4_t acc0[NTW], acc1[NTW];
-            const float4 b0 = *(const float4*)(bias + g * 4 * MT + (2 * q) * 4);
-            const float4 b1 = *(const float4*)(bias + g * 4 * MT + (2 * q + 1) * 4);
+    // GEMM chunk q: rows 2q (first-half channels) and 2q+1 (their gate partners) -> LDS buffer q&1, zero outside the image
+    auto gemm_chunk = [&](int q) {
+        char* lds_a = lds_a2[q & 1];
+        f32x4_t acc0[NTW], acc1[NTW];
+        const float4 b0 = *(const float4*)(bias + g * 4 * MT + (2 * q) * 4);
+        const float4 b1 = *(const float4*)(bias + g * 4 * MT + (2 * q + 1) * 4);
 #pragma unroll
-            for (int n = 0; n < NTW; ++n) { acc0[n] = (f32x4_t){b0.x, b0.y, b0.z, b0.w}; acc1[n] = (f32x4_t){b1.x, b1.y, b1.z, b1.w}; }
+        for (int n = 0; n < NTW; ++n) { acc0[n] = (f32x4_t){b0.x, b0.y, b0.z, b0.w}; acc1[n] = (f32x4_t){b1.x, b1.y, b1.z, b1.w}; }
 #pragma unroll
-            for (int s = (dbg & 16) ? KS : 0; s < KS; ++s) {
-                const bf16x8_t a0 = as_frag(wfrag[((2 * q) * KS + s) * 64 + lane]);
-                const bf16x8_t a1 = as_frag(wfrag[((2 * q + 1) * KS + s) * 64 + lane]);
+        for (int s = (dbg & 16) ? KS : 0; s < KS; ++s) {
+            const bf16x8_t a0 = as_frag(wfrag[((2 * q) * KS + s) * 64 + lane]);
+            const bf16x8_t a1 = as_frag(wfrag[((2 * q + 1) * KS + s) * 64 + lane]);
 #pragma unroll
-                for (int n = 0; n < NTW; ++n) { acc0[n] = mfma16(a0, B[n][s], acc0[n]); acc1[n] = mfma16(a1, B[n][s], acc1[n]); }
-            }
+            for (int n = 0; n < NTW; ++n) { acc0[n] = mfma16(a0, B[n][s], acc0[n]); acc1[n] = mfma16(a1, B[n][s], acc1[n]); }
+        }
 #pragma unroll
-            for (int n = 0; n < NTW; ++n) {
-                const int rp = (wv + NWV * n) * 16 + p;
-                if (rp < NPX && (wv + NWV * n) < NTILES) {
-                    uint4 o = make_uint4(0, 0, 0, 0);
-                    if (inimg[n]) {
-                        o.x = pack_bf2(acc0[n][0], acc0[n][1]); o.y = pack_bf2(acc0[n][2], acc0[n][3]);
-                        o.z = pack_bf2(acc1[n][0], acc1[n][1]); o.w = pack_bf2(acc1[n][2], acc1[n][3]);
-                    }
-                    *(uint4*)(lds_a + rp * PSA + g * 16) = o;
+        for (int n = 0; n < NTW; ++n) {
+            const int rp = (wv + NWV * n) * 16 + p;
+            if (rp < NPX && (wv + NWV * n) < NTILES) {
+                uint4 o = make_uint4(0, 0, 0, 0);
+                if (inimg[n]) {
+                    o.x = pack_bf2(acc0[n][0], acc0[n][1]); o.y = pack_bf2(acc0[n][2], acc0[n][3]);
+                    o.z = pack_bf2(acc1[n][0], acc1[n][1]); o.w = pack_bf2(acc1[n][2], acc1[n][3]);
                 }
+                *(uint4*)(lds_a + rp * PSA + g * 16) = o;
             }
         }
+    };
+    gemm_chunk(0);
+#pragma unroll 1
+    for (int q = 0; q < NCHK; ++q) {
+        // one barrier per chunk: chunk q is complete in buffer q&1, and every wave is done reading buffer (q+1)&1 (chunk q-1)
         __syncthreads();
+        if (q + 1 < NCHK) gemm_chunk(q + 1);            // MFMA work of the next chunk overlaps this chunk's stencil
+        const char* lds_a = lds_a2[q & 1];
         // ---- depthwise 3x3 (+identity) and gate: waves (gs, gs+4) share lane-group slot gs of the chunk and split the
         //      tile's pixels in halves; lanes are pixels, the slot's weights are wave-uniform (scalar loads) ----
         {
@@ -138,8 +148,8 @@ __global__ __launch_bounds__(512) void ln_gemm_gate_kernel(const UnitK2 U, const
 #pragma unroll
                 for (int j = 0; j < 8; ++j) wt[tp][j] = wdw[tp * (2 * C) + gs * 4 * MT + q * 8 + j];
 #pragma unroll
-            for (int it = (dbg & 32) ? (TH * TW) / 128 : 0; it < (TH * TW) / 128; ++it) {
-                const int op = (half * ((TH * TW) / 128) + it) * 64 + lane, oy = op / TW, ox = op - oy * TW;
+            for (int it = (dbg & 32) ? ITERS : 0; it < ITERS; ++it) {
+                const int op = (half * ITERS + it) * 64 + lane, oy = op / TW, ox = op - oy * TW;
                 float o[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = 0.f;
@@ -170,14 +180,13 @@ __global__ __launch_bounds__(512) void ln_gemm_gate_kernel(const UnitK2 U, const
                     s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
                     s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
                     if (lane == 0) {
-                        const int nblk = 2 * gridDim.x * gridDim.y, blk = 2 * (blockIdx.y * gridDim.x + blockIdx.x) + half;
+                        const int nblk = NSPLIT * gridDim.x * gridDim.y, blk = NSPLIT * (blockIdx.y * gridDim.x + blockIdx.x) + half;
                         pool[((size_t)t * nblk + blk) * C + gs * 2 * MT + q * 4 + j] = s;
                     }
                     psum[j] = 0.f;
                 }
             }
         }
-        __syncthreads();
     }
 }
 
@@ -366,7 +375,7 @@ int sn_debug_set(int v) { g_sn_debug = v; return 0; }   /* profiling ablations o
 #endif
 int sn_dw5_blocks(int h, int w) { return ((h + SN_DW5_TY - 1) / SN_DW5_TY) * ((w + 63) / 64); }
 
-int sn_lngate_blocks(int h, int w) { return 2 * ((h + 7) / 8) * ((w + 31) / 32); }   /* two pixel halves per tile */
+int sn_lngate_blocks(int h, int w) { return (SN_K12_NWV / 4) * ((h + SN_K12_TH - 1) / SN_K12_TH) * ((w + 31) / 32); }
 
 int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, const uint32_t* wdw,
                     void* g1, float* pool, int g1_blocked, void* stream) {
@@ -374,9 +383,9 @@ int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, con
     if (!s || !s->x || (s->C != 64 && s->C != 80) || s->mode < 0 || s->mode > 2 || !wfrag || !bias || !wdw || !g1 ||
         (s->mode != 0 && !hw) || (g1_blocked && s->C != 64)) return SN_EINVAL;
     UnitK2 u; u.x = (const bf16_t*)s->x; u.T = s->T; u.h = s->h; u.w = s->w; u.C = s->C; u.mode = s->mode; u.wrap = s->wrap;
-    dim3 grid((s->w + 31) / 32, (s->h + 7) / 8, s->T);
+    dim3 grid((s->w + 31) / 32, (s->h + SN_K12_TH - 1) / SN_K12_TH, s->T);
     hipStream_t st = (hipStream_t)stream;
-#define SN_LAUNCH_K12(CC, HW_) hipLaunchKernelGGL((ln_gemm_gate_kernel<CC, HW_>), grid, dim3(512), 0, st, u, (const bf16_t*)hw, \
+#define SN_LAUNCH_K12(CC, HW_) hipLaunchKernelGGL((ln_gemm_gate_kernel<CC, HW_>), grid, dim3(SN_K12_NWV * 64), 0, st, u, (const bf16_t*)hw, \
         (const uint4*)wfrag, bias, wdw, (bf16_t*)g1, pool, g1_blocked, g_sn_debug)
     if (s->C == 64) { if (s->mode) SN_LAUNCH_K12(64, true); else SN_LAUNCH_K12(64, false); }
     else { if (s->mode) SN_LAUNCH_K12(80, true); else SN_LAUNCH_K12(80, false); }
