@@ -99,8 +99,9 @@ int sn_gsts_gather(const sn_unit_src* s, const int8_t* offs, void* u, void* stre
 int sn_temporal_roll(const sn_unit_src* s, void* y, void* stream);
 
 /* hw = CAB2.conv1(spatial_shift2(borrowed half)) (gshift_deblur1.py:470-503,223,251): depthwise 3x3 of the
- * zero-padded displaced neighbour-frame channels, never materialising the shifted tensor.  w1:[C/2][9] f32. */
-int sn_gsts_shiftconv(const sn_unit_src* s, const int8_t* offs, const float* w1, void* hw, void* stream);
+ * zero-padded displaced neighbour-frame channels, never materialising the shifted tensor.
+ * w1:[C/2][9] u32 words: the bf16 weight in the LOW half, high half zero (operand of v_dot2c_f32_bf16). */
+int sn_gsts_shiftconv(const sn_unit_src* s, const int8_t* offs, const uint32_t* w1, void* hw, void* stream);
 
 /* a = body[0](norm(cat(shortcut, hw))): LayerNorm2d over 3C/2 (CAB2) or C (CAB1) channels, eps 1e-6, affine folded
  * into the 1x1 weights, then the 1x1 conv to 2C (gshift_deblur1.py:19-28,190,225,252).  a:[T][h][w][2C] in

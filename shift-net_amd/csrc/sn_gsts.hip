@@ -63,24 +63,62 @@ __global__ void gather_kernel(const UnitK U, const int8_t* offs, bf16_t* u, cons
 // K0: hw[t][p][k] = sum_tap w1[k][tap] * [p+tap in image] * shifted_k(p+tap),  shifted_k(q) = x[fb][q + off_k][ob + k] or 0
 template <int CH>
 __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const int8_t* __restrict__ offs,
-                                                      const float* __restrict__ w1, bf16_t* hw) {
+                                                      const uint32_t* __restrict__ w1d, bf16_t* hw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RW = 34, PSB = CH * 2 + 4;       // odd number of dwords per pixel: lanes = pixels hit distinct banks
     constexpr int PCS = CH / 8;
     const int tid = threadIdx.x, t = blockIdx.z, y0 = blockIdx.y * 16, x0 = blockIdx.x * 16;
     const Slabs s = unit_slabs(U, t);
     const bf16_t* src = U.x + (size_t)s.fb * U.h * U.w * U.C + s.ob;
-    for (int idx = tid; idx < RW * RW * PCS; idx += 256) {
-        const int pix = idx / PCS, pc = idx - pix * PCS;
-        const int ry = pix / RW, rx = pix - ry * RW;
-        const int gy = y0 - 9 + ry, gx = x0 - 9 + rx;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (gy >= 0 && gy < U.h && gx >= 0 && gx < U.w) v = *(const uint4*)(src + ((size_t)gy * U.w + gx) * U.C + pc * 8);
-        uint32_t* d = (uint32_t*)(smem + pix * PSB + pc * 16);
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    {   // staging: issue ALL global loads first (branch-free, clamped addresses), then mask + write to LDS: one memory
+        // round trip per workgroup instead of one per loop iteration
+        constexpr int NIT = (RW * RW * PCS + 255) / 256;
+        uint4 v[NIT];
+        int lo[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int idx = tid + k * 256;
+            const int pix = idx / PCS, pc = idx - pix * PCS;
+            const int ry = pix / RW, rx = pix - ry * RW;
+            const int gy = y0 - 9 + ry, gx = x0 - 9 + rx;
+            const bool in = idx < RW * RW * PCS && gy >= 0 && gy < U.h && gx >= 0 && gx < U.w;
+            lo[k] = idx < RW * RW * PCS ? (in ? pix * PSB + pc * 16 : -(pix * PSB + pc * 16) - 1) : 0x7fffffff;
+            v[k] = *(const uint4*)(src + (in ? ((size_t)gy * U.w + gx) * U.C + pc * 8 : 0));
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            if (lo[k] == 0x7fffffff) continue;
+            const bool in = lo[k] >= 0;
+            uint32_t* d = (uint32_t*)(smem + (in ? lo[k] : -(lo[k] + 1)));
+            d[0] = in ? v[k].x : 0u; d[1] = in ? v[k].y : 0u; d[2] = in ? v[k].z : 0u; d[3] = in ? v[k].w : 0u;
+        }
     }
     __syncthreads();
     const int px = tid & 15, py = tid >> 4, oy = y0 + py, ox = x0 + px;
+    const bool valid = oy < U.h && ox < U.w;
+    // interior tiles (every tap position p+tap of every output pixel is inside the image): no conv-padding masks at all,
+    // and each tap is ONE v_dot2c on the zero-extended bf16 value with a packed weight word (bf16 weight in the low half)
+    const bool interior = y0 >= 1 && x0 >= 1 && y0 + 16 < U.h && x0 + 16 < U.w;
+    if (interior) {
+        for (int kc = 0; kc < PCS; ++kc) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = kc * 8 + j;
+                const int dy = offs[2 * k], dx = offs[2 * k + 1];
+                const char* base = smem + ((py + 8 + dy) * RW + (px + 8 + dx)) * PSB + k * 2;
+                float acc = 0.f;
+#pragma unroll
+                for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx)
+                        acc = dot2bf((uint32_t)(*(const bf16_t*)(base + (ty * RW + tx) * PSB)), w1d[k * 9 + ty * 3 + tx], acc);
+                o[j] = acc;
+            }
+            *(uint4*)(hw + (((size_t)t * U.h + oy) * U.w + ox) * CH + kc * 8) = pack8(o);
+        }
+        return;
+    }
     float m[9];
 #pragma unroll
     for (int ty = 0; ty < 3; ++ty)
@@ -89,7 +127,6 @@ __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const int
             const int qy = oy + ty - 1, qx = ox + tx - 1;
             m[ty * 3 + tx] = (qy >= 0 && qy < U.h && qx >= 0 && qx < U.w) ? 1.f : 0.f;
         }
-    const bool valid = oy < U.h && ox < U.w;
     for (int kc = 0; kc < PCS; ++kc) {
         float o[8];
 #pragma unroll
@@ -102,8 +139,8 @@ __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const int
             for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
                 for (int tx = 0; tx < 3; ++tx) {
-                    const float v = bf_to_f(*(const bf16_t*)(base + (ty * RW + tx) * PSB));
-                    acc += w1[k * 9 + ty * 3 + tx] * m[ty * 3 + tx] * v;
+                    const float v = m[ty * 3 + tx] * bf_to_f(*(const bf16_t*)(base + (ty * RW + tx) * PSB));
+                    acc = dot2bf(__float_as_uint(v) >> 16, w1d[k * 9 + ty * 3 + tx], acc);   // same bf16 weights as the fast path
                 }
             o[j] = acc;
         }
@@ -454,7 +491,7 @@ int sn_temporal_roll(const sn_unit_src* s, void* y, void* stream) {
     return sn_check_launch();
 }
 
-int sn_gsts_shiftconv(const sn_unit_src* s, const int8_t* offs, const float* w1, void* hw, void* stream) {
+int sn_gsts_shiftconv(const sn_unit_src* s, const int8_t* offs, const uint32_t* w1, void* hw, void* stream) {
     sn_clear_error();
     if (!unit_ok(s) || !offs || !w1 || !hw || s->mode == 0) return SN_EINVAL;
     dim3 grid((s->w + 15) / 16, (s->h + 15) / 16, s->T);

@@ -81,7 +81,8 @@ class Plan:
         u: Dict[str, object] = {}
         i = 0
         if with_shift:
-            u["w1"] = self._dev(sd[pre + "conv1.weight"].reshape(c // 2, 9))
+            w1 = sd[pre + "conv1.weight"].reshape(c // 2, 9)
+            u["w1"] = self._dev((w1.to(torch.bfloat16).view(torch.int16).to(torch.int32) & 0xFFFF).contiguous())   # bf16 in the low half
         g = prep.pack_ln_gemm(sd[f"{pre}body.{i}.weight"], sd[pre + "norm.weight"], sd[pre + "norm.bias"], c); i += 1
         u["w_ln"], u["b_ln"] = self._dev(g["wfrag"]), self._dev(g["bias"])
         w3 = prep.pack_dw3_gate(sd[f"{pre}body.{i}.conv_2.weight"], c); i += 1
