@@ -86,7 +86,7 @@ def cpu_baseline_subprocess(timeout_s=240):
                 "sample": f"cpu leg exceeded {timeout_s} s and was stopped"}
 
 
-def cpu_baseline(budget_s=15.0):
+def cpu_baseline(budget_s=7.0):
     """The CPU oracle (a port of the reference forward, kind 'port') timed on this host's cores on a bounded sample."""
     from oracle import shiftnet_oracle as O
     from shiftnet_amd import synth
@@ -196,9 +196,16 @@ def main():
         unit_ms = 0.0
         unit_bytes = 0.0
         for fn, label, meta, e0, e1 in eng.prof:
-            a = agg.setdefault(fn, {"ms": 0.0, "n": 0, "bytes": 0.0})
+            key = fn
+            if fn == "sn_conv2d":                       # one GPU kernel per (M-tiles, tile shape): key by template instance
+                mt = -(-max(meta[5], 1) // 16) if meta[9] != 1 else -(-meta[5] * 4 // 16)
+                key = f"sn_conv2d<mt{mt},{'8x32' if meta[7] == 1 else '4x16'}>"
+            elif fn == "sn_ln_gemm_gate":
+                key = f"sn_ln_gemm_gate<{'cab2' if meta[5] else 'cab1'}>"
+            a = agg.setdefault(key, {"ms": 0.0, "n": 0, "bytes": 0.0})
             d = e0.elapsed_time(e1)
             a["ms"] += d; a["n"] += 1; a["bytes"] += kernel_alg_bytes(fn, meta)
+            fn = key
             if meta and meta[0] == "naf":
                 unit_ms += d
                 if fn == "sn_scale_gemm_res":            # one CAB finished: its fused-unit bytes = read x + write y

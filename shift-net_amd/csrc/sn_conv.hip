@@ -73,18 +73,31 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK P) {
     {
         const int nblk8 = P.cv >> 3, csb = P.cs >> 3, total = P.rh * P.rw * nblk8;
         const int iy0 = oy0 * P.stride - P.pad, ix0 = ox0 * P.stride - P.pad;
-        for (int idx = tid; idx < total; idx += 256) {
-            const int pix = fdiv(idx, P.m_nblk8), blk = idx - pix * nblk8;
-            const int ry = fdiv(pix, P.m_rw), rx = pix - ry * P.rw;
-            const int ii = fdiv(blk, P.m_csb), cb = blk - ii * csb;
-            const bf16_t* src = ii == 0 ? P.in0 : (ii == 1 ? P.in1 : P.in2);
-            const int gy = iy0 + ry, gx = ix0 + rx;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (gy >= 0 && gy < P.hin && gx >= 0 && gx < P.win) {
-                if (P.in_mode == 0) v = *(const uint4*)(src + (((size_t)t * P.hin + gy) * P.win + gx) * P.cs + cb * 8);
-                else v = ld_bilinear(src, t, P.hin >> 1, P.win >> 1, P.cs, cb, gy, gx);
+        // loads are issued in batches of 4 before any LDS write (clamped addresses, masked afterwards): a load inside a
+        // branch is waited for immediately, which serialises one memory round trip per item
+        for (int idx0 = tid; idx0 < total; idx0 += 4 * 256) {
+            uint4 v[4];
+            int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * 256;
+                const int idc = idx < total ? idx : tid;
+                const int pix = fdiv(idc, P.m_nblk8), blk = idc - pix * nblk8;
+                const int ry = fdiv(pix, P.m_rw), rx = pix - ry * P.rw;
+                const int ii = fdiv(blk, P.m_csb), cb = blk - ii * csb;
+                const bf16_t* src = ii == 0 ? P.in0 : (ii == 1 ? P.in1 : P.in2);
+                const int gy = iy0 + ry, gx = ix0 + rx;
+                const bool in = gy >= 0 && gy < P.hin && gx >= 0 && gx < P.win;
+                dst[u] = idx < total ? (in ? pix * P.ps + blk * 16 : -(pix * P.ps + blk * 16) - 1) : 0x7fffffff;
+                if (P.in_mode == 0) v[u] = *(const uint4*)(src + (in ? (((size_t)t * P.hin + gy) * P.win + gx) * P.cs + cb * 8 : 0));
+                else v[u] = in ? ld_bilinear(src, t, P.hin >> 1, P.win >> 1, P.cs, cb, gy, gx) : make_uint4(0, 0, 0, 0);
             }
-            *(uint4*)(smem + pix * P.ps + blk * 16) = v;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (dst[u] == 0x7fffffff) continue;
+                const bool in = dst[u] >= 0;
+                *(uint4*)(smem + (in ? dst[u] : -(dst[u] + 1))) = in ? v[u] : make_uint4(0, 0, 0, 0);
+            }
         }
     }
     __syncthreads();

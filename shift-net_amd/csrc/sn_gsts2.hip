@@ -67,18 +67,19 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int kk0 = s * 32 + g * 8;
-            const bf16_t* src = nullptr;
-            if (kk0 < CH) src = U.x + ((size_t)sl.f0 * hw + ii) * C + sl.o0 + kk0;
-            else if (kk0 < C) src = U.x + ((size_t)sl.f1 * hw + ii) * C + sl.o1 + kk0 - CH;
-            else if (WITH_HW && kk0 < K) src = hwb + ((size_t)t * hw + ii) * CH + kk0 - C;
-            if (src && !(dbg & 8)) {
-                unpack8(*(const uint4*)src, xv[s]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) sum += xv[s][j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) xv[s][j] = 0.f;
+            // branch-free: pick the address with selects and ALWAYS load (a load inside a divergent branch is waited
+            // for on the spot, one memory round trip per slab); padding slabs re-read x and are zeroed afterwards
+            const bool has = kk0 < K && !(dbg & 8);
+            const bf16_t* s0 = U.x + ((size_t)sl.f0 * hw + ii) * C + sl.o0 + (kk0 < CH ? kk0 : 0);
+            const bf16_t* s1 = U.x + ((size_t)sl.f1 * hw + ii) * C + sl.o1 + (kk0 >= CH && kk0 < C ? kk0 - CH : 0);
+            const bf16_t* src = kk0 < CH ? s0 : s1;
+            if (WITH_HW) {
+                const bf16_t* s2 = hwb + ((size_t)t * hw + ii) * CH + (kk0 >= C && kk0 < K ? kk0 - C : 0);
+                src = kk0 >= C ? s2 : src;
             }
+            unpack8(*(const uint4*)src, xv[s]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { xv[s][j] = has ? xv[s][j] : 0.f; sum += xv[s][j]; }
         }
         sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
         const float mean = sum * (1.0f / K);
