@@ -41,7 +41,6 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
     constexpr int CH = C / 2, K = WITH_HW ? C + CH : C, KS = (K + 31) / 32, MT = C / 8, NCHK = MT / 2;
     constexpr int TH = SN_K12_TH, TW = 32, RH = TH + 2, RW = TW + 2, NPX = RH * RW;  // tile + 1-pixel ring (8x32: 340 px, 16x32: 612 px)
     constexpr int NWV = SN_K12_NWV;                                                // waves per workgroup
-    constexpr int NSPLIT = NWV / 4, ITERS = (TH * TW) / (64 * NSPLIT);             // stencil: 4 lane-group slots x NSPLIT pixel ranges
     constexpr int NTILES = (NPX + 15) / 16, NTW = (NTILES + NWV - 1) / NWV;        // 22 N-tiles, <= 3 per wave
     constexpr int PSA = 80;                                                        // LDS bytes per pixel of an a-chunk (64 + 16 pad)
     __shared__ __attribute__((aligned(16))) char lds_a2[2][NPX * PSA];           // double-buffered a-chunk: one barrier per chunk
@@ -103,7 +102,6 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
         }
     }
 
-    float psum[4] = {0.f, 0.f, 0.f, 0.f};
     // GEMM chunk q: rows 2q (first-half channels) and 2q+1 (their gate partners) -> LDS buffer q&1, zero outside the image
     auto gemm_chunk = [&](int q) {
         char* lds_a = lds_a2[q & 1];
@@ -139,52 +137,63 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
         __syncthreads();
         if (q + 1 < NCHK) gemm_chunk(q + 1);            // MFMA work of the next chunk overlaps this chunk's stencil
         const char* lds_a = lds_a2[q & 1];
-        // ---- depthwise 3x3 (+identity) and gate: waves (gs, gs+4) share lane-group slot gs of the chunk and split the
-        //      tile's pixels in halves; lanes are pixels, the slot's weights are wave-uniform (scalar loads) ----
+        // ---- depthwise 3x3 (+identity) and gate.  Wave = (64-pixel group pg, lane-group-slot pair gp): it handles slots
+        //      2gp and 2gp+1 one after the other (the slot's weights are wave-uniform scalar loads), lanes are pixels, so a
+        //      lane ends up with 8 consecutive g1 channels of the chunk block = ONE 16-byte store per pixel and chunk.
         {
-            const int gs = wv & 3, half = wv >> 2;
-            uint32_t wt[9][8];            // weight of position j as bf16 in half (j & 1) of its word, other half zero
+            static_assert(NWV == 2 * ((TH * TW) / 64), "K12 stencil mapping: two waves per 64-pixel group");
+            const int pg = wv % ((TH * TW) / 64), gp = wv / ((TH * TW) / 64);
+            const int op = pg * 64 + lane, oy = op / TW, ox = op - oy * TW;
+            const int gy = oy0 + oy, gx = ox0 + ox;
+            const bool inside = gy < U.h && gx < U.w;
+            uint32_t ow[4];
 #pragma unroll
-            for (int tp = 0; tp < 9; ++tp)
+            for (int gi = 0; gi < 2; ++gi) {
+                const int gs = gp * 2 + gi;
+                uint32_t wt[9][8];            // weight of position j as bf16 in half (j & 1) of its word, other half zero
 #pragma unroll
-                for (int j = 0; j < 8; ++j) wt[tp][j] = wdw[tp * (2 * C) + gs * 4 * MT + q * 8 + j];
+                for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-            for (int it = (dbg & 32) ? ITERS : 0; it < ITERS; ++it) {
-                const int op = (half * ITERS + it) * 64 + lane, oy = op / TW, ox = op - oy * TW;
+                    for (int j = 0; j < 8; ++j) wt[tp][j] = wdw[tp * (2 * C) + gs * 4 * MT + q * 8 + j];
                 float o[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = 0.f;
+                if (!(dbg & 32)) {
 #pragma unroll
-                for (int ty = 0; ty < 3; ++ty)
+                    for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
-                    for (int tx = 0; tx < 3; ++tx) {
-                        const uint4 v = *(const uint4*)(lds_a + ((oy + ty) * RW + ox + tx) * PSA + gs * 16);
-                        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+                        for (int tx = 0; tx < 3; ++tx) {
+                            const uint4 v = *(const uint4*)(lds_a + ((oy + ty) * RW + ox + tx) * PSA + gs * 16);
+                            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) o[j] = dot2bf(d[j >> 1], wt[ty * 3 + tx][j], o[j]);
+                            for (int j = 0; j < 8; ++j) o[j] = dot2bf(d[j >> 1], wt[ty * 3 + tx][j], o[j]);
+                        }
+                }
+                const float r0 = o[0] * o[4], r1 = o[1] * o[5], r2 = o[2] * o[6], r3 = o[3] * o[7];
+                ow[2 * gi] = pack_bf2(r0, r1); ow[2 * gi + 1] = pack_bf2(r2, r3);
+                if (pool) {                   // denoise CALayer2 on g1: per-wave channel sums (4 channels of slot gs)
+                    float ps[4] = {inside ? r0 : 0.f, inside ? r1 : 0.f, inside ? r2 : 0.f, inside ? r3 : 0.f};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float sm = ps[j];
+                        sm += __shfl_xor(sm, 1); sm += __shfl_xor(sm, 2); sm += __shfl_xor(sm, 4); sm += __shfl_xor(sm, 8);
+                        sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+                        if (lane == 0) {
+                            constexpr int NPG = (TH * TW) / 64;
+                            const int nblk = NPG * gridDim.x * gridDim.y, blk = NPG * (blockIdx.y * gridDim.x + blockIdx.x) + pg;
+                            pool[((size_t)t * nblk + blk) * C + gs * 2 * MT + q * 4 + j] = sm;
+                        }
                     }
-                const int gy = oy0 + oy, gx = ox0 + ox;
-                if (gy < U.h && gx < U.w) {
-                    const float r0 = o[0] * o[4], r1 = o[1] * o[5], r2 = o[2] * o[6], r3 = o[3] * o[7];
-                    uint2 qv; qv.x = pack_bf2(r0, r1); qv.y = pack_bf2(r2, r3);
-                    // natural NHWC, or (C = 64 only) channel-blocked [T][4][h][w][16] (block = this wave's 16 channels) so
-                    // that sn_dw5_gemm_gate stages 16 channels of a pixel row as one contiguous run
-                    if (blocked) *(uint2*)(g1 + (((size_t)t * 4 + gs) * hw + (size_t)gy * U.w + gx) * 16 + q * 4) = qv;
-                    else *(uint2*)(g1 + ((size_t)t * hw + (size_t)gy * U.w + gx) * C + gs * 2 * MT + q * 4) = qv;
-                    psum[0] += r0; psum[1] += r1; psum[2] += r2; psum[3] += r3;
                 }
             }
-            if (pool) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float s = psum[j];
-                    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-                    s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-                    if (lane == 0) {
-                        const int nblk = NSPLIT * gridDim.x * gridDim.y, blk = NSPLIT * (blockIdx.y * gridDim.x + blockIdx.x) + half;
-                        pool[((size_t)t * nblk + blk) * C + gs * 2 * MT + q * 4 + j] = s;
-                    }
-                    psum[j] = 0.f;
+            if (inside) {
+                const size_t pix = (size_t)gy * U.w + gx;
+                if (blocked) {   // chunk-blocked [T][NCHK][h][w][16]: block q, position gs*4 + r  <->  channel gs*2*MT + q*4 + r
+                    *(uint4*)(g1 + (((size_t)t * NCHK + q) * hw + pix) * 16 + gp * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                } else {         // natural NHWC
+                    bf16_t* dst = g1 + ((size_t)t * hw + pix) * C + q * 4;
+                    *(uint2*)(dst + (gp * 2) * 2 * MT) = make_uint2(ow[0], ow[1]);
+                    *(uint2*)(dst + (gp * 2 + 1) * 2 * MT) = make_uint2(ow[2], ow[3]);
                 }
             }
         }
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(256) void dw5_gemm_gate_kernel(const bf16_t* __rest
             }
             float sc[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sc[j] = ca_in ? ca_in[(size_t)t * C + cb * 4 + j] : 1.f;
+            for (int j = 0; j < 4; ++j) sc[j] = ca_in ? ca_in[(size_t)t * C + wv * 16 + pass * 4 + j] : 1.f;   // channel of (pass, wv, j)
 #pragma unroll
             for (int oy = 0; oy < TY; ++oy) {
                 uint2 o;
@@ -376,7 +385,7 @@ int sn_debug_set(int v) { g_sn_debug = v; return 0; }   /* profiling ablations o
 #endif
 int sn_dw5_blocks(int h, int w) { return ((h + SN_DW5_TY - 1) / SN_DW5_TY) * ((w + 63) / 64); }
 
-int sn_lngate_blocks(int h, int w) { return (SN_K12_NWV / 4) * ((h + SN_K12_TH - 1) / SN_K12_TH) * ((w + 31) / 32); }
+int sn_lngate_blocks(int h, int w) { return (SN_K12_TH * 32 / 64) * ((h + SN_K12_TH - 1) / SN_K12_TH) * ((w + 31) / 32); }
 
 int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, const uint32_t* wdw,
                     void* g1, float* pool, int g1_blocked, void* stream) {

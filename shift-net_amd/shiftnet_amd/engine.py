@@ -98,9 +98,14 @@ class Plan:
         else:
             w5 = prep.pack_dw5(sd[f"{pre}body.{i}.conv_1.weight"], sd[f"{pre}body.{i}.conv_2.weight"])
             u["w_dw5"] = self._dev(w5)
-            u["w_dw5_d2"] = self._dev(prep.dot2_words(w5))
+            if c == 64:      # v1 path: g1 / r travel in chunk-block position order (prep.chunk_block_perm)
+                perm = torch.from_numpy(prep.chunk_block_perm(c))
+                u["w_dw5_d2"] = self._dev(prep.dot2_words(w5[:, perm]))
         i += 1
-        u["w_gate"] = self._dev(prep.pack_gate_gemm(sd[f"{pre}body.{i}.weight"], c)); i += 1
+        u["w_gate"] = self._dev(prep.pack_gate_gemm(sd[f"{pre}body.{i}.weight"], c))
+        if c == 64 and not V.grouped_rep:
+            u["w_gate_blk"] = self._dev(prep.pack_gate_gemm_blocked(sd[f"{pre}body.{i}.weight"], c))
+        i += 1
         i += 1
         self.add_ca(f"{pre}ca2", f"{pre}body.{i}."); i += 1
         o = prep.pack_out_gemm(sd[f"{pre}body.{i}.weight"], sd[pre + "beta"], sd.get(f"{pre}body.{i}.bias"), c)
@@ -329,7 +334,8 @@ class Engine:
         k3 = "sn_dw5_gemm_gate" if (self.gsts_v >= 1 and c == 64 and not V.grouped_rep) else "sn_dw_gemm_gate"
         nb = lib.sn_dw5_blocks(h, w) if k3 == "sn_dw5_gemm_gate" else lib.sn_dwgemm_blocks(h, w)
         pool2 = torch.empty((T, nb, c), dtype=torch.float32, device=self.dev)
-        self._call(k3, k3, g1.data_ptr(), ca1_ptr, u["w_dw5_d2" if k3 == "sn_dw5_gemm_gate" else "w_dw5"].data_ptr(), u["w_gate"].data_ptr(), g2.data_ptr(),
+        self._call(k3, k3, g1.data_ptr(), ca1_ptr, u["w_dw5_d2" if k3 == "sn_dw5_gemm_gate" else "w_dw5"].data_ptr(),
+                   u["w_gate_blk" if k3 == "sn_dw5_gemm_gate" else "w_gate"].data_ptr(), g2.data_ptr(),
                                     pool2.data_ptr(), T, h, w, c, st)
         ca2 = self.ca_mlp(pre + "ca2", pool2, h * w)
         y = self._new(T, h, w, c)

@@ -176,3 +176,21 @@ def dot2_words(w: torch.Tensor) -> torch.Tensor:
     n = w.shape[-1]
     shift = (torch.arange(n) & 1) * 16
     return (bits << shift).to(torch.int32).contiguous()
+
+
+def chunk_block_perm(c: int = 64) -> np.ndarray:
+    """position -> channel of the chunk-blocked g1 / r layout used between sn_ln_gemm_gate and sn_dw5_gemm_gate (C = 64):
+    position pos = q*16 + gs*4 + r (block q written by chunk q of K12)  <->  channel gs*16 + q*4 + r."""
+    assert c == 64
+    pos = np.arange(c)
+    q, gs, r = pos // 16, (pos % 16) // 4, pos % 4
+    return gs * 16 + q * 4 + r
+
+
+def pack_gate_gemm_blocked(w2: torch.Tensor, c: int) -> torch.Tensor:
+    """pack_gate_gemm with the K axis in chunk-block position order."""
+    w = w2.detach().float().cpu().numpy().reshape(2 * c, c)[:, chunk_block_perm(c)]
+    ks = (c + 31) // 32
+    wp = np.zeros((16 * (c // 8), 32 * ks), np.float32)
+    wp[rows_gate(c), :c] = w
+    return pack_frag(wp)
