@@ -137,6 +137,13 @@ int sn_debug_set(int v);
 int sn_dw5_gemm_gate(const void* g1, const float* ca_in, const uint32_t* w5, const void* wfrag, void* g2, float* pool,
                      int T, int h, int w, int C, void* stream);
 
+/* "+" variants: RepConv with groups = C/8 (gshift_deblur1.py:157-165) as a block-diagonal MFMA GEMM, then body[4]
+ * (1x1 C->2C), SimpleGate2 and the channel sums.  g1:[T][h][w][C] natural NHWC, wgrp: prep.pack_grouped_frag
+ * [C/16][13][64][8] bf16 (3x3 and identity folded), C = 80.  pool: [T][sn_grp5_blocks][C]. */
+int sn_grp5_gemm_gate(const void* g1, const float* ca_in, const void* wgrp, const void* wfrag, void* g2, float* pool,
+                      int T, int h, int w, int C, void* stream);
+int sn_grp5_blocks(int h, int w);
+
 /* y = shortcut + beta * body[7](ca * g2) (gshift_deblur1.py:201,210,254): beta and the optional bias are folded
  * into wfrag/bias; the shortcut is the ROLLED tensor for CAB2 (mode 1/2) and x for CAB1 (mode 0). */
 int sn_scale_gemm_res(const sn_unit_src* s, const void* g2, const float* ca, const void* wfrag, const float* bias,

@@ -373,6 +373,149 @@ __global__ __launch_bounds__(256) void dw5_gemm_gate_kernel(const bf16_t* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// K3g ("+" variants, RepConv with groups = C/8): grouped 5x5 (+3x3 +identity folded) as a block-diagonal MFMA GEMM
+// (one M-tile = two groups of 8 output channels, K = 25 taps x their 16 input channels, half of each A fragment is zero),
+// then the 1x1 C -> 2C, SimpleGate2 and the channel sums.  Tile 32 x 4 pixels, g1 region (+2 ring, all C channels) in LDS.
+template <int C>
+__global__ __launch_bounds__(256) void grp5_gemm_gate_kernel(const bf16_t* __restrict__ g1, const float* __restrict__ ca_in,
+                                                           const uint4* __restrict__ wgrp, const uint4* __restrict__ wfrag,
+                                                           bf16_t* g2, float* pool, int h, int w) {
+    constexpr int TY = 4, TXW = 32, RH = TY + 4, RW = TXW + 4, PS = C * 2 + 16, MTG = C / 16, KSG = 13;
+    constexpr int MT = C / 8, KS = (C + 31) / 32, NPC = C / 8, NT = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_g = smem;                                  // [RH*RW][PS]
+    char* lds_r = smem + RH * RW * PS;                   // [TY*TXW][PS]
+    float* red = (float*)(lds_r + TY * TXW * PS);        // [4][C]
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
+    const int t = blockIdx.z, y0 = blockIdx.y * TY, x0 = blockIdx.x * TXW;
+    const bf16_t* gt = g1 + (size_t)t * h * w * C;
+
+    {   // stage the region: all loads first (branch-free), then optional CALayer2 scale, mask and LDS write
+        constexpr int NIT = (RH * RW * NPC + 255) / 256;
+        uint4 v[NIT];
+        int lo[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int idx = tid + k * 256, pix = idx / NPC, pc = idx - pix * NPC;
+            const int ry = pix / RW, rx = pix - ry * RW, gy = y0 - 2 + ry, gx = x0 - 2 + rx;
+            const bool live = idx < RH * RW * NPC, in = live && gy >= 0 && gy < h && gx >= 0 && gx < w;
+            lo[k] = live ? (in ? pix * PS + pc * 16 : -(pix * PS + pc * 16) - 1) : 0x7fffffff;
+            v[k] = *(const uint4*)(gt + (in ? ((size_t)gy * w + gx) * C + pc * 8 : 0));
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            if (lo[k] == 0x7fffffff) continue;
+            const bool in = lo[k] >= 0;
+            const int off = in ? lo[k] : -(lo[k] + 1);
+            uint4 q = in ? v[k] : make_uint4(0, 0, 0, 0);
+            if (ca_in && in) {
+                const int pc = (off % PS) >> 4;
+                float f[8];
+                unpack8(q, f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] *= ca_in[(size_t)t * C + pc * 8 + j];
+                q = pack8(f);
+            }
+            *(uint4*)(lds_g + off) = q;
+        }
+    }
+    __syncthreads();
+
+    // ---- grouped 5x5: k-step s covers taps 2s, 2s+1; lane group g -> tap 2s + (g>>1), input channels 16*mt + (g&1)*8 ..
+    {
+        f32x4_t acc[MTG][NT];
+#pragma unroll
+        for (int m = 0; m < MTG; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        int pbase[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int nt = wv * NT + n, row = nt >> 1, xb = nt & 1;
+            pbase[n] = (row * RW + xb * 16 + p) * PS + (g & 1) * 16;
+        }
+#pragma unroll 1
+        for (int s = 0; s < KSG; ++s) {
+            int tap = 2 * s + (g >> 1);
+            tap = tap < 25 ? tap : 0;                     // the 26th slot has zero weights: any valid address will do
+            const int dy = tap / 5, dx = tap - dy * 5;
+            const int toff = (dy * RW + dx) * PS;
+#pragma unroll
+            for (int m = 0; m < MTG; ++m) {
+                const bf16x8_t a = as_frag(wgrp[(m * KSG + s) * 64 + lane]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = mfma16(a, as_frag(*(const uint4*)(lds_g + pbase[n] + toff + m * 32)), acc[m][n]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MTG; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                uint2 o; o.x = pack_bf2(acc[m][n][0], acc[m][n][1]); o.y = pack_bf2(acc[m][n][2], acc[m][n][3]);
+                *(uint2*)(lds_r + ((wv * NT + n) * 16 + p) * PS + (m * 16 + g * 4) * 2) = o;
+            }
+    }
+    __syncthreads();
+
+    // ---- 1x1 C -> 2C (gate-paired rows), SimpleGate2, stores, channel sums ----
+    float ps[MT / 2][4];
+#pragma unroll
+    for (int mp = 0; mp < MT / 2; ++mp)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) ps[mp][rr] = 0.f;
+#pragma unroll 1
+    for (int n = 0; n < NT; ++n) {
+        const int tp = (wv * NT + n) * 16 + p;
+        bf16x8_t Bf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int kk0 = s * 32 + g * 8;
+            Bf[s] = as_frag(kk0 < C ? *(const uint4*)(lds_r + tp * PS + kk0 * 2) : make_uint4(0, 0, 0, 0));
+        }
+        uint32_t o[MT];
+#pragma unroll
+        for (int mp = 0; mp < MT / 2; ++mp) {
+            f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                a0 = mfma16(as_frag(wfrag[((2 * mp) * KS + s) * 64 + lane]), Bf[s], a0);
+                a1 = mfma16(as_frag(wfrag[((2 * mp + 1) * KS + s) * 64 + lane]), Bf[s], a1);
+            }
+            float v[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) v[rr] = a0[rr] * sigmoidf_(a1[rr]);
+            o[2 * mp] = pack_bf2(v[0], v[1]); o[2 * mp + 1] = pack_bf2(v[2], v[3]);
+            const int oyv = y0 + (tp >> 5), oxv = x0 + (tp & 31);
+            if (oyv < h && oxv < w) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) ps[mp][rr] += v[rr];
+            }
+        }
+        const int oy = y0 + (tp >> 5), ox = x0 + (tp & 31);
+        if (oy < h && ox < w) {
+            bf16_t* dst = g2 + (((size_t)t * h + oy) * w + ox) * C + g * 2 * MT;       // 4*(MT/2) consecutive channels
+#pragma unroll
+            for (int m = 0; m + 3 < MT; m += 4) *(uint4*)(dst + m * 2) = make_uint4(o[m], o[m + 1], o[m + 2], o[m + 3]);
+            if (MT & 2) *(uint2*)(dst + (MT & ~3) * 2) = make_uint2(o[MT - 2], o[MT - 1]);
+        }
+    }
+#pragma unroll
+    for (int mp = 0; mp < MT / 2; ++mp)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            float sm = ps[mp][rr];
+            sm += __shfl_xor(sm, 1); sm += __shfl_xor(sm, 2); sm += __shfl_xor(sm, 4); sm += __shfl_xor(sm, 8);
+            if (p == 0) red[wv * C + g * 2 * MT + mp * 4 + rr] = sm;
+        }
+    __syncthreads();
+    if (pool && tid < C) {
+        const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
+        pool[((size_t)t * nblk + blk) * C + tid] = red[tid] + red[C + tid] + red[2 * C + tid] + red[3 * C + tid];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -411,6 +554,21 @@ int sn_dw5_gemm_gate(const void* g1, const float* ca_in, const uint32_t* w5, con
     const int nwg = ntiles < 512 ? ntiles : 512;            // 2 resident workgroups per CU x 256 CUs, persistent
     hipLaunchKernelGGL(dw5_gemm_gate_kernel<SN_DW5_TY>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g1, ca_in, w5,
                        (const uint4*)wfrag, (bf16_t*)g2, pool, T, h, w, g_sn_debug);
+    return sn_check_launch();
+}
+
+int sn_grp5_blocks(int h, int w) { return ((h + 3) / 4) * ((w + 31) / 32); }
+
+int sn_grp5_gemm_gate(const void* g1, const float* ca_in, const void* wgrp, const void* wfrag, void* g2, float* pool,
+                      int T, int h, int w, int C, void* stream) {
+    sn_clear_error();
+    if (!g1 || !wgrp || !wfrag || !g2 || C != 80) return SN_EINVAL;
+    dim3 grid((w + 31) / 32, (h + 3) / 4, T);
+    const size_t lds = (size_t)(8 * 36 + 4 * 32) * (C * 2 + 16) + 4 * C * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)grp5_gemm_gate_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    sn_clear_error();
+    hipLaunchKernelGGL(grp5_gemm_gate_kernel<80>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)g1, ca_in,
+                       (const uint4*)wgrp, (const uint4*)wfrag, (bf16_t*)g2, pool, h, w);
     return sn_check_launch();
 }
 

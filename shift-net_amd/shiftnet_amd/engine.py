@@ -93,8 +93,9 @@ class Plan:
             self.add_ca(f"{pre}ca1", f"{pre}body.{i}."); i += 1
         if V.grouped_rep:
             dense = prep.pack_grouped_rep(sd[f"{pre}body.{i}.conv_1.weight"], sd[f"{pre}body.{i}.conv_2.weight"])
-            self.add_conv(pre + "rep", "", [c], weight=dense)
+            self.add_conv(pre + "rep", "", [c], weight=dense)           # SN_GSTS_V=0 path only
             u["w_dw5"] = self._dev(prep.identity_dw5(c))
+            u["w_grp"] = self._dev(prep.pack_grouped_frag(sd[f"{pre}body.{i}.conv_1.weight"], sd[f"{pre}body.{i}.conv_2.weight"]))
         else:
             w5 = prep.pack_dw5(sd[f"{pre}body.{i}.conv_1.weight"], sd[f"{pre}body.{i}.conv_2.weight"])
             u["w_dw5"] = self._dev(w5)
@@ -321,8 +322,20 @@ class Engine:
         if V.denoise:
             ca1 = self.ca_mlp(pre + "ca1", pool1, h * w)
             ca1_ptr = ca1.data_ptr()
+        if V.grouped_rep and self.gsts_v >= 1:
+            # "+" RepConv (groups = C/8) as a block-diagonal MFMA GEMM fused with the 1x1 / SimpleGate2 that follow it
+            g2 = self._new(T, h, w, c)
+            pool2 = torch.empty((T, lib.sn_grp5_blocks(h, w), c), dtype=torch.float32, device=self.dev)
+            self._call("sn_grp5_gemm_gate", "sn_grp5_gemm_gate", g1.data_ptr(), ca1_ptr, u["w_grp"].data_ptr(), u["w_gate"].data_ptr(),
+                       g2.data_ptr(), pool2.data_ptr(), T, h, w, c, st)
+            ca2 = self.ca_mlp(pre + "ca2", pool2, h * w)
+            y = self._new(T, h, w, c)
+            b_out = u["b_out"].data_ptr() if u["b_out"] is not None else None
+            self._call("sn_scale_gemm_res", "sn_scale_gemm_res", C.byref(src), g2.data_ptr(), ca2.data_ptr(), u["w_out"].data_ptr(), b_out,
+                       y.data_ptr(), st)
+            return Act(y, c)
         if V.grouped_rep:
-            # "+" RepConv is a grouped (8->8) 5x5: round 1 runs it as a block-diagonal dense conv on the MFMA conv kernel;
+            # SN_GSTS_V=0: the grouped 5x5 as a block-diagonal dense conv on the MFMA conv kernel (10x redundant MFMA work);
             # the CALayer2 scale of the denoise variant must precede it, so it is applied by a scale pass first.
             g1a = Act(g1, c)
             if ca1_ptr is not None:

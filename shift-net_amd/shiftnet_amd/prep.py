@@ -194,3 +194,26 @@ def pack_gate_gemm_blocked(w2: torch.Tensor, c: int) -> torch.Tensor:
     wp = np.zeros((16 * (c // 8), 32 * ks), np.float32)
     wp[rows_gate(c), :c] = w
     return pack_frag(wp)
+
+
+def pack_grouped_frag(w5: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
+    """grouped RepConv ("+", 8 in / 8 out per group): fold 3x3 + identity into the 5x5 and lay it out for the
+    block-diagonal MFMA of sn_grp5_gemm_gate: M-tile mt = output channels [16mt, 16mt+16) (two groups), k-step s =
+    taps 2s, 2s+1, slot (g, j) = tap 2s + (g >> 1), input channel 16mt + (g & 1)*8 + j; a row only sees its own group."""
+    a = w5.detach().float().cpu().numpy().copy()          # [C, 8, 5, 5]
+    c = a.shape[0]
+    a[:, :, 1:4, 1:4] += w3.detach().float().cpu().numpy()
+    for o in range(c):
+        a[o, o % 8, 2, 2] += 1.0
+    mtg, ksg = c // 16, 13
+    wp = np.zeros((16 * mtg, 32 * ksg), np.float32)
+    for mt in range(mtg):
+        for m16 in range(16):
+            o = 16 * mt + m16
+            for s in range(ksg):
+                for g in range(4):
+                    tap = 2 * s + (g >> 1)
+                    if tap >= 25 or (g & 1) != (m16 >> 3):
+                        continue
+                    wp[16 * mt + m16, s * 32 + g * 8: s * 32 + g * 8 + 8] = a[o, :, tap // 5, tap % 5]
+    return pack_frag(wp)
