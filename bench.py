@@ -28,12 +28,14 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 VARIANT = "gshift_deblur2"
 H, W, ONE_LEN = 720, 1280, 16
-# elements per full-res pixel: stage0+stage1 per INPUT frame, stage2 per OUTPUT frame (Shift-Net-s)
-E_IN, E_OUT = 765.2 + 2180.0, 765.2
+# elements per full-res pixel: stage0+stage1 per INPUT frame, stage2 per OUTPUT frame
+ELEMS = {"gshift_deblur2": (765.2 + 2180.0, 765.2), "gshift_deblur1": (2268.0 + 2866.5, 2268.0),
+         "gshift_denoise2": (766.2 + 2194.0, 765.2), "gshift_denoise1": (2269.0 + 2962.5, 2268.0)}
 
 
-def algorithmic_bytes_window(h, w, t_in, t_out, s=2):
-    return h * w * s * (t_in * E_IN + t_out * E_OUT)
+def algorithmic_bytes_window(variant, h, w, t_in, t_out, s=2):
+    e_in, e_out = ELEMS[variant]
+    return h * w * s * (t_in * e_in + t_out * e_out)
 
 
 def kernel_alg_bytes(fn, meta):
@@ -126,6 +128,8 @@ def main():
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--one-len", type=int, default=ONE_LEN)
+    ap.add_argument("--variant", default=VARIANT, choices=list(ELEMS),
+                    help="default gshift_deblur2 = BASELINE config 2; the other variants are extra measurements")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline()))
@@ -134,21 +138,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from basicsr.models.archs.gshift_deblur2 import GShiftNet
+    import importlib
+    GShiftNet = importlib.import_module(f"basicsr.models.archs.{args.variant}").GShiftNet
     from shiftnet_amd import synth
     from shiftnet_amd.clip_parallel import assemble_window
     from shiftnet_amd.weights import synth_state_dict
 
     h, w, L = args.height, args.width, args.one_len
     net = GShiftNet(future_frames=2, past_frames=2)
-    net.load_state_dict(synth_state_dict(VARIANT), strict=True)
+    net.load_state_dict(synth_state_dict(args.variant), strict=True)
     net = net.to(torch.bfloat16).to(dev).eval()
+    denoise = "denoise" in args.variant
+    sigma_map = torch.full((1, L + 4, 1, h, w), 30.0 / 255.0, dtype=torch.bfloat16, device=dev) if denoise else None
 
     # this rank's slice of one long synthetic clip: L owned frames (+ the clip edges on the first / last rank)
     blur, _ = synth.blurred_clip(L + 4, h, w, seed=100 + rank)
@@ -157,7 +165,7 @@ def main():
 
     def step():
         win = assemble_window(own, first_edge, last_edge, rank, world)
-        return net(win.unsqueeze(0))
+        return net(win.unsqueeze(0), sigma_map) if denoise else net(win.unsqueeze(0))
 
     def barrier():
         if world > 1:
@@ -215,12 +223,12 @@ def main():
         ach = agg[dom]["bytes"] / (agg[dom]["ms"] * 1e-3) / 1e9
         kernels = {k: {"ms_total": round(v["ms"], 3), "launches": v["n"],
                        "gbps_algorithmic": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)} for k, v in agg.items()}
-        win_bytes = algorithmic_bytes_window(h, w, L + 4, L)
+        win_bytes = algorithmic_bytes_window(args.variant, h, w, L + 4, L)
         result = {
-            "metric": "restored frames/sec at 1280x720 T=16 bf16", "value": round(fps, 3), "unit": "frames/s",
+            "metric": f"restored frames/sec at {w}x{h} T={L} bf16", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"Shift-Net-s (gshift_deblur2) deblur, {w}x{h}, one_len={L} (T_in={L + 4}), "
+            "config": {"workload": f"{'Shift-Net-s' if args.variant.endswith('2') else 'Shift-Net+'} ({args.variant}), {w}x{h}, one_len={L} (T_in={L + 4}), "
                                    "one window per GPU, synthetic checkpoint", "parallelism": f"clip-parallel x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,

@@ -104,3 +104,48 @@ def test_conv_emulation_matches_oracle(case):
     assert (got - ref).abs().max().item() < 0.03 * max(1.0, ref.abs().max().item())
     if out.shape[-1] > w.shape[0]:
         assert np.abs(out[..., w.shape[0]:]).max() == 0.0       # pad channels stay zero
+
+
+def test_grouped_frag_and_chunk_block_tables():
+    """pack_grouped_frag (block-diagonal MFMA layout of the '+' RepConv) and the chunk-block permutation of the
+    depthwise path reproduce the oracle's RepConv / 1x1 when pushed through the kernels' documented slot conventions."""
+    F = torch.nn.functional
+    sd = synth_state_dict("gshift_deblur1")
+    pre = "stage1.decoder_level1.encoder_level1.0.body.3."
+    C, T, h, w = 80, 1, 6, 18
+    x = torch.from_numpy(synth.unit_noise((T, C, h, w), seed=77))
+    ref = F.conv2d(x, sd[pre + "conv_1.weight"], padding=2, groups=C // 8) + F.conv2d(x, sd[pre + "conv_2.weight"], padding=1, groups=C // 8) + x
+    wg = emu.frag_to_np(prep.pack_grouped_frag(sd[pre + "conv_1.weight"], sd[pre + "conv_2.weight"]))     # [5][13][64][8]
+    xn = np.zeros((h + 4, w + 4, C), np.float32); xn[2:-2, 2:-2] = nhwc(x)[0]
+    out = np.zeros((h, w, C), np.float32)
+    for oy in range(h):
+        for ox0 in range(0, w, 16):
+            for mt in range(C // 16):
+                bfrag = np.zeros((13, 64, 8), np.float32)
+                for lane in range(64):
+                    g, p = lane >> 4, lane & 15
+                    ox = min(ox0 + p, w - 1)
+                    for s in range(13):
+                        tap = 2 * s + (g >> 1)
+                        tap = tap if tap < 25 else 0
+                        dy, dx = divmod(tap, 5)
+                        c0 = 16 * mt + (g & 1) * 8
+                        bfrag[s, lane] = xn[oy + dy, ox + dx, c0:c0 + 8]
+                regs = emu.mfma_tiles(wg[mt:mt + 1], bfrag)[0]
+                for lane in range(64):
+                    g, p = lane >> 4, lane & 15
+                    if ox0 + p < w:
+                        out[oy, ox0 + p, 16 * mt + g * 4: 16 * mt + g * 4 + 4] = regs[lane]
+    got = torch.from_numpy(out).permute(2, 0, 1)[None]
+    assert (got - ref).abs().max().item() < 0.03 * max(1.0, ref.abs().max().item())
+    # chunk-block permutation is a bijection and matches the K12 store rule position q*16 + gs*4 + r <-> channel gs*16 + q*4 + r
+    perm = prep.chunk_block_perm(64)
+    assert sorted(perm.tolist()) == list(range(64))
+    assert perm[1 * 16 + 2 * 4 + 3] == 2 * 16 + 1 * 4 + 3
+    w2 = sd["stage1.decoder_level1.encoder_level1.0.body.4.weight"][:128, :64] if False else torch.randn(128, 64, 1, 1)
+    a = emu.frag_to_np(prep.pack_gate_gemm(w2, 64)); b = emu.frag_to_np(prep.pack_gate_gemm_blocked(w2, 64))
+    A = a.reshape(8, 2, 4, 16, 8).transpose(0, 3, 1, 2, 4).reshape(128, 64)        # rows x K (natural)
+    Bm = b.reshape(8, 2, 4, 16, 8).transpose(0, 3, 1, 2, 4).reshape(128, 64)       # rows x K (block positions)
+    assert np.array_equal(Bm, A[:, perm])
+    words = prep.dot2_words(torch.tensor([[1.0, -2.0, 0.5, 3.0]]))
+    assert [x & 0xFFFFFFFF for x in words[0].tolist()] == [0x3F80, 0xC0000000, 0x3F00, 0x40400000]
