@@ -45,7 +45,8 @@ def kernel_alg_bytes(fn, meta):
         px = T * h * w * 2
         return {"sn_gsts_shiftconv": px * c, "sn_ln_gemm": px * (3.5 * c if mode else 3 * c), "sn_dw_gate": px * 3 * c,
                 "sn_dw_gemm_gate": px * 2 * c, "sn_scale_gemm_res": px * 3 * c,
-                "sn_ln_gemm_gate": px * (2.5 * c if mode else 2 * c), "sn_dw5_gemm_gate": px * 2 * c}.get(fn, 0)
+                "sn_ln_gemm_gate": px * (2.5 * c if mode else 2 * c), "sn_dw5_gemm_gate": px * 2 * c,
+                "sn_grp5_gemm_gate": px * 2 * c}.get(fn, 0)
     if meta and meta[0] == "conv":
         _, T, ho, wo, cin, cs_out, k, stride, in_mode, out_mode = meta
         pin = T * ho * wo * stride * stride / (4 if in_mode == 1 else 1)

@@ -372,3 +372,24 @@ def test_cli_synthetic_runs(tmp_path):
     assert len(list((tmp_path / "d" / "synthetic").glob("*.png"))) == 8
     p, s = cli.main("gshift_denoise2", ["--synthetic", "96", "128", "9", "--sigma", "30", "--result_path", str(tmp_path / "n")])
     assert np.isfinite(p) and p > 15
+
+
+def test_odd_sizes_small_variant():
+    """Shift-Net-s only needs H, W % 4 == 0: 68x100 has odd level-2 maps (17x25) and ragged tiles everywhere."""
+    from basicsr.models.archs.gshift_deblur2 import GShiftNet
+    name = "gshift_deblur2"
+    sd = synth_state_dict(name)
+    net = GShiftNet(future_frames=2, past_frames=2)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(torch.bfloat16).cuda().eval()
+    blur, _ = synth.blurred_clip(6, 68, 100, seed=13)
+    x = O.frames_to_tensor(list(blur))
+    with torch.no_grad():
+        out = net(x.bfloat16().cuda()).float().cpu()
+        ref = O.forward(O.VARIANTS[name], sd, x, None, 2, 2)
+        ref_b = O.forward(O.VARIANTS[name], {k: v.bfloat16() for k, v in sd.items()}, x.bfloat16(), None, 2, 2).float()
+    p_hip, p_yard = _psnr(out, ref), _psnr(ref_b, ref)
+    REPORT.append({"name": "odd_68x100", "psnr_vs_ref": p_hip, "cpu_bf16_oracle_psnr": p_yard})
+    assert out.shape == ref.shape and p_hip >= p_yard - 1.0
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 5, 3, 66, 100, dtype=torch.bfloat16, device="cuda"))
