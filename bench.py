@@ -219,8 +219,28 @@ def main():
                 unit_ms += d
                 if fn == "sn_scale_gemm_res":            # one CAB finished: its fused-unit bytes = read x + write y
                     unit_bytes += 2 * meta[1] * meta[2] * meta[3] * meta[4] * 2
+        prof_copy = list(eng.prof)
         eng.prof = None
         dom = max(agg, key=lambda k: agg[k]["ms"])
+        # HBM traffic of the dominant kernel from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+        # passes, tools/bench_unit.py at the level-1 size), scaled by the pixels this bench's launches processed.
+        traffic, traffic_note = None, "no PMC entry for this kernel under profiles/"
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_unit_L1.json")))["kernels"]
+            sym = {"sn_dw5_gemm_gate": "dw5_gemm_gate_kernel", "sn_ln_gemm_gate<cab2>": "ln_gemm_gate_kernel<64, true>",
+                   "sn_ln_gemm_gate<cab1>": "ln_gemm_gate_kernel<64, false>", "sn_scale_gemm_res": "scale_gemm_res_kernel<64>",
+                   "sn_gsts_shiftconv": "shiftconv_kernel<32>"}.get(dom)
+            ent = next((v for k, v in pmc.items() if sym and sym in k), None)
+            if ent and args.variant == VARIANT:
+                l1_px = 20 * 360 * 640
+                px = [m[1] * m[2] * m[3] for f, _, m, _, _ in prof_copy if m and m[0] == "naf" and dom.startswith(f)
+                      and ("<cab" not in dom or (m[5] != 0) == dom.endswith("<cab2>"))]
+                scale = sum(px) / (len(px) * l1_px)
+                traffic = round((ent["FETCH_SIZE_KB_per_launch"] + ent["WRITE_SIZE_KB_per_launch"]) * 1024 * scale / 1e9, 4)
+                traffic_note = ("GB per launch (average over this kernel's launches): raw FETCH_SIZE+WRITE_SIZE of the committed PMC run "
+                                "at the level-1 size, scaled by pixels; FETCH_SIZE may under-report wide reads on gfx950 (MI355X_MICROARCH.md)")
+        except Exception as e:                                      # noqa: BLE001
+            traffic_note = f"PMC file unreadable: {e}"
         ach = agg[dom]["bytes"] / (agg[dom]["ms"] * 1e-3) / 1e9
         kernels = {k: {"ms_total": round(v["ms"], 3), "launches": v["n"],
                        "gbps_algorithmic": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)} for k, v in agg.items()}
@@ -232,7 +252,8 @@ def main():
             "config": {"workload": f"{'Shift-Net-s' if args.variant.endswith('2') else 'Shift-Net+'} ({args.variant}), {w}x{h}, one_len={L} (T_in={L + 4}), "
                                    "one window per GPU, synthetic checkpoint", "parallelism": f"clip-parallel x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                         "algorithmic_gb_per_launch": round(agg[dom]["bytes"] / agg[dom]["n"] / 1e9, 4),
                          "avg_launch_ms": round(agg[dom]["ms"] / agg[dom]["n"], 4), "launches": agg[dom]["n"]},
             "gsts_unit_roofline": {"achieved": round(unit_bytes / max(unit_ms, 1e-9) / 1e6, 1), "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": round(unit_bytes / max(unit_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
@@ -241,6 +262,26 @@ def main():
                                    "frac": round(win_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "kernels": kernels,
         }
+        if world == 1 and args.variant == VARIANT:
+            # parity sample next to the throughput: the same module on a small clip vs the CPU oracle (checker only)
+            from oracle import shiftnet_oracle as O
+            sd = synth_state_dict(VARIANT)
+            blur_s, sharp_s = synth.blurred_clip(7, 96, 128, seed=4)
+            xs = O.frames_to_tensor(list(blur_s))
+            with torch.no_grad():
+                o_hip = net(xs.to(torch.bfloat16).to(dev)).float().cpu()
+                o_ref = O.forward(O.VARIANTS[VARIANT], sd, xs, None, 2, 2)
+                o_b16 = O.forward(O.VARIANTS[VARIANT], {k: v.bfloat16() for k, v in sd.items()}, xs.bfloat16(), None, 2, 2).float()
+            gt = torch.from_numpy(sharp_s[2:5]).permute(0, 3, 1, 2).float() / 255
+
+            def psnr(a, b):
+                m = (a - b).pow(2).mean().item()
+                return 99.0 if m == 0 else 10 * __import__("math").log10(1.0 / m)
+            result["parity"] = {"sample": "Shift-Net-s, 7x96x128 synthetic clip, 3 restored frames, vs CPU fp32 oracle",
+                                "psnr_hip_vs_fp32_db": round(psnr(o_hip, o_ref), 2),
+                                "psnr_cpu_bf16_oracle_vs_fp32_db": round(psnr(o_b16, o_ref), 2),
+                                "delta_psnr_vs_gt_db": round(abs(psnr(o_hip.clamp(0, 1), gt) - psnr(o_ref.clamp(0, 1), gt)), 4),
+                                "max_abs": round((o_hip - o_ref).abs().max().item(), 5)}
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle on a bounded sample (child process, hard timeout)")
             result["cpu_baseline"] = cpu_baseline_subprocess()
