@@ -67,6 +67,9 @@ typedef struct sn_conv_desc {
     const void* sc;      /* mode 2: NCHW tensor of nchw_dtype, same shape as out */
     float* pool;         /* NULL or [T][gridDim.y*gridDim.x][16*mt] f32 per-workgroup channel sums of the output
                             (first half of AdaptiveAvgPool2d(1), CALayer :69); rows per frame = sn_conv_pool_blocks(d) */
+    const float* oscale; /* NULL or [T][oscale_stride] f32: out = conv * oscale[t][c] (+ res) -- the CALayer scale of a CAB
+                            applied in the epilogue of its second conv ("res = self.CA(res); res += x", :155-157) */
+    int oscale_stride;
 } sn_conv_desc;
 int sn_conv2d(const sn_conv_desc* d, void* stream);   /* d is a HOST pointer, read during the call */
 /* number of workgroups per frame sn_conv2d launches for this descriptor (= rows of `pool` per frame); host only */
@@ -76,6 +79,15 @@ int sn_conv_pool_blocks(const sn_conv_desc* d);
  * partial:[T][nblk][cpad] f32 sums, wa:[cr][c], wb:[c][cr] f32, ca:[T][cpad] f32 out (pad entries 0). */
 int sn_ca_mlp(const float* partial, int nblk, int cpad, int c, int cr, float inv_hw,
               const float* wa, const float* wb, float* ca, int T, void* stream);
+
+/* CALayer of a CAB computed BEFORE its second conv runs: the pooled mean of res = conv2(mid) is linear in mid,
+ *   sum_p res[co](p) = sum_ci sum_tap W2[co][ci][tap] * S_tap[ci],   S_tap = sum of mid over the pixels the tap can reach
+ *   (total - excluded border row / column + corner), so it follows from the channel sums of mid (partial, from conv1's
+ * epilogue) and the first/last rows and columns of mid.  Then the usual 1x1 -> ReLU -> 1x1 -> sigmoid (:61-70).
+ * mid:[T][h][w][cs] bf16, w2:[cin=c][9][cpad] f32 (bias-free 3x3, zero beyond c), ca:[T][cpad] out.  Lets sn_conv2d apply the scale and the
+ * residual in conv2's epilogue (no separate pass over res). */
+int sn_cab_ca(const float* partial, int nblk, int cpad, const void* mid, int cs, int c, int cr, int h, int w,
+              const float* w2, const float* wa, const float* wb, float* ca, int T, void* stream);
 
 /* CAB tail "res = self.CA(res); res += x" (gshift_deblur1.py:155-157): out = res * ca[t][c] + x. */
 int sn_scale_residual(const void* res, const void* x, const float* ca, int cpad, void* out,
@@ -124,7 +136,8 @@ int sn_dwgemm_blocks(int h, int w);
 /* Fused sn_ln_gemm + sn_dw_gate: g1 = SimpleGate(RepConv2(body[0](norm(cat(shortcut, hw))))) with the 2C-channel
  * intermediate kept in LDS (gshift_deblur1.py:190-198,225-233).  Same weight layouts as the two kernels it replaces.
  * wdw: [9][2C] u32, the bf16 weight of position j in half (j & 1) of its word, other half zero (v_dot2c operand).
- * g1_blocked != 0 (C = 64 only): g1 is written channel-blocked [T][4][h][w][16], the layout sn_dw5_gemm_gate reads.
+ * g1_blocked = 1 (C = 64 only): g1 is written channel-blocked [T][4][h][w][16], the layout sn_dw5_gemm_gate reads;
+ * g1_blocked = 2 (C = 64 only): channel-planar [T][h][C][sn_planar_pitch(w)], zeros in the pad columns (sn_dw5m_gemm_gate).
  * pool: NULL or [T][sn_lngate_blocks][C]. */
 int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, const uint32_t* wdw,
                     void* g1, float* pool, int g1_blocked, void* stream);
@@ -143,6 +156,21 @@ int sn_dw5_gemm_gate(const void* g1, const float* ca_in, const uint32_t* w5, con
 int sn_grp5_gemm_gate(const void* g1, const float* ca_in, const void* wgrp, const void* wfrag, void* g2, float* pool,
                       int T, int h, int w, int C, void* stream);
 int sn_grp5_blocks(int h, int w);
+
+/* ---- matrix-core stencils (csrc/sn_gsts3.hip) ------------------------------------------------------------------
+ * A depthwise k x k conv is a GEMM over the x axis: 16 outputs x 32 input columns of ONE channel per MFMA (banded
+ * Toeplitz A operand), N = 16 places of that channel.  Its input is channel-planar: [T][h][C][wr] bf16,
+ * wr = sn_planar_pitch(w) (w rounded up to 8), columns >= w are ZERO. */
+int sn_planar_pitch(int w);
+int sn_nhwc_to_planar(const void* x, void* xp, int T, int h, int w, int C, void* stream);   /* x:[T][h][w][C] -> xp planar */
+
+/* Same operator as sn_dw5_gemm_gate (RepConv -> body 1x1 -> SimpleGate2 + channel sums, gshift_deblur2.py RepConv /
+ * SimpleGate2 / CAB body), C = 64, with g1p channel-planar (natural channel order) and the 5x5 as Toeplitz MFMAs.
+ * ttab: bf16 [C][5][2][20] padded bands (prep.pack_toeplitz), wfrag: body 1x1 fragments, gate-paired rows, natural K.
+ * pool: [T][sn_dw5m_blocks(h,w)][C] partial sums of g2. */
+int sn_dw5m_blocks(int h, int w);
+int sn_dw5m_gemm_gate(const void* g1p, const float* ca_in, const void* ttab, const void* wfrag, void* g2, float* pool,
+                      int T, int h, int w, int C, void* stream);
 
 /* y = shortcut + beta * body[7](ca * g2) (gshift_deblur1.py:201,210,254): beta and the optional bias are folded
  * into wfrag/bias; the shortcut is the ROLLED tensor for CAB2 (mode 1/2) and x for CAB1 (mode 0). */

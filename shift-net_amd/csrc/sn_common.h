@@ -62,6 +62,21 @@ __device__ __forceinline__ float dot2bf(uint32_t a, uint32_t b, float acc) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+// Sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), result in every lane: four full-rate v_add_f32_dpp.
+// __shfl_xor lowers to ds_bpermute_b32 + s_waitcnt per step, ~100 cycles each and serialised by the compiler.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+// integer DPP move, zero where the source lane is outside the row; 0x100 + n = row_shl:n (lane i reads lane i + n)
+template <int CTRL> __device__ __forceinline__ int dpp_movi(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ float row_sum16(float x) {
+    x += dpp_mov<0xB1>(x);     // quad_perm [1,0,3,2]
+    x += dpp_mov<0x4E>(x);     // quad_perm [2,3,0,1]
+    x += dpp_mov<0x141>(x);    // row_half_mirror
+    x += dpp_mov<0x140>(x);    // row_mirror
+    return x;
+}
+
 // wave-uniform wave index (threadIdx-derived values are "divergent" to the compiler; make it provably uniform)
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 

@@ -23,7 +23,7 @@ struct ConvK {
     const uint4* wfrag; int ks;
     const float* bias; int act; float prelu;
     const bf16_t* res; bf16_t* out; int cs_out, out_mode, c_out, nchw_dtype;
-    const void* sc; float* pool;
+    const void* sc; float* pool; const float* oscale; int oscale_stride;
     int rh, rw, ps;
     unsigned m_nblk8, m_rw, m_csb, m_cv, m_k;   // ceil(2^24/d) multipliers: integer division by runtime constants without v_div
 };
@@ -133,6 +133,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK P) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) psum[m][r] = 0.f;
 
+    // per-channel epilogue constants once per lane (the stores below may alias them as far as the compiler knows)
+    float4 bia[MT], osc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int co0 = g * 4 * MT + m * 4;
+        bia[m] = P.bias ? *(const float4*)(P.bias + co0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        osc[m] = P.oscale ? *(const float4*)(P.oscale + (size_t)t * P.oscale_stride + co0) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
         const int nn = wv * NTW + n, row = nn / XB, xb = nn - row * XB;
@@ -143,14 +151,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK P) {
         for (int m = 0; m < MT; ++m) {
             const int co0 = g * 4 * MT + m * 4;
             float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
-            if (P.bias) {
-                const float4 bb = *(const float4*)(P.bias + co0);
-                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-            }
+            v[0] += bia[m].x; v[1] += bia[m].y; v[2] += bia[m].z; v[3] += bia[m].w;
             if (P.act == 1) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : v[r] * P.prelu;
             }
+            v[0] *= osc[m].x; v[1] *= osc[m].y; v[2] *= osc[m].z; v[3] *= osc[m].w;
             if (P.res && valid && co0 < P.cs_out) {
                 const uint2 rr = *(const uint2*)(P.res + opix * P.cs_out + co0);
                 v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK P) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float s = psum[m][r];
-                s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+                s = row_sum16(s);
                 if (p == 0) red[wv * 16 * MT + g * 4 * MT + m * 4 + r] = s;
             }
         __syncthreads();
@@ -282,6 +288,98 @@ __global__ __launch_bounds__(1024) void ca_mlp_kernel(const float* partial, int 
     }
 }
 
+// CALayer of a CAB from the sums of `mid` (see shiftnet_hip.h::sn_cab_ca).  One workgroup per frame.
+__global__ __launch_bounds__(1024) void cab_ca_kernel(const float* partial, int nblk, int cpad, const bf16_t* mid, int cs, int c, int cr,
+                                                     int h, int w, const float* w2, const float* wa, const float* wb, float* ca) {
+    __shared__ float acc[1024];
+    __shared__ float S[9][128];      // 0 total, 1 row0, 2 row h-1, 3 col0, 4 col w-1, 5..8 corners (0,0) (0,w-1) (h-1,0) (h-1,w-1)
+    __shared__ float mean[128];
+    __shared__ float hid[128];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const bf16_t* mt = mid + (size_t)t * h * w * cs;
+    {   // totals from conv1's per-workgroup partial sums
+        const int nsplit = 1024 / cpad, ch = tid % cpad, part = tid / cpad;
+        float s = 0.f;
+        if (part < nsplit) {
+            const float* pp = partial + (size_t)t * nblk * cpad + ch;
+            for (int b = part; b < nblk; b += nsplit) s += pp[(size_t)b * cpad];
+        }
+        acc[tid] = s;
+        __syncthreads();
+        if (tid < cpad) {
+            float m = 0.f;
+            for (int q = 0; q < nsplit; ++q) m += acc[q * cpad + tid];
+            if (tid < 128) S[0][tid] = m;
+        }
+        __syncthreads();
+    }
+    // border rows / columns: thread = (segment, channel); cs <= 128
+    for (int line = 0; line < 4; ++line) {
+        const int len = line < 2 ? w : h;
+        const int nseg = 1024 / cs, ch = tid % cs, seg = tid / cs;
+        float s = 0.f;
+        if (seg < nseg)
+            for (int i = seg; i < len; i += nseg) {
+                const int y = line == 0 ? 0 : (line == 1 ? h - 1 : i), x = line == 2 ? 0 : (line == 3 ? w - 1 : i);
+                s += bf_to_f(mt[((size_t)y * w + x) * cs + ch]);
+            }
+        acc[tid] = s;
+        __syncthreads();
+        if (tid < cs) {
+            float m = 0.f;
+            for (int q = 0; q < nseg; ++q) m += acc[q * cs + tid];
+            S[1 + line][tid] = m;
+        }
+        __syncthreads();
+    }
+    if (tid < cs) {
+        S[5][tid] = bf_to_f(mt[tid]);
+        S[6][tid] = bf_to_f(mt[((size_t)(w - 1)) * cs + tid]);
+        S[7][tid] = bf_to_f(mt[((size_t)(h - 1) * w) * cs + tid]);
+        S[8][tid] = bf_to_f(mt[((size_t)(h - 1) * w + w - 1) * cs + tid]);
+    }
+    __syncthreads();
+    {   // pooled res[co] = (1/hw) sum_ci sum_tap w2[ci][tap][co] * S_tap[ci]; thread = (slice of ci, co), then a tree over slices
+        const int nsplit = 1024 / cpad, co = tid % cpad, part = tid / cpad;
+        float r = 0.f;
+        if (part < nsplit)
+            for (int cin = part; cin < c; cin += nsplit) {
+                const float tot = S[0][cin], r0 = S[1][cin], r1 = S[2][cin], c0 = S[3][cin], c1 = S[4][cin];
+                const float k00 = S[5][cin], k01 = S[6][cin], k10 = S[7][cin], k11 = S[8][cin];
+                const float* wk = w2 + (size_t)cin * 9 * cpad + co;
+                // tap (ky,kx) reads mid(p + (ky-1, kx-1)): dy=+1 cannot reach row 0, dy=-1 cannot reach row h-1, same for columns
+                const float rowex[3] = {r1, 0.f, r0}, colex[3] = {c1, 0.f, c0};
+                const float cor[3][3] = {{k11, 0.f, k10}, {0.f, 0.f, 0.f}, {k01, 0.f, k00}};
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) r += wk[(ky * 3 + kx) * cpad] * (tot - rowex[ky] - colex[kx] + cor[ky][kx]);
+            }
+        acc[tid] = r;
+        __syncthreads();
+        if (tid < cpad) {
+            float m = 0.f;
+            for (int q = 0; q < nsplit; ++q) m += acc[q * cpad + tid];
+            if (tid < 128) mean[tid] = m / ((float)h * (float)w);
+        }
+    }
+    __syncthreads();
+    if (tid < cr) {
+        float hh = 0.f;
+        for (int j = 0; j < c; ++j) hh += wa[tid * c + j] * mean[j];
+        hid[tid] = hh > 0.f ? hh : 0.f;
+    }
+    __syncthreads();
+    if (tid < cpad) {
+        float o = 0.f;
+        if (tid < c) {
+            for (int j = 0; j < cr; ++j) o += wb[tid * cr + j] * hid[j];
+            o = sigmoidf_(o);
+        }
+        ca[(size_t)t * cpad + tid] = o;
+    }
+}
+
 __global__ void scale_residual_kernel(const uint4* res, const uint4* x, const float* ca, int cpad, uint4* out, int hw, int cs8) {
     const int t = blockIdx.y;
     const size_t n = (size_t)hw * cs8;
@@ -349,6 +447,7 @@ int sn_conv2d(const sn_conv_desc* d, void* stream) {
     if (d->in_mode == 1 && ((d->h_in | d->w_in) & 1)) return SN_EINVAL;
     if (d->out_mode == 2 && (!d->sc || d->c_out > 4 * d->mt)) return SN_EINVAL;
     if (d->ks * 32 < d->k * d->k * d->n_in * d->cs_in) return SN_EINVAL;
+    if (d->oscale && d->oscale_stride < 16 * d->mt) return SN_EINVAL;
     ConvK K;
     K.in0 = (const bf16_t*)d->in[0]; K.in1 = (const bf16_t*)d->in[1]; K.in2 = (const bf16_t*)d->in[2];
     K.n_in = d->n_in; K.cs = d->cs_in; K.cv = d->n_in * d->cs_in;
@@ -356,7 +455,7 @@ int sn_conv2d(const sn_conv_desc* d, void* stream) {
     K.hout = d->h_out; K.wout = d->w_out;
     K.wfrag = (const uint4*)d->wfrag; K.ks = d->ks; K.bias = d->bias; K.act = d->act; K.prelu = d->prelu;
     K.res = (const bf16_t*)d->res; K.out = (bf16_t*)d->out; K.cs_out = d->cs_out; K.out_mode = d->out_mode;
-    K.c_out = d->c_out; K.nchw_dtype = d->nchw_dtype; K.sc = d->sc; K.pool = d->pool;
+    K.c_out = d->c_out; K.nchw_dtype = d->nchw_dtype; K.sc = d->sc; K.pool = d->pool; K.oscale = d->oscale; K.oscale_stride = d->oscale_stride;
     const int blocks = K.cv >> 3;
     K.ps = (blocks & 1) ? K.cv * 2 : K.cv * 2 + 16;
     K.rh = K.rw = 0;
@@ -371,6 +470,16 @@ int sn_ca_mlp(const float* partial, int nblk, int cpad, int c, int cr, float inv
     sn_clear_error();
     if (!partial || !wa || !wb || !ca || cpad < 16 || cpad > 128 || c > cpad || cr > 128 || cr < 1 || nblk < 1) return SN_EINVAL;
     hipLaunchKernelGGL(ca_mlp_kernel, dim3(T), dim3(1024), 0, (hipStream_t)stream, partial, nblk, cpad, c, cr, inv_hw, wa, wb, ca);
+    return sn_check_launch();
+}
+
+int sn_cab_ca(const float* partial, int nblk, int cpad, const void* mid, int cs, int c, int cr, int h, int w,
+              const float* w2, const float* wa, const float* wb, float* ca, int T, void* stream) {
+    sn_clear_error();
+    if (!partial || !mid || !w2 || !wa || !wb || !ca || cpad < 16 || cpad > 128 || cs > 128 || (cs & 7) || c > cs || c > cpad ||
+        cr < 1 || cr > 128 || nblk < 1 || h < 2 || w < 2) return SN_EINVAL;
+    hipLaunchKernelGGL(cab_ca_kernel, dim3(T), dim3(1024), 0, (hipStream_t)stream, partial, nblk, cpad, (const bf16_t*)mid, cs, c, cr,
+                       h, w, w2, wa, wb, ca);
     return sn_check_launch();
 }
 

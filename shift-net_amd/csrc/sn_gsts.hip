@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const bf16_t* __restrict__
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float s = psum[j];
-                s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+                s = row_sum16(s);
                 s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
                 if (lane == 0) {
                     const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void dw_gemm_gate_kernel(const bf16_t* __restr
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float s = ps[r];
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+            s = row_sum16(s);
             if (p == 0) red[wv * C + g * 2 * MT + mp * 4 + r] = s;
         }
     }

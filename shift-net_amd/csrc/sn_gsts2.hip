@@ -44,6 +44,7 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
     constexpr int NTILES = (NPX + 15) / 16, NTW = (NTILES + NWV - 1) / NWV;        // 22 N-tiles, <= 3 per wave
     constexpr int PSA = 80;                                                        // LDS bytes per pixel of an a-chunk (64 + 16 pad)
     __shared__ __attribute__((aligned(16))) char lds_a2[2][NPX * PSA];           // double-buffered a-chunk: one barrier per chunk
+    __shared__ __attribute__((aligned(16))) uint16_t lds_tr[NWV][8][64];          // per-wave transpose scratch of the planar epilogue
     const int lane = threadIdx.x & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
     const int t = blockIdx.z, oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
     const int hw = U.h * U.w;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float sm = ps[j];
-                        sm += __shfl_xor(sm, 1); sm += __shfl_xor(sm, 2); sm += __shfl_xor(sm, 4); sm += __shfl_xor(sm, 8);
+                        sm = row_sum16(sm);
                         sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
                         if (lane == 0) {
                             constexpr int NPG = (TH * TW) / 64;
@@ -186,7 +187,25 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
                     }
                 }
             }
-            if (inside) {
+            if (blocked == 2) {
+                // channel-planar g1 [T][h][C][wr] for the matrix-core stencil (sn_gsts3.hip): the wave's 64 pixels x 8 channels
+                // go through a wave-private LDS transpose (LDS operations of one wave execute in order: no barrier), then every
+                // lane stores 8 consecutive columns of one channel (16 B).  Pixels outside the image are written as zeros
+                // (pad columns w .. wr-1 must read as zero downstream).
+                uint16_t (*tr)[64] = lds_tr[wv];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t v = inside ? ow[k] : 0u;
+                    tr[2 * k][lane] = (uint16_t)(v & 0xffffu);
+                    tr[2 * k + 1][lane] = (uint16_t)(v >> 16);
+                }
+                const int ci = lane >> 3, xc = lane & 7;                              // channel index 0..7 of this wave's set, 8-pixel piece
+                const uint4 v = *(const uint4*)(&tr[ci][xc * 8]);
+                const int ch = (gp * 2 + (ci >> 2)) * 2 * MT + q * 4 + (ci & 3);      // slot gs = 2gp + (ci>>2), r = ci & 3
+                const int py = oy0 + pg * (64 / TW) + (xc >> 2), pxx = ox0 + (xc & 3) * 8;
+                const int wr = (U.w + 7) & ~7;
+                if (py < U.h && pxx < wr) *(uint4*)(g1 + (((size_t)t * U.h + py) * C + ch) * wr + pxx) = v;
+            } else if (inside) {
                 const size_t pix = (size_t)gy * U.w + gx;
                 if (blocked) {   // chunk-blocked [T][NCHK][h][w][16]: block q, position gs*4 + r  <->  channel gs*2*MT + q*4 + r
                     *(uint4*)(g1 + (((size_t)t * NCHK + q) * hw + pix) * 16 + gp * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
@@ -363,7 +382,7 @@ __global__ __launch_bounds__(256) void dw5_gemm_gate_kernel(const bf16_t* __rest
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 float sm = ps[mp][rr];
-                sm += __shfl_xor(sm, 1); sm += __shfl_xor(sm, 2); sm += __shfl_xor(sm, 4); sm += __shfl_xor(sm, 8);
+                sm = row_sum16(sm);
                 if (p == 0) red[wv * C + g * 2 * MT + mp * 4 + rr] = sm;
             }
         __syncthreads();
@@ -506,7 +525,7 @@ __global__ __launch_bounds__(256) void grp5_gemm_gate_kernel(const bf16_t* __res
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             float sm = ps[mp][rr];
-            sm += __shfl_xor(sm, 1); sm += __shfl_xor(sm, 2); sm += __shfl_xor(sm, 4); sm += __shfl_xor(sm, 8);
+            sm = row_sum16(sm);
             if (p == 0) red[wv * C + g * 2 * MT + mp * 4 + rr] = sm;
         }
     __syncthreads();
@@ -521,7 +540,11 @@ __global__ __launch_bounds__(256) void grp5_gemm_gate_kernel(const bf16_t* __res
 extern "C" {
 
 static int g_sn_debug = 0;
-int sn_debug_set(int v) { g_sn_debug = v; return 0; }   /* profiling ablations only (tools/); 0 in production */
+int sn_debug_set(int v) { g_sn_debug = v; return 0; }
+int sn_debug_get(void) { return g_sn_debug; }
+static void* g_sn_debug_buf = nullptr;          /* optional device buffer for in-kernel cycle counters (tools/) */
+int sn_debug_buf_set(void* p) { g_sn_debug_buf = p; return 0; }
+void* sn_debug_buf_get(void) { return g_sn_debug_buf; }   /* profiling ablations only (tools/); 0 in production */
 
 #ifndef SN_DW5_TY
 #define SN_DW5_TY 4
@@ -534,7 +557,7 @@ int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, con
                     void* g1, float* pool, int g1_blocked, void* stream) {
     sn_clear_error();
     if (!s || !s->x || (s->C != 64 && s->C != 80) || s->mode < 0 || s->mode > 2 || !wfrag || !bias || !wdw || !g1 ||
-        (s->mode != 0 && !hw) || (g1_blocked && s->C != 64)) return SN_EINVAL;
+        (s->mode != 0 && !hw) || (g1_blocked && s->C != 64) || g1_blocked < 0 || g1_blocked > 2) return SN_EINVAL;
     UnitK2 u; u.x = (const bf16_t*)s->x; u.T = s->T; u.h = s->h; u.w = s->w; u.C = s->C; u.mode = s->mode; u.wrap = s->wrap;
     dim3 grid((s->w + 31) / 32, (s->h + SN_K12_TH - 1) / SN_K12_TH, s->T);
     hipStream_t st = (hipStream_t)stream;

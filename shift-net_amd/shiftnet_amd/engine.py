@@ -75,6 +75,11 @@ class Plan:
         self.add_conv(pre + "body.0", pre + "body.0.", [c])
         self.add_conv(pre + "body.2", pre + "body.2.", [c])
         self.add_ca(pre + "CA", pre + "CA.")
+        # fp32 [cin][9][cpad] copy of the second conv for the closed-form pooled mean of res (sn_cab_ca); bf16-rounded like the MFMA operand
+        cpad = 16 * int(self.convs[pre + "body.2"]["mt"])
+        w2 = torch.zeros((c, 9, cpad), dtype=torch.float32)
+        w2[:, :, :c] = self.sd[pre + "body.2.weight"].to(torch.bfloat16).float().reshape(c, c, 9).permute(1, 2, 0)
+        self.cas[pre + "CA"]["w2"] = self._dev(w2)
 
     def add_naf(self, pre: str, c: int, with_shift: bool) -> None:
         V, sd = self.V, self.sd
@@ -102,6 +107,7 @@ class Plan:
             if c == 64:      # v1 path: g1 / r travel in chunk-block position order (prep.chunk_block_perm)
                 perm = torch.from_numpy(prep.chunk_block_perm(c))
                 u["w_dw5_d2"] = self._dev(prep.dot2_words(w5[:, perm]))
+                u["w_toep5"] = self._dev(prep.pack_toeplitz(w5, 5))       # v2 path: 5x5 on the matrix cores
         i += 1
         u["w_gate"] = self._dev(prep.pack_gate_gemm(sd[f"{pre}body.{i}.weight"], c))
         if c == 64 and not V.grouped_rep:
@@ -182,7 +188,8 @@ class Engine:
         self.V = plan.V
         self.lib = L.load()
         self.dev = plan.device
-        self.gsts_v = int(os.environ.get("SN_GSTS_V", "1"))   # 0 = round-1 five-kernel chain, 1 = fused K12 + LDS-staged K3
+        self.cab_v = int(os.environ.get("SN_CAB_V", "1"))     # 1: CALayer scale + residual in the second conv's epilogue
+        self.gsts_v = int(os.environ.get("SN_GSTS_V", "2"))   # 0 = five-kernel chain, 1 = fused K12 + LDS-staged VALU K3, 2 = K12 (planar g1) + matrix-core K3m
         self.prof: Optional[list] = None      # bench.py attaches a list to collect (fn, label, meta, ev0, ev1)
         self._meta: Tuple = ()
 
@@ -206,7 +213,7 @@ class Engine:
         return torch.empty((T, h, w, cs), dtype=torch.bfloat16, device=self.dev)
 
     def conv(self, name: str, ins: Sequence[Act], *, stride: int = 1, pad: Optional[int] = None, prelu: Optional[float] = None,
-             res: Optional[Act] = None, out_mode: int = 0, pool: bool = False, in_mode: int = 0,
+             res: Optional[Act] = None, out_mode: int = 0, pool: bool = False, in_mode: int = 0, oscale: Optional[torch.Tensor] = None,
              nchw_out: Optional[torch.Tensor] = None, nchw_sc: Optional[torch.Tensor] = None):
         p = self.P.convs[name]
         k, cout = int(p["k"]), int(p["cout"])
@@ -241,6 +248,8 @@ class Engine:
         if res is not None:
             assert out_mode == 0 and res.dims == out_act.dims
             d.res = res.t.data_ptr()
+        if oscale is not None:
+            d.oscale, d.oscale_stride = oscale.data_ptr(), oscale.shape[1]
         if pool:
             nblk = self.lib.sn_conv_pool_blocks(C.byref(d))
             pool_buf = torch.empty((T, nblk, 16 * d.mt), dtype=torch.float32, device=self.dev)
@@ -269,7 +278,19 @@ class Engine:
 
     # ---- blocks (oracle/shiftnet_oracle.py has the same names) ----------------------------------------------
     def cab(self, pre: str, x: Act) -> Act:
-        """CAB: 3x3 -> PReLU -> 3x3 -> CALayer -> +x (gshift_deblur1.py:141-156)."""
+        """CAB: 3x3 -> PReLU -> 3x3 -> CALayer -> +x (gshift_deblur1.py:141-156).
+
+        cab_v 1: the CALayer scale is known BEFORE the second conv (its pooled input is linear in `mid`, sn_cab_ca), so
+        the second conv applies scale and residual in its epilogue: 5 tensor passes instead of 7, no pass over `res`."""
+        if self.cab_v >= 1:
+            mid, pool, _ = self.conv(pre + "body.0", [x], prelu=self.P.scalar(pre + "body.1.weight"), pool=True)
+            p = self.P.cas[pre + "CA"]
+            T, h, w, cs = mid.dims
+            _, nblk, cpad = pool.shape
+            ca = torch.empty((T, cpad), dtype=torch.float32, device=self.dev)
+            self._call("sn_cab_ca", f"sn_cab_ca[{pre}]", pool.data_ptr(), nblk, cpad, mid.t.data_ptr(), cs, p["c"], p["cr"], h, w,
+                       p["w2"].data_ptr(), p["wa"].data_ptr(), p["wb"].data_ptr(), ca.data_ptr(), T, self._stream())
+            return self.conv(pre + "body.2", [mid], res=x, oscale=ca)
         r = self.conv(pre + "body.0", [x], prelu=self.P.scalar(pre + "body.1.weight"))
         r, pool, npix = self.conv(pre + "body.2", [r], pool=True)
         return self.scale_residual(r, x, self.ca_mlp(pre + "CA", pool, npix))
@@ -303,10 +324,15 @@ class Engine:
             hwb = self._new(T, h, w, c // 2)
             self._call("sn_gsts_shiftconv", "sn_gsts_shiftconv", C.byref(src), P.offs.data_ptr(), u["w1"].data_ptr(), hwb.data_ptr(), st)
             hw_ptr = hwb.data_ptr()
-        g1 = self._new(T, h, w, c)
         ca1_ptr = None
         pool1 = None
-        blocked = 1 if (self.gsts_v >= 1 and c == 64 and not V.grouped_rep) else 0   # g1 layout [T][4][h][w][16] for K3'
+        mstencil = self.gsts_v >= 2 and c == 64 and not V.grouped_rep                 # K3m: Toeplitz-MFMA 5x5 on planar g1
+        blocked = 1 if (self.gsts_v >= 1 and c == 64 and not V.grouped_rep and not mstencil) else 0   # g1 [T][4][h][w][16] for K3'
+        if mstencil:
+            blocked = 2                                                                # g1 channel-planar [T][h][C][wr]
+            g1 = torch.empty((T, h, c, lib.sn_planar_pitch(w)), dtype=torch.bfloat16, device=self.dev)
+        else:
+            g1 = self._new(T, h, w, c)
         if self.gsts_v >= 1:      # fused LN + 1x1 + dw3x3 + gate: the 2C tensor stays in LDS
             if V.denoise:
                 pool1 = torch.empty((T, lib.sn_lngate_blocks(h, w), c), dtype=torch.float32, device=self.dev)
@@ -343,6 +369,18 @@ class Engine:
                 g1a = self.scale_residual(g1a, Act(zero, c), ca1)
                 ca1_ptr = None
             g1 = self.conv(pre + "rep", [g1a]).t
+        if mstencil:
+            g1p = g1
+            g2 = self._new(T, h, w, c)
+            pool2 = torch.empty((T, lib.sn_dw5m_blocks(h, w), c), dtype=torch.float32, device=self.dev)
+            self._call("sn_dw5m_gemm_gate", "sn_dw5m_gemm_gate", g1p.data_ptr(), ca1_ptr, u["w_toep5"].data_ptr(), u["w_gate"].data_ptr(),
+                       g2.data_ptr(), pool2.data_ptr(), T, h, w, c, st)
+            ca2 = self.ca_mlp(pre + "ca2", pool2, h * w)
+            y = self._new(T, h, w, c)
+            b_out = u["b_out"].data_ptr() if u["b_out"] is not None else None
+            self._call("sn_scale_gemm_res", "sn_scale_gemm_res", C.byref(src), g2.data_ptr(), ca2.data_ptr(), u["w_out"].data_ptr(), b_out,
+                       y.data_ptr(), st)
+            return Act(y, c)
         g2 = self._new(T, h, w, c)
         k3 = "sn_dw5_gemm_gate" if (self.gsts_v >= 1 and c == 64 and not V.grouped_rep) else "sn_dw_gemm_gate"
         nb = lib.sn_dw5_blocks(h, w) if k3 == "sn_dw5_gemm_gate" else lib.sn_dwgemm_blocks(h, w)

@@ -17,7 +17,7 @@ SN_F32, SN_F16, SN_BF16 = 0, 1, 2
 
 SYMBOLS = [
     "sn_abi_version", "sn_selftest_mfma", "sn_ingest", "sn_conv2d", "sn_conv_pool_blocks", "sn_ca_mlp",
-    "sn_scale_residual", "sn_gsts_gather", "sn_temporal_roll", "sn_gsts_shiftconv", "sn_ln_gemm", "sn_dw_gate",
+    "sn_scale_residual", "sn_cab_ca", "sn_planar_pitch", "sn_nhwc_to_planar", "sn_dw5m_blocks", "sn_dw5m_gemm_gate", "sn_gsts_gather", "sn_temporal_roll", "sn_gsts_shiftconv", "sn_ln_gemm", "sn_dw_gate",
     "sn_dwgate_blocks", "sn_dw_gemm_gate", "sn_dwgemm_blocks", "sn_scale_gemm_res",
     "sn_ln_gemm_gate", "sn_lngate_blocks", "sn_dw5_gemm_gate", "sn_dw5_blocks", "sn_debug_set", "sn_grp5_gemm_gate", "sn_grp5_blocks",
 ]
@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
         ("wfrag", C.c_void_p), ("mt", C.c_int), ("ks", C.c_int), ("bias", C.c_void_p),
         ("act", C.c_int), ("prelu", C.c_float), ("res", C.c_void_p), ("out", C.c_void_p),
         ("cs_out", C.c_int), ("out_mode", C.c_int), ("c_out", C.c_int), ("nchw_dtype", C.c_int),
-        ("sc", C.c_void_p), ("pool", C.c_void_p),
+        ("sc", C.c_void_p), ("pool", C.c_void_p), ("oscale", C.c_void_p), ("oscale_stride", C.c_int),
     ]
 
 
@@ -70,6 +70,11 @@ def load() -> C.CDLL:
     lib.sn_conv2d.argtypes = [C.POINTER(ConvDesc), vp]
     lib.sn_conv_pool_blocks.argtypes = [C.POINTER(ConvDesc)]
     lib.sn_ca_mlp.argtypes = [vp, ci, ci, ci, ci, cf, vp, vp, vp, ci, vp]
+    lib.sn_planar_pitch.argtypes = [ci]
+    lib.sn_nhwc_to_planar.argtypes = [vp, vp, ci, ci, ci, ci, vp]
+    lib.sn_dw5m_blocks.argtypes = [ci, ci]
+    lib.sn_dw5m_gemm_gate.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
+    lib.sn_cab_ca.argtypes = [vp, ci, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp]
     lib.sn_scale_residual.argtypes = [vp, vp, vp, ci, vp, ci, ci, ci, vp]
     lib.sn_gsts_gather.argtypes = [C.POINTER(UnitSrc), vp, vp, vp]
     lib.sn_temporal_roll.argtypes = [C.POINTER(UnitSrc), vp, vp]

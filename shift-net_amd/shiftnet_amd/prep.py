@@ -217,3 +217,19 @@ def pack_grouped_frag(w5: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
                         continue
                     wp[16 * mt + m16, s * 32 + g * 8: s * 32 + g * 8 + 8] = a[o, :, tap // 5, tap % 5]
     return pack_frag(wp)
+
+
+def pack_toeplitz(wk: torch.Tensor, k: int) -> torch.Tensor:
+    """depthwise k x k stencil [k*k][C] fp32 -> padded bands bf16 [C][k][2][20] for the Toeplitz MFMAs (csrc/sn_gsts3.hip).
+
+    The A operand of kernel row dy is A[m][kk] = w[dy][kk - m - (8 - k//2)] (16 outputs x 32 input columns, the window
+    starts 8 columns left of the tile).  With the band padded to P = [0]*7 + w[dy] + [0]*(13-k) (20 values), lane (m, g)
+    needs A[m][8g .. 8g+7] = P[s0 .. s0+7], s0 = k//2 - 1 - m + 8g (an all-zero window, s0 = 12, when out of range).
+    Copy 0 is P, copy 1 is P shifted left by one so that odd starts are dword-aligned too."""
+    w = wk.detach().float().cpu().numpy()
+    c = w.shape[1]
+    w = w.T.reshape(c, k, k)
+    tab = np.zeros((c, k, 2, 20), np.float32)
+    tab[:, :, 0, 7:7 + k] = w
+    tab[:, :, 1, 6:6 + k] = w
+    return torch.from_numpy(tab).to(torch.bfloat16)

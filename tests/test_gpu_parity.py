@@ -207,7 +207,7 @@ def test_cab(name, pre, c, engines):
     check(f"cab_{name}_{pre}", to_cpu(out.t, c), O.cab(sd, pre, x), 4e-2)
 
 
-@pytest.mark.parametrize("gsts_v", [1, 0])
+@pytest.mark.parametrize("gsts_v", [2, 1, 0])
 @pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_denoise2", "gshift_deblur1", "gshift_denoise1"])
 def test_gsts_pieces(name, gsts_v, engines):
     """shiftconv alone, then CAB2 (both directions), CAB1, a whole unit and a whole Encoder_shift_block.
@@ -243,7 +243,7 @@ def test_gsts_pieces(name, gsts_v, engines):
     x2 = bf(torch.from_numpy(synth.unit_noise((2, C, 13, 70), seed=82)))
     out = eng.gsts_unit(blk + "encoder_level1.", act(to_dev(x2), C), False)
     check(f"unit_fwd_ragged_v{gsts_v}_{name}", to_cpu(out.t, C), O.gsts_unit(sd, blk + "encoder_level1.", x2, False, V), 4e-2)
-    eng.gsts_v = 1
+    eng.gsts_v = 2
 
 
 def C_byref(s):
@@ -393,3 +393,19 @@ def test_odd_sizes_small_variant():
     assert out.shape == ref.shape and p_hip >= p_yard - 1.0
     with pytest.raises(ValueError):
         net(torch.zeros(1, 5, 3, 66, 100, dtype=torch.bfloat16, device="cuda"))
+
+
+@pytest.mark.gpu
+def test_nhwc_to_planar_bit_exact():
+    """layout op of the matrix-core stencil path: [T][h][w][C] -> [T][h][C][wr], zeros in the pad columns."""
+    from shiftnet_amd import lib as L
+    lib = L.load()
+    T, h, w, C = 2, 5, 77, 64
+    x = torch.randn(T, h, w, C, device=DEV).to(torch.bfloat16)
+    wr = lib.sn_planar_pitch(w)
+    assert wr == 80
+    xp = torch.full((T, h, C, wr), 7.0, dtype=torch.bfloat16, device=DEV)
+    L.check(lib.sn_nhwc_to_planar(x.data_ptr(), xp.data_ptr(), T, h, w, C, torch.cuda.current_stream().cuda_stream), "planar")
+    torch.cuda.synchronize()
+    assert torch.equal(xp[..., :w], x.permute(0, 1, 3, 2))
+    assert torch.count_nonzero(xp[..., w:]) == 0

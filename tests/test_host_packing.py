@@ -149,3 +149,32 @@ def test_grouped_frag_and_chunk_block_tables():
     assert np.array_equal(Bm, A[:, perm])
     words = prep.dot2_words(torch.tensor([[1.0, -2.0, 0.5, 3.0]]))
     assert [x & 0xFFFFFFFF for x in words[0].tolist()] == [0x3F80, 0xC0000000, 0x3F00, 0x40400000]
+
+
+@pytest.mark.parametrize("k", [3, 5])
+def test_toeplitz_band_table(k):
+    """prep.pack_toeplitz: rebuild the 16 x 32 A operand of every (channel, kernel row) from the padded bands the way the
+    lanes of sn_dw5m_gemm_gate address them (start s0 = k//2 - 1 - m + 8g, odd starts from the shifted copy, dword reads),
+    then check that A @ (32 input columns starting 8 left of the tile) is the depthwise row convolution."""
+    rng = np.random.default_rng(5)
+    c = 8
+    wk = torch.from_numpy(rng.standard_normal((k * k, c)).astype(np.float32)).bfloat16().float()
+    tab = prep.pack_toeplitz(wk, k).float().numpy()                   # [c][k][2][20]
+    assert tab.shape == (c, k, 2, 20)
+    rec = tab.reshape(c, k, 40)
+    A = np.zeros((c, k, 16, 32), np.float32)
+    for m in range(16):
+        for g in range(4):
+            s0 = k // 2 - 1 - m + 8 * g
+            if s0 < 0 or s0 > 11:
+                s0 = 12
+            tw = 10 + (s0 - 1) // 2 if s0 & 1 else s0 // 2            # dword offset in the 20-dword record
+            A[:, :, m, 8 * g:8 * g + 8] = rec[:, :, 2 * tw:2 * tw + 8]
+    x = rng.standard_normal((c, k + 3, 16 + 32)).astype(np.float32)    # rows, columns; tile starts at column 8
+    w = wk.numpy().T.reshape(c, k, k)
+    for ch in range(c):
+        for oy in range(3):
+            got = sum(A[ch, dy] @ x[ch, oy + dy, 0:32] for dy in range(k))
+            ref = np.array([sum(w[ch, dy, dx] * x[ch, oy + dy, 8 + m + dx - k // 2] for dy in range(k) for dx in range(k))
+                            for m in range(16)])
+            np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
