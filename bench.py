@@ -25,6 +25,7 @@ for p in (ROOT, os.path.join(ROOT, "shift-net_amd")):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+PMC_FILE = "r01_v3_pmc_hbm_traffic_unit_L1.json"      # rocprofv3 --pmc passes of tools/bench_unit.py, summarised by tools/pmc_summary.py
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 VARIANT = "gshift_deblur2"
 H, W, ONE_LEN = 720, 1280, 16
@@ -45,8 +46,8 @@ def kernel_alg_bytes(fn, meta):
         px = T * h * w * 2
         return {"sn_gsts_shiftconv": px * c, "sn_ln_gemm": px * (3.5 * c if mode else 3 * c), "sn_dw_gate": px * 3 * c,
                 "sn_dw_gemm_gate": px * 2 * c, "sn_scale_gemm_res": px * 3 * c,
-                "sn_ln_gemm_gate": px * (2.5 * c if mode else 2 * c), "sn_dw5_gemm_gate": px * 2 * c,
-                "sn_grp5_gemm_gate": px * 2 * c}.get(fn, 0)
+                "sn_ln_gemm_gate": px * (2.5 * c if mode else 2 * c), "sn_ln_gemm_gate_m": px * (2.5 * c if mode else 2 * c),
+                "sn_dw5_gemm_gate": px * 2 * c, "sn_dw5m_gemm_gate": px * 2 * c, "sn_grp5_gemm_gate": px * 2 * c}.get(fn, 0)
     if meta and meta[0] == "conv":
         _, T, ho, wo, cin, cs_out, k, stride, in_mode, out_mode = meta
         pin = T * ho * wo * stride * stride / (4 if in_mode == 1 else 1)
@@ -209,8 +210,8 @@ def main():
             if fn == "sn_conv2d":                       # one GPU kernel per (M-tiles, tile shape): key by template instance
                 mt = -(-max(meta[5], 1) // 16) if meta[9] != 1 else -(-meta[5] * 4 // 16)
                 key = f"sn_conv2d<mt{mt},{'8x32' if meta[7] == 1 else '4x16'}>"
-            elif fn == "sn_ln_gemm_gate":
-                key = f"sn_ln_gemm_gate<{'cab2' if meta[5] else 'cab1'}>"
+            elif fn in ("sn_ln_gemm_gate", "sn_ln_gemm_gate_m"):
+                key = f"{fn}<{'cab2' if meta[5] else 'cab1'}>"
             a = agg.setdefault(key, {"ms": 0.0, "n": 0, "bytes": 0.0})
             d = e0.elapsed_time(e1)
             a["ms"] += d; a["n"] += 1; a["bytes"] += kernel_alg_bytes(fn, meta)
@@ -226,8 +227,8 @@ def main():
         # passes, tools/bench_unit.py at the level-1 size), scaled by the pixels this bench's launches processed.
         traffic, traffic_note = None, "no PMC entry for this kernel under profiles/"
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_unit_L1.json")))["kernels"]
-            sym = {"sn_dw5_gemm_gate": "dw5_gemm_gate_kernel", "sn_ln_gemm_gate<cab2>": "ln_gemm_gate_kernel<64, true>",
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))["kernels"]
+            sym = {"sn_dw5_gemm_gate": "dw5_gemm_gate_kernel", "sn_dw5m_gemm_gate": "dw5m_gemm_gate_kernel", "sn_ln_gemm_gate<cab2>": "ln_gemm_gate_kernel<64, true>",
                    "sn_ln_gemm_gate<cab1>": "ln_gemm_gate_kernel<64, false>", "sn_scale_gemm_res": "scale_gemm_res_kernel<64>",
                    "sn_gsts_shiftconv": "shiftconv_kernel<32>"}.get(dom)
             ent = next((v for k, v in pmc.items() if sym and sym in k), None)

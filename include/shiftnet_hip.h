@@ -164,6 +164,14 @@ int sn_grp5_blocks(int h, int w);
 int sn_planar_pitch(int w);
 int sn_nhwc_to_planar(const void* x, void* xp, int T, int h, int w, int C, void* stream);   /* x:[T][h][w][C] -> xp planar */
 
+/* Same operator as sn_ln_gemm_gate (LayerNorm2d -> body[0] 1x1 -> RepConv2 -> SimpleGate, gshift_deblur1.py:19-28,190-198)
+ * for C = 64 with the depthwise 3x3 as Toeplitz MFMAs and g1 written channel-planar [T][h][C][sn_planar_pitch(w)].
+ * wfrag / bias: as for sn_ln_gemm_gate; ttab3: bf16 [C/16][32][3][2][20] band records (prep.pack_toeplitz_dw3_chunks).
+ * pool: NULL or [T][sn_lngatem_blocks(h,w)][C] per-workgroup sums of g1 (denoise CALayer2). */
+int sn_lngatem_blocks(int h, int w);
+int sn_ln_gemm_gate_m(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, const void* ttab3,
+                      void* g1p, float* pool, void* stream);
+
 /* Same operator as sn_dw5_gemm_gate (RepConv -> body 1x1 -> SimpleGate2 + channel sums, gshift_deblur2.py RepConv /
  * SimpleGate2 / CAB body), C = 64, with g1p channel-planar (natural channel order) and the 5x5 as Toeplitz MFMAs.
  * ttab: bf16 [C][5][2][20] padded bands (prep.pack_toeplitz), wfrag: body 1x1 fragments, gate-paired rows, natural K.

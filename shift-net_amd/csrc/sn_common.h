@@ -77,6 +77,19 @@ __device__ __forceinline__ float row_sum16(float x) {
     return x;
 }
 
+// Sum over the four DPP rows (lanes l, l^16, l^32, l^48), result in every lane: v_permlane16_swap / v_permlane32_swap
+// (gfx950) exchange odd/even rows and the wave halves inside the VALU, no LDS round trip (ds_bpermute) per step.
+__device__ __forceinline__ float sum_rows4(float x) {
+    // Inline asm: the instruction swaps IN PLACE between two distinct registers; through the builtin hipcc (ROCm 7.2) adds
+    // result 0 to itself when both inputs carry the same value.  s_nop 1: wait states between a VALU write and the swap.
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    const float s = a + b;
+    float c = s, d = s;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c), "+v"(d));
+    return c + d;
+}
+
 // wave-uniform wave index (threadIdx-derived values are "divergent" to the compiler; make it provably uniform)
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 

@@ -100,6 +100,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK P) {
             }
         }
     }
+    bf16x8_t a_cur[MT];                      // k-step 0 fragments: in flight across the barrier
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a_cur[m] = as_frag(P.wfrag[(m * P.ks) * 64 + lane]);
     __syncthreads();
 
     f32x4_t acc[MT][NTW];
@@ -113,17 +116,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK P) {
         const int nn = wv * NTW + n, row = nn / XB, xb = nn - row * XB;
         pixbase[n] = ((row * P.stride) * P.rw + (xb * 16 + p) * P.stride) * P.ps;
     }
+    // weight fragments one k-step AHEAD (they come from L1/L2; loaded at the point of use every k-step would pay the full
+    // load latency, and the trip count is a run-time value, so the compiler cannot pipeline this itself)
     for (int s = 0; s < P.ks; ++s) {
         const int toff = tapoff[s * 4 + g];
+        const int sn = s + 1 < P.ks ? s + 1 : s;
+        bf16x8_t a_nxt[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a_nxt[m] = as_frag(P.wfrag[(m * P.ks + sn) * 64 + lane]);
         bf16x8_t b[NTW];
 #pragma unroll
         for (int n = 0; n < NTW; ++n) b[n] = as_frag(*(const uint4*)(smem + pixbase[n] + toff));
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const bf16x8_t a = as_frag(P.wfrag[(m * P.ks + s) * 64 + lane]);
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n = 0; n < NTW; ++n) acc[m][n] = mfma16(a, b[n], acc[m][n]);
-        }
+            for (int n = 0; n < NTW; ++n) acc[m][n] = mfma16(a_cur[m], b[n], acc[m][n]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
     }
 
     // ---------------- epilogue: lane (g,p) owns channels [g*4*MT, (g+1)*4*MT) of pixel p of each N-tile ------------

@@ -37,7 +37,7 @@ __device__ __forceinline__ Slabs2 unit_slabs2(const UnitK2& U, int t) {
 template <int C, bool WITH_HW>
 __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const UnitK2 U, const bf16_t* __restrict__ hwb, const uint4* __restrict__ wfrag,
                                                          const float* __restrict__ bias, const uint32_t* __restrict__ wdw,
-                                                         bf16_t* g1, float* pool, const int blocked, const int dbg) {
+                                                         bf16_t* g1, float* pool, const int blocked, const int dbg, unsigned long long* prof) {
     constexpr int CH = C / 2, K = WITH_HW ? C + CH : C, KS = (K + 31) / 32, MT = C / 8, NCHK = MT / 2;
     constexpr int TH = SN_K12_TH, TW = 32, RH = TH + 2, RW = TW + 2, NPX = RH * RW;  // tile + 1-pixel ring (8x32: 340 px, 16x32: 612 px)
     constexpr int NWV = SN_K12_NWV;                                                // waves per workgroup
@@ -49,6 +49,24 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
     const int t = blockIdx.z, oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
     const int hw = U.h * U.w;
     const Slabs2 sl = unit_slabs2(U, t);
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+    auto tick = [&](int slot) {
+        if (prof) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tacc[slot] += now - tlast; tlast = now; }
+    };
+
+    // weight fragments and bias of one chunk, fetched one chunk AHEAD (they come from L2: ~1 us when loaded at the point of use)
+    bf16x8_t Wf[2][KS];
+    float4 Wb[2];
+    auto load_w = [&](int q) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            Wf[0][s] = as_frag(wfrag[((2 * q) * KS + s) * 64 + lane]);
+            Wf[1][s] = as_frag(wfrag[((2 * q + 1) * KS + s) * 64 + lane]);
+        }
+        Wb[0] = *(const float4*)(bias + g * 4 * MT + (2 * q) * 4);
+        Wb[1] = *(const float4*)(bias + g * 4 * MT + (2 * q + 1) * 4);
+    };
+    load_w(0);
 
     // ---- LayerNorm of every pixel of the ring-extended tile; results stay in registers as MFMA B fragments ----
     bf16x8_t B[NTW][KS];
@@ -81,7 +99,7 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
 #pragma unroll
             for (int j = 0; j < 8; ++j) { xv[s][j] = has ? xv[s][j] : 0.f; sum += xv[s][j]; }
         }
-        sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+        sum = sum_rows4(sum);
         const float mean = sum * (1.0f / K);
         float sq = 0.f;
 #pragma unroll
@@ -93,7 +111,7 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
                 xv[s][j] = d; sq += d * d;
             }
         }
-        sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
+        sq = sum_rows4(sq);
         const float rstd = 1.0f / sqrtf(sq * (1.0f / K) + 1e-6f);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -107,16 +125,13 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
     auto gemm_chunk = [&](int q) {
         char* lds_a = lds_a2[q & 1];
         f32x4_t acc0[NTW], acc1[NTW];
-        const float4 b0 = *(const float4*)(bias + g * 4 * MT + (2 * q) * 4);
-        const float4 b1 = *(const float4*)(bias + g * 4 * MT + (2 * q + 1) * 4);
+        const float4 b0 = Wb[0], b1 = Wb[1];
 #pragma unroll
         for (int n = 0; n < NTW; ++n) { acc0[n] = (f32x4_t){b0.x, b0.y, b0.z, b0.w}; acc1[n] = (f32x4_t){b1.x, b1.y, b1.z, b1.w}; }
 #pragma unroll
         for (int s = (dbg & 16) ? KS : 0; s < KS; ++s) {
-            const bf16x8_t a0 = as_frag(wfrag[((2 * q) * KS + s) * 64 + lane]);
-            const bf16x8_t a1 = as_frag(wfrag[((2 * q + 1) * KS + s) * 64 + lane]);
 #pragma unroll
-            for (int n = 0; n < NTW; ++n) { acc0[n] = mfma16(a0, B[n][s], acc0[n]); acc1[n] = mfma16(a1, B[n][s], acc1[n]); }
+            for (int n = 0; n < NTW; ++n) { acc0[n] = mfma16(Wf[0][s], B[n][s], acc0[n]); acc1[n] = mfma16(Wf[1][s], B[n][s], acc1[n]); }
         }
 #pragma unroll
         for (int n = 0; n < NTW; ++n) {
@@ -131,12 +146,18 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
             }
         }
     };
+    tick(0);
     gemm_chunk(0);
+    load_w(1);
+    tick(1);
 #pragma unroll 1
     for (int q = 0; q < NCHK; ++q) {
         // one barrier per chunk: chunk q is complete in buffer q&1, and every wave is done reading buffer (q+1)&1 (chunk q-1)
         __syncthreads();
+        tick(2);
         if (q + 1 < NCHK) gemm_chunk(q + 1);            // MFMA work of the next chunk overlaps this chunk's stencil
+        load_w(q + 2 < NCHK ? q + 2 : NCHK - 1);        // unconditional (clamped): consumed one iteration later
+        tick(1);
         const char* lds_a = lds_a2[q & 1];
         // ---- depthwise 3x3 (+identity) and gate.  Wave = (64-pixel group pg, lane-group-slot pair gp): it handles slots
         //      2gp and 2gp+1 one after the other (the slot's weights are wave-uniform scalar loads), lanes are pixels, so a
@@ -187,6 +208,7 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
                     }
                 }
             }
+            tick(3);
             if (blocked == 2) {
                 // channel-planar g1 [T][h][C][wr] for the matrix-core stencil (sn_gsts3.hip): the wave's 64 pixels x 8 channels
                 // go through a wave-private LDS transpose (LDS operations of one wave execute in order: no barrier), then every
@@ -215,7 +237,12 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
                     *(uint2*)(dst + (gp * 2 + 1) * 2 * MT) = make_uint2(ow[2], ow[3]);
                 }
             }
+            tick(4);
         }
+    }
+    if (prof && lane == 0 && blockIdx.z == 0 && blockIdx.y * gridDim.x + blockIdx.x < 256) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) prof[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wv) * 8 + k] = tacc[k];
     }
 }
 
@@ -562,7 +589,7 @@ int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, con
     dim3 grid((s->w + 31) / 32, (s->h + SN_K12_TH - 1) / SN_K12_TH, s->T);
     hipStream_t st = (hipStream_t)stream;
 #define SN_LAUNCH_K12(CC, HW_) hipLaunchKernelGGL((ln_gemm_gate_kernel<CC, HW_>), grid, dim3(SN_K12_NWV * 64), 0, st, u, (const bf16_t*)hw, \
-        (const uint4*)wfrag, bias, wdw, (bf16_t*)g1, pool, g1_blocked, g_sn_debug)
+        (const uint4*)wfrag, bias, wdw, (bf16_t*)g1, pool, g1_blocked, g_sn_debug, (unsigned long long*)((g_sn_debug & 256) ? g_sn_debug_buf : nullptr))
     if (s->C == 64) { if (s->mode) SN_LAUNCH_K12(64, true); else SN_LAUNCH_K12(64, false); }
     else { if (s->mode) SN_LAUNCH_K12(80, true); else SN_LAUNCH_K12(80, false); }
 #undef SN_LAUNCH_K12

@@ -231,6 +231,218 @@ __global__ __launch_bounds__(1024) void dw5m_gemm_gate_kernel(const bf16_t* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// K12m: g1 = SimpleGate(RepConv2(body[0](norm(u)))) for C = 64 with the depthwise 3x3 on the matrix cores, g1 written
+// channel-planar.  Same chunk pipeline as sn_ln_gemm_gate (LayerNorm'd operands resident in registers, the 2C-channel
+// tensor `a` only ever exists 32 channels at a time in LDS, next chunk's GEMM overlaps this chunk's stencil), but
+//   * the GEMM runs with the PIXELS on M (A = normalised activations, B = weights: the same prepacked fragments, operands
+//     swapped), so a lane's 4 accumulators are 4 consecutive columns of one channel: `a` goes to LDS channel-planar with
+//     ds_write_b64 -- exactly the layout the Toeplitz MFMAs read their B operands from;
+//   * region = 10 rows x 48 columns (3 M-tiles per row, the tile's 32 columns start at column 8): windows stay 16-byte
+//     aligned; 30 M-tiles per workgroup instead of 22 (the price of planar rows);
+//   * stencil: per gate pair two channels x 3 kernel rows = 6 MFMAs for the whole 8 x 32 tile (N = 2 x-tiles x 8 rows),
+//     band fragments from a per-chunk table in LDS (7.5 KB, double buffered, prefetched through registers);
+//   * SimpleGate is lane-local (both halves of a pair come out in the same lane layout); the product is 4 consecutive
+//     columns of one g1 channel = one 8-byte store into the planar tensor, no transpose epilogue.
+struct UnitK3 {
+    const bf16_t* x;
+    int T, h, w, C, mode, wrap;
+};
+struct Slabs3 { int f0, o0, f1, o1; };
+__device__ __forceinline__ Slabs3 unit_slabs3(const UnitK3& U, int t) {      // same table as sn_gsts2.hip::unit_slabs2
+    const int Ch = U.C >> 1;
+    Slabs3 s; s.f0 = t; s.o0 = 0; s.f1 = t; s.o1 = Ch;
+    if (U.mode == 1) { if (t > 0 || U.wrap) { s.f0 = (t - 1 + U.T) % U.T; s.o0 = Ch; s.f1 = t; s.o1 = 0; } }
+    else if (U.mode == 2) { if (t < U.T - 1 || U.wrap) { s.f0 = t; s.o0 = Ch; s.f1 = (t + 1) % U.T; s.o1 = 0; } }
+    return s;
+}
+
+constexpr int K12M_TH = 8, K12M_TW = 32, K12M_RH = 10, K12M_RC = 48;
+constexpr int K12M_PLANE = K12M_RH * K12M_RC + 8;           // elements per channel plane; +8: the 16 planes a ds_write_b64 group touches spread over the banks (2-way instead of 8-way)
+constexpr int K12M_ABUF = 32 * K12M_PLANE * 2;              // 30720 B: 32 channel planes of one chunk
+constexpr int K12M_TDW = 32 * 3 * 20;                       // 1920 dwords: band records of one chunk
+constexpr int K12M_LDS = 2 * K12M_ABUF + 2 * K12M_TDW * 4;  // 77824 B -> two workgroups per CU
+
+template <bool WITH_HW>
+__global__ __launch_bounds__(512) void ln_gemm_gate_m_kernel(const UnitK3 U, const bf16_t* __restrict__ hwb, const uint4* __restrict__ wfrag,
+                                                           const float* __restrict__ bias, const uint32_t* __restrict__ ttab3,
+                                                           bf16_t* g1p, float* pool, const int wr, unsigned long long* prof) {
+    constexpr int C = 64, CH = 32, K = WITH_HW ? C + CH : C, KS = K / 32, MT = 8, NCHK = 4;
+    constexpr int TH = K12M_TH, TW = K12M_TW, RH = K12M_RH, RC = K12M_RC, PLANE = K12M_PLANE;
+    constexpr int NWV = 8, NMT = RH * 3, NTW = (NMT + NWV - 1) / NWV;            // 30 M-tiles of 16 region pixels, <= 4 per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_a = smem;                                                  // [2][32 planes][RH][RC] bf16
+    uint32_t* lds_t = (uint32_t*)(smem + 2 * K12M_ABUF);                 // [2][32 planes][3][20]
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
+    const int t = blockIdx.z, oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+    const int hw = U.h * U.w;
+    const Slabs3 sl = unit_slabs3(U, t);
+
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+    auto tick = [&](int slot) {
+        if (prof) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tacc[slot] += now - tlast; tlast = now; }
+    };
+    // weight fragments, bias and band table of one chunk, fetched one chunk AHEAD through registers
+    bf16x8_t Wf[2][KS];
+    float Wb[2];
+    uint32_t Tq[4];
+    auto load_w = [&](int q) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            Wf[0][s] = as_frag(wfrag[((2 * q) * KS + s) * 64 + lane]);
+            Wf[1][s] = as_frag(wfrag[((2 * q + 1) * KS + s) * 64 + lane]);
+        }
+        // as the B operand lane (g, n = p) carries weight row n of the 16-row block: its bias sits at (n>>2)*4*MT + mt*4 + (n&3)
+        Wb[0] = bias[(p >> 2) * 4 * MT + (2 * q) * 4 + (p & 3)];
+        Wb[1] = bias[(p >> 2) * 4 * MT + (2 * q + 1) * 4 + (p & 3)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = tid + k * 512;
+            Tq[k] = ttab3[q * K12M_TDW + (idx < K12M_TDW ? idx : 0)];
+        }
+    };
+    load_w(0);
+
+    // ---- LayerNorm of the 30 M-tiles (16 consecutive region columns of one region row); operands stay in registers ----
+    bf16x8_t Xf[NTW][KS];
+    int ry_[NTW], cb_[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        const int mt = wv + NWV * n;                          // wave-uniform
+        const int ry = mt / 3, cb = mt - ry * 3;
+        ry_[n] = ry; cb_[n] = cb;
+        const int gy = oy0 - 1 + ry, gx = ox0 - 8 + 16 * cb + p;
+        const bool in = mt < NMT && gy >= 0 && gy < U.h && gx >= 0 && gx < U.w;
+        const int ii = in ? gy * U.w + gx : 0;
+        float xv[KS][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int kk0 = s * 32 + g * 8;                   // K is a multiple of 32 here: every slab is real
+            const bf16_t* s0 = U.x + ((size_t)sl.f0 * hw + ii) * C + sl.o0 + (kk0 < CH ? kk0 : 0);
+            const bf16_t* s1 = U.x + ((size_t)sl.f1 * hw + ii) * C + sl.o1 + (kk0 >= CH && kk0 < C ? kk0 - CH : 0);
+            const bf16_t* src = kk0 < CH ? s0 : s1;
+            if (WITH_HW) {
+                const bf16_t* s2 = hwb + ((size_t)t * hw + ii) * CH + (kk0 >= C ? kk0 - C : 0);
+                src = kk0 >= C ? s2 : src;
+            }
+            unpack8(*(const uint4*)src, xv[s]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += xv[s][j];
+        }
+        sum = sum_rows4(sum);
+        const float mean = sum * (1.0f / K);
+        float sq = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = xv[s][j] - mean; xv[s][j] = d; sq += d * d; }
+        sq = sum_rows4(sq);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / K) + 1e-6f);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[s][j] *= rstd;
+            Xf[n][s] = as_frag(pack8(xv[s]));
+        }
+    }
+
+    // GEMM chunk q -> LDS buffer q & 1 (planes 0..15: first-half channels, 16..31: their gate partners), zero outside the image;
+    // the chunk's band table (prefetched into Tq) goes to the table buffer of the same parity.
+    auto gemm_chunk = [&](int q) {
+        char* ab = lds_a + (q & 1) * K12M_ABUF;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            if (wv + NWV * n >= NMT) continue;                // wave-uniform
+            f32x4_t acc0 = {Wb[0], Wb[0], Wb[0], Wb[0]}, acc1 = {Wb[1], Wb[1], Wb[1], Wb[1]};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { acc0 = mfma16(Xf[n][s], Wf[0][s], acc0); acc1 = mfma16(Xf[n][s], Wf[1][s], acc1); }
+            // lane (g, p): pixels = region columns 16 cb + 4g + r of row ry, channel row p
+            const int gy = oy0 - 1 + ry_[n], gx0 = ox0 - 8 + 16 * cb_[n] + 4 * g;
+            const bool yok = gy >= 0 && gy < U.h;
+            float v0[4], v1[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool in = yok && gx0 + r >= 0 && gx0 + r < U.w;
+                v0[r] = in ? acc0[r] : 0.f; v1[r] = in ? acc1[r] : 0.f;
+            }
+            const int off = (ry_[n] * RC + 16 * cb_[n] + 4 * g) * 2;
+            *(uint2*)(ab + (p * PLANE) * 2 + off) = make_uint2(pack_bf2(v0[0], v0[1]), pack_bf2(v0[2], v0[3]));
+            *(uint2*)(ab + ((16 + p) * PLANE) * 2 + off) = make_uint2(pack_bf2(v1[0], v1[1]), pack_bf2(v1[2], v1[3]));
+        }
+        uint32_t* tb = lds_t + (q & 1) * K12M_TDW;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = tid + k * 512;
+            if (idx < K12M_TDW) tb[idx] = Tq[k];
+        }
+    };
+    tick(0);
+    gemm_chunk(0);
+    load_w(1);
+    tick(1);
+
+    // Toeplitz constants (3-tap band, prep.pack_toeplitz(k=3)): window start s0 = -m + 8g; see dw5m_gemm_gate_kernel
+    const int s0 = -p + 8 * g;
+    const int twx = (s0 < 0 || s0 > 5) ? 0 : ((s0 & 1) ? 10 + (s0 + 5) / 2 : (s0 + 6) / 2);
+    const int tww = (s0 < 6 || s0 > 11) ? 0 : ((s0 & 1) ? 10 + (s0 - 1) / 2 : s0 / 2);
+    const int xt = p & 1, row = p >> 1;                                   // B column n = p: x-tile (16 columns) and tile row
+    const int boff = (row * RC + 16 * xt + 8 * g) * 2;
+    const int oy = oy0 + row, ox = ox0 + 16 * xt + 4 * g;                 // this lane's 4 output columns ox .. ox + 3
+    const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
+
+#pragma unroll 1
+    for (int q = 0; q < NCHK; ++q) {
+        __syncthreads();          // chunk q (and its table) complete in buffer q&1; everybody is done with buffer (q+1)&1
+        tick(2);
+        if (q + 1 < NCHK) gemm_chunk(q + 1);
+        load_w(q + 2 < NCHK ? q + 2 : NCHK - 1);
+        tick(1);
+        const char* ab = lds_a + (q & 1) * K12M_ABUF + boff;
+        const uint32_t* tb = lds_t + (q & 1) * K12M_TDW;
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+            const int nn = 2 * wv + pi;                                   // gate pair of the chunk (wave-uniform)
+            f32x4_t D[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int plane = half * 16 + nn;
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int x3 = (int)tb[(plane * 3 + dy) * 20 + twx], w0 = (int)tb[(plane * 3 + dy) * 20 + tww];
+                    const int d1 = __builtin_amdgcn_update_dpp(dpp_movi<0x104>(x3), w0, 0x112, 0xf, 0xf, false);
+                    const int d2 = __builtin_amdgcn_update_dpp(dpp_movi<0x114>(w0), x3, 0x102, 0xf, 0xf, false);
+                    const bf16x8_t A = as_frag(make_uint4((uint32_t)w0, (uint32_t)d1, (uint32_t)d2, (uint32_t)x3));
+                    const bf16x8_t B = as_frag(*(const uint4*)(ab + (plane * PLANE + dy * RC) * 2));
+                    acc = mfma16(A, B, acc);
+                }
+                D[half] = acc;
+            }
+            const int ch = (nn >> 2) * 2 * MT + q * 4 + (nn & 3);       // natural g1 channel of the pair
+            float v[4];
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool in = oy < U.h && ox + r < U.w;
+                v[r] = in ? D[0][r] * D[1][r] : 0.f;                     // zeros in the pad columns w .. wr-1
+                ps += v[r];
+            }
+            if (oy < U.h && ox < wr)
+                *(uint2*)(g1p + (((size_t)t * U.h + oy) * C + ch) * wr + ox) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            if (pool) {                       // denoise CALayer2 on g1: the whole wave holds ONE channel -> wave sum
+                ps = sum_rows4(row_sum16(ps));
+                if (lane == 0) pool[((size_t)t * nblk + blk) * C + ch] = ps;
+            }
+        }
+        tick(3);
+    }
+    if (prof && lane == 0 && blockIdx.z == 0 && blk < 256) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) prof[((size_t)blk * 8 + wv) * 8 + k] = tacc[k];
+    }
+}
+
 // NHWC [T][h][w][C] -> planar [T][h][C][wr] (pad columns zero).  64-pixel row segments through LDS.
 __global__ __launch_bounds__(256) void nhwc_to_planar_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ xp, int h, int w, int C, int wr) {
     __shared__ bf16_t tile[64][136];              // [px][channel], C <= 128; row pitch 272 B
@@ -270,6 +482,31 @@ int sn_nhwc_to_planar(const void* x, void* xp, int T, int h, int w, int C, void*
     return sn_check_launch();
 }
 
+int sn_lngatem_blocks(int h, int w) { return ((h + K12M_TH - 1) / K12M_TH) * ((w + K12M_TW - 1) / K12M_TW); }
+
+int sn_ln_gemm_gate_m(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, const void* ttab3,
+                      void* g1p, float* pool, void* stream) {
+    sn_clear_error();
+    if (!s || !s->x || s->C != 64 || s->mode < 0 || s->mode > 2 || !wfrag || !bias || !ttab3 || !g1p || (s->mode != 0 && !hw))
+        return SN_EINVAL;
+    UnitK3 u; u.x = (const bf16_t*)s->x; u.T = s->T; u.h = s->h; u.w = s->w; u.C = s->C; u.mode = s->mode; u.wrap = s->wrap;
+    dim3 grid((s->w + K12M_TW - 1) / K12M_TW, (s->h + K12M_TH - 1) / K12M_TH, s->T);
+    hipStream_t st = (hipStream_t)stream;
+    const int wr = sn_planar_pitch(s->w);
+    if (s->mode) {
+        (void)hipFuncSetAttribute((const void*)ln_gemm_gate_m_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, K12M_LDS);
+        sn_clear_error();
+        hipLaunchKernelGGL(ln_gemm_gate_m_kernel<true>, grid, dim3(512), K12M_LDS, st, u, (const bf16_t*)hw, (const uint4*)wfrag, bias,
+                           (const uint32_t*)ttab3, (bf16_t*)g1p, pool, wr, (unsigned long long*)((sn_debug_get() & 256) ? sn_debug_buf_get() : nullptr));
+    } else {
+        (void)hipFuncSetAttribute((const void*)ln_gemm_gate_m_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, K12M_LDS);
+        sn_clear_error();
+        hipLaunchKernelGGL(ln_gemm_gate_m_kernel<false>, grid, dim3(512), K12M_LDS, st, u, (const bf16_t*)hw, (const uint4*)wfrag, bias,
+                           (const uint32_t*)ttab3, (bf16_t*)g1p, pool, wr, (unsigned long long*)((sn_debug_get() & 256) ? sn_debug_buf_get() : nullptr));
+    }
+    return sn_check_launch();
+}
+
 int sn_dw5m_blocks(int h, int w) { return ((h + K3M_TH - 1) / K3M_TH) * ((w + K3M_TW - 1) / K3M_TW); }
 
 int sn_dw5m_gemm_gate(const void* g1p, const float* ca_in, const void* ttab, const void* wfrag, void* g2, float* pool,
@@ -281,7 +518,7 @@ int sn_dw5m_gemm_gate(const void* g1p, const float* ca_in, const void* ttab, con
     (void)hipFuncSetAttribute((const void*)dw5m_gemm_gate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, K3M_LDS);
     sn_clear_error();
     hipLaunchKernelGGL(dw5m_gemm_gate_kernel, dim3(nwg), dim3(1024), K3M_LDS, (hipStream_t)stream, (const bf16_t*)g1p, ca_in,
-                       (const uint32_t*)ttab, (const uint4*)wfrag, (bf16_t*)g2, pool, T, h, w, sn_planar_pitch(w), sn_debug_get(), (unsigned long long*)sn_debug_buf_get());
+                       (const uint32_t*)ttab, (const uint4*)wfrag, (bf16_t*)g2, pool, T, h, w, sn_planar_pitch(w), sn_debug_get(), (unsigned long long*)((sn_debug_get() & 512) ? sn_debug_buf_get() : nullptr));
     return sn_check_launch();
 }
 

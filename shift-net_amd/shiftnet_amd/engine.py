@@ -93,6 +93,8 @@ class Plan:
         w3 = prep.pack_dw3_gate(sd[f"{pre}body.{i}.conv_2.weight"], c); i += 1
         u["w_dw3"] = self._dev(w3)
         u["w_dw3_d2"] = self._dev(prep.dot2_words(w3))
+        if c == 64:
+            u["w_toep3"] = self._dev(prep.pack_toeplitz_dw3_chunks(sd[f"{pre}body.{i - 1}.conv_2.weight"], c))   # K12m band records
         i += 1
         if V.denoise:
             self.add_ca(f"{pre}ca1", f"{pre}body.{i}."); i += 1
@@ -333,7 +335,12 @@ class Engine:
             g1 = torch.empty((T, h, c, lib.sn_planar_pitch(w)), dtype=torch.bfloat16, device=self.dev)
         else:
             g1 = self._new(T, h, w, c)
-        if self.gsts_v >= 1:      # fused LN + 1x1 + dw3x3 + gate: the 2C tensor stays in LDS
+        if mstencil and self.gsts_v >= 3:     # K12m: the depthwise 3x3 on the matrix cores as well, planar g1 without a transpose epilogue
+            if V.denoise:
+                pool1 = torch.empty((T, lib.sn_lngatem_blocks(h, w), c), dtype=torch.float32, device=self.dev)
+            self._call("sn_ln_gemm_gate_m", "sn_ln_gemm_gate_m", C.byref(src), hw_ptr, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(),
+                       u["w_toep3"].data_ptr(), g1.data_ptr(), pool1.data_ptr() if pool1 is not None else None, st)
+        elif self.gsts_v >= 1:      # fused LN + 1x1 + dw3x3 + gate: the 2C tensor stays in LDS
             if V.denoise:
                 pool1 = torch.empty((T, lib.sn_lngate_blocks(h, w), c), dtype=torch.float32, device=self.dev)
             self._call("sn_ln_gemm_gate", "sn_ln_gemm_gate", C.byref(src), hw_ptr, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(),

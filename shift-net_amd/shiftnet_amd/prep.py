@@ -233,3 +233,21 @@ def pack_toeplitz(wk: torch.Tensor, k: int) -> torch.Tensor:
     tab[:, :, 0, 7:7 + k] = w
     tab[:, :, 1, 6:6 + k] = w
     return torch.from_numpy(tab).to(torch.bfloat16)
+
+
+def pack_toeplitz_dw3_chunks(w: torch.Tensor, c: int) -> torch.Tensor:
+    """RepConv2 depthwise 3x3 [2C,1,3,3] (+identity) -> band records for sn_ln_gemm_gate_m: bf16 [C/16][32][3][2][20].
+
+    Chunk q, plane = half*16 + n holds channel half*C + (n>>2)*(C/4) + 4q + (n&3): the channel that row n of the gate-paired
+    16-row weight blocks 2q (half 0) / 2q+1 (half 1) produces (rows_gate)."""
+    wn = w.detach().float().cpu().reshape(2 * c, 9).clone()
+    wn[:, 4] += 1.0
+    rec = pack_toeplitz(wn.T.contiguous(), 3)                      # [2C][3][2][20]
+    nchk = c // 16
+    out = torch.zeros((nchk, 32, 3, 2, 20), dtype=torch.bfloat16)
+    for q in range(nchk):
+        for half in range(2):
+            for n in range(16):
+                ch = half * c + (n >> 2) * (c // 4) + 4 * q + (n & 3)
+                out[q, half * 16 + n] = rec[ch]
+    return out

@@ -207,7 +207,7 @@ def test_cab(name, pre, c, engines):
     check(f"cab_{name}_{pre}", to_cpu(out.t, c), O.cab(sd, pre, x), 4e-2)
 
 
-@pytest.mark.parametrize("gsts_v", [2, 1, 0])
+@pytest.mark.parametrize("gsts_v", [3, 2, 1, 0])
 @pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_denoise2", "gshift_deblur1", "gshift_denoise1"])
 def test_gsts_pieces(name, gsts_v, engines):
     """shiftconv alone, then CAB2 (both directions), CAB1, a whole unit and a whole Encoder_shift_block.

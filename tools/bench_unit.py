@@ -17,7 +17,7 @@ def main():
     ap.add_argument("--h", type=int, default=360)
     ap.add_argument("--w", type=int, default=640)
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--gsts-v", type=int, default=1)
+    ap.add_argument("--gsts-v", type=int, default=2)
     ap.add_argument("--dbg", type=int, default=0)
     args = ap.parse_args()
     from shiftnet_amd.engine import Act, Engine, Plan

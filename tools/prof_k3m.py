@@ -47,9 +47,11 @@ def main():
     print(f"plain: {e0.elapsed_time(e1) / 5 * 1e3:.1f} us")
     lib.sn_debug_buf_set.argtypes = [L.C.c_void_p]
     lib.sn_debug_buf_set(buf.data_ptr())
+    lib.sn_debug_set(args.dbg | 512)
     run(); torch.cuda.synchronize()
     e0.record(); run(); e1.record(); torch.cuda.synchronize()
     lib.sn_debug_buf_set(None)
+    lib.sn_debug_set(0)
     print(f"instrumented: {e0.elapsed_time(e1) * 1e3:.1f} us")
     a = buf.view(256, 8, 8).double()
     names = ["stage(write+issue)", "barrier_after_gemm", "-", "toeplitz", "-", "barrier_step", "gemm", "tile_top"]
