@@ -85,9 +85,11 @@ int sn_ca_mlp(const float* partial, int nblk, int cpad, int c, int cr, float inv
  *   (total - excluded border row / column + corner), so it follows from the channel sums of mid (partial, from conv1's
  * epilogue) and the first/last rows and columns of mid.  Then the usual 1x1 -> ReLU -> 1x1 -> sigmoid (:61-70).
  * mid:[T][h][w][cs] bf16, w2:[cin=c][9][cpad] f32 (bias-free 3x3, zero beyond c), ca:[T][cpad] out.  Lets sn_conv2d apply the scale and the
- * residual in conv2's epilogue (no separate pass over res). */
+ * residual in conv2's epilogue (no separate pass over res).
+ * scratch: sn_cab_ca_scratch_floats(T) floats of workspace (partial sums of the split reduction). */
+int sn_cab_ca_scratch_floats(int T);
 int sn_cab_ca(const float* partial, int nblk, int cpad, const void* mid, int cs, int c, int cr, int h, int w,
-              const float* w2, const float* wa, const float* wb, float* ca, int T, void* stream);
+              const float* w2, const float* wa, const float* wb, float* scratch, float* ca, int T, void* stream);
 
 /* CAB tail "res = self.CA(res); res += x" (gshift_deblur1.py:155-157): out = res * ca[t][c] + x. */
 int sn_scale_residual(const void* res, const void* x, const float* ca, int cpad, void* out,

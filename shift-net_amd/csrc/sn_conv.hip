@@ -297,8 +297,53 @@ __global__ __launch_bounds__(1024) void ca_mlp_kernel(const float* partial, int 
     }
 }
 
-// CALayer of a CAB from the sums of `mid` (see shiftnet_hip.h::sn_cab_ca).  One workgroup per frame.
-__global__ __launch_bounds__(1024) void cab_ca_kernel(const float* partial, int nblk, int cpad, const bf16_t* mid, int cs, int c, int cr,
+// CALayer of a CAB from the sums of `mid` (see shiftnet_hip.h::sn_cab_ca).  Two launches: the sums (total from conv1's
+// per-workgroup partials, first/last row, first/last column) are split over SN_CABCA_NS workgroups per frame -- one
+// workgroup per frame was a 40 us latency chain, 101 times per window -- then one workgroup per frame finishes.
+#define SN_CABCA_NS 16
+__global__ __launch_bounds__(256) void cab_ca_part_kernel(const float* partial, int nblk, int cpad, const bf16_t* mid, int cs,
+                                                        int h, int w, float* scratch) {
+    __shared__ float acc[256];
+    const int t = blockIdx.y, sidx = blockIdx.x, tid = threadIdx.x;
+    const bf16_t* mt = mid + (size_t)t * h * w * cs;
+    float* out = scratch + ((size_t)t * SN_CABCA_NS + sidx) * 5 * 128;
+    {
+        const int nsplit = 256 / cpad, ch = tid % cpad, part = tid / cpad;
+        float sm = 0.f;
+        if (part < nsplit) {
+            const float* pp = partial + (size_t)t * nblk * cpad + ch;
+            for (int bb = sidx * nsplit + part; bb < nblk; bb += SN_CABCA_NS * nsplit) sm += pp[(size_t)bb * cpad];
+        }
+        acc[tid] = sm;
+        __syncthreads();
+        if (tid < cpad) {
+            float m = 0.f;
+            for (int q = 0; q < nsplit; ++q) m += acc[q * cpad + tid];
+            if (tid < 128) out[tid] = m;
+        }
+        __syncthreads();
+    }
+    for (int line = 0; line < 4; ++line) {
+        const int len = line < 2 ? w : h;
+        const int nseg = 256 / cs, ch = tid % cs, seg = tid / cs;
+        float sm = 0.f;
+        if (seg < nseg)
+            for (int i = sidx * nseg + seg; i < len; i += SN_CABCA_NS * nseg) {
+                const int y = line == 0 ? 0 : (line == 1 ? h - 1 : i), x = line == 2 ? 0 : (line == 3 ? w - 1 : i);
+                sm += bf_to_f(mt[((size_t)y * w + x) * cs + ch]);
+            }
+        acc[tid] = sm;
+        __syncthreads();
+        if (tid < cs) {
+            float m = 0.f;
+            for (int q = 0; q < nseg; ++q) m += acc[q * cs + tid];
+            out[(1 + line) * 128 + tid] = m;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024) void cab_ca_kernel(const float* scratch, int cpad, const bf16_t* mid, int cs, int c, int cr,
                                                      int h, int w, const float* w2, const float* wa, const float* wb, float* ca) {
     __shared__ float acc[1024];
     __shared__ float S[9][128];      // 0 total, 1 row0, 2 row h-1, 3 col0, 4 col w-1, 5..8 corners (0,0) (0,w-1) (h-1,0) (h-1,w-1)
@@ -306,40 +351,14 @@ __global__ __launch_bounds__(1024) void cab_ca_kernel(const float* partial, int 
     __shared__ float hid[128];
     const int t = blockIdx.x, tid = threadIdx.x;
     const bf16_t* mt = mid + (size_t)t * h * w * cs;
-    {   // totals from conv1's per-workgroup partial sums
-        const int nsplit = 1024 / cpad, ch = tid % cpad, part = tid / cpad;
-        float s = 0.f;
-        if (part < nsplit) {
-            const float* pp = partial + (size_t)t * nblk * cpad + ch;
-            for (int b = part; b < nblk; b += nsplit) s += pp[(size_t)b * cpad];
+    if (tid < 5 * 128) {
+        const int k = tid >> 7, ch = tid & 127;
+        float m = 0.f;
+        if (ch < (k == 0 ? cpad : cs)) {
+            const float* sp = scratch + (size_t)t * SN_CABCA_NS * 5 * 128 + tid;
+            for (int q = 0; q < SN_CABCA_NS; ++q) m += sp[q * 5 * 128];
         }
-        acc[tid] = s;
-        __syncthreads();
-        if (tid < cpad) {
-            float m = 0.f;
-            for (int q = 0; q < nsplit; ++q) m += acc[q * cpad + tid];
-            if (tid < 128) S[0][tid] = m;
-        }
-        __syncthreads();
-    }
-    // border rows / columns: thread = (segment, channel); cs <= 128
-    for (int line = 0; line < 4; ++line) {
-        const int len = line < 2 ? w : h;
-        const int nseg = 1024 / cs, ch = tid % cs, seg = tid / cs;
-        float s = 0.f;
-        if (seg < nseg)
-            for (int i = seg; i < len; i += nseg) {
-                const int y = line == 0 ? 0 : (line == 1 ? h - 1 : i), x = line == 2 ? 0 : (line == 3 ? w - 1 : i);
-                s += bf_to_f(mt[((size_t)y * w + x) * cs + ch]);
-            }
-        acc[tid] = s;
-        __syncthreads();
-        if (tid < cs) {
-            float m = 0.f;
-            for (int q = 0; q < nseg; ++q) m += acc[q * cs + tid];
-            S[1 + line][tid] = m;
-        }
-        __syncthreads();
+        S[k][ch] = m;
     }
     if (tid < cs) {
         S[5][tid] = bf_to_f(mt[tid]);
@@ -482,13 +501,17 @@ int sn_ca_mlp(const float* partial, int nblk, int cpad, int c, int cr, float inv
     return sn_check_launch();
 }
 
+int sn_cab_ca_scratch_floats(int T) { return T * SN_CABCA_NS * 5 * 128; }
+
 int sn_cab_ca(const float* partial, int nblk, int cpad, const void* mid, int cs, int c, int cr, int h, int w,
-              const float* w2, const float* wa, const float* wb, float* ca, int T, void* stream) {
+              const float* w2, const float* wa, const float* wb, float* scratch, float* ca, int T, void* stream) {
     sn_clear_error();
-    if (!partial || !mid || !w2 || !wa || !wb || !ca || cpad < 16 || cpad > 128 || cs > 128 || (cs & 7) || c > cs || c > cpad ||
-        cr < 1 || cr > 128 || nblk < 1 || h < 2 || w < 2) return SN_EINVAL;
-    hipLaunchKernelGGL(cab_ca_kernel, dim3(T), dim3(1024), 0, (hipStream_t)stream, partial, nblk, cpad, (const bf16_t*)mid, cs, c, cr,
-                       h, w, w2, wa, wb, ca);
+    if (!partial || !mid || !w2 || !wa || !wb || !ca || !scratch || cpad < 16 || cpad > 128 || cs > 128 || (cs & 7) || c > cs ||
+        c > cpad || cr < 1 || cr > 128 || nblk < 1 || h < 2 || w < 2) return SN_EINVAL;
+    hipLaunchKernelGGL(cab_ca_part_kernel, dim3(SN_CABCA_NS, T), dim3(256), 0, (hipStream_t)stream, partial, nblk, cpad,
+                       (const bf16_t*)mid, cs, h, w, scratch);
+    hipLaunchKernelGGL(cab_ca_kernel, dim3(T), dim3(1024), 0, (hipStream_t)stream, (const float*)scratch, cpad, (const bf16_t*)mid, cs,
+                       c, cr, h, w, w2, wa, wb, ca);
     return sn_check_launch();
 }
 

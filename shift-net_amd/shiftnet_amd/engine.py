@@ -290,8 +290,9 @@ class Engine:
             T, h, w, cs = mid.dims
             _, nblk, cpad = pool.shape
             ca = torch.empty((T, cpad), dtype=torch.float32, device=self.dev)
+            scratch = torch.empty((self.lib.sn_cab_ca_scratch_floats(T),), dtype=torch.float32, device=self.dev)
             self._call("sn_cab_ca", f"sn_cab_ca[{pre}]", pool.data_ptr(), nblk, cpad, mid.t.data_ptr(), cs, p["c"], p["cr"], h, w,
-                       p["w2"].data_ptr(), p["wa"].data_ptr(), p["wb"].data_ptr(), ca.data_ptr(), T, self._stream())
+                       p["w2"].data_ptr(), p["wa"].data_ptr(), p["wb"].data_ptr(), scratch.data_ptr(), ca.data_ptr(), T, self._stream())
             return self.conv(pre + "body.2", [mid], res=x, oscale=ca)
         r = self.conv(pre + "body.0", [x], prelu=self.P.scalar(pre + "body.1.weight"))
         r, pool, npix = self.conv(pre + "body.2", [r], pool=True)

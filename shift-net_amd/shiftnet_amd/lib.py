@@ -17,7 +17,7 @@ SN_F32, SN_F16, SN_BF16 = 0, 1, 2
 
 SYMBOLS = [
     "sn_abi_version", "sn_selftest_mfma", "sn_ingest", "sn_conv2d", "sn_conv_pool_blocks", "sn_ca_mlp",
-    "sn_scale_residual", "sn_cab_ca", "sn_planar_pitch", "sn_nhwc_to_planar", "sn_dw5m_blocks", "sn_dw5m_gemm_gate", "sn_lngatem_blocks", "sn_ln_gemm_gate_m", "sn_gsts_gather", "sn_temporal_roll", "sn_gsts_shiftconv", "sn_ln_gemm", "sn_dw_gate",
+    "sn_scale_residual", "sn_cab_ca", "sn_cab_ca_scratch_floats", "sn_planar_pitch", "sn_nhwc_to_planar", "sn_dw5m_blocks", "sn_dw5m_gemm_gate", "sn_lngatem_blocks", "sn_ln_gemm_gate_m", "sn_gsts_gather", "sn_temporal_roll", "sn_gsts_shiftconv", "sn_ln_gemm", "sn_dw_gate",
     "sn_dwgate_blocks", "sn_dw_gemm_gate", "sn_dwgemm_blocks", "sn_scale_gemm_res",
     "sn_ln_gemm_gate", "sn_lngate_blocks", "sn_dw5_gemm_gate", "sn_dw5_blocks", "sn_debug_set", "sn_grp5_gemm_gate", "sn_grp5_blocks",
 ]
@@ -76,7 +76,8 @@ def load() -> C.CDLL:
     lib.sn_lngatem_blocks.argtypes = [ci, ci]
     lib.sn_ln_gemm_gate_m.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp, vp, vp]
     lib.sn_dw5m_gemm_gate.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
-    lib.sn_cab_ca.argtypes = [vp, ci, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp]
+    lib.sn_cab_ca.argtypes = [vp, ci, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp]
+    lib.sn_cab_ca_scratch_floats.argtypes = [ci]
     lib.sn_scale_residual.argtypes = [vp, vp, vp, ci, vp, ci, ci, ci, vp]
     lib.sn_gsts_gather.argtypes = [C.POINTER(UnitSrc), vp, vp, vp]
     lib.sn_temporal_roll.argtypes = [C.POINTER(UnitSrc), vp, vp]
