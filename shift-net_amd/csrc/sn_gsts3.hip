@@ -21,34 +21,44 @@
 //     of the M-tiles, A fragments resident in registers), SimpleGate2, NHWC stores, channel sums.
 //   sn_nhwc_to_planar: layout change for A/B tests and for producers that still write NHWC.
 #include "sn_common.h"
+#include <stdlib.h>
 #include "../../include/shiftnet_hip.h"
 
 namespace {
 
-constexpr int K3M_C = 64, K3M_TW = 64, K3M_TH = 8, K3M_RH = K3M_TH + 4, K3M_RX = 80, K3M_CHK = 16, K3M_NWV = 16;
+constexpr int K3M_C = 64, K3M_TW = 64, K3M_RX = 80, K3M_CHK = 16;
 constexpr int K3M_TAB_BYTES = K3M_C * 5 * 80;                          // 25600: [c][dy]{band padded to 20, same shifted by one}
-constexpr int K3M_GIMG_BYTES = K3M_CHK * K3M_RH * K3M_RX * 2;          // 30720 per buffer, two buffers
-constexpr int K3M_RPITCH = K3M_TW * K3M_TH + 4;                        // dwords per channel-pair plane of r (516: lane groups g land 16 banks apart)
-constexpr int K3M_R_BYTES = (K3M_C / 2) * K3M_RPITCH * 4;              // 66048
-constexpr int K3M_RED_BYTES = K3M_NWV * 32 * 4;                        // 2048
-constexpr int K3M_LDS = K3M_TAB_BYTES + 2 * K3M_GIMG_BYTES + K3M_R_BYTES + K3M_RED_BYTES;   // 155136
+// Two shapes of the same kernel.  TH = 8 (default): 1024 threads, one workgroup per CU, double-buffered staging image (one
+// barrier per step).  TH = 4 (SN_K3M_TH=4, kept for A/B): 512 threads, two independent workgroups per CU (80 KB of LDS
+// each, single staging buffer, two barriers per step).
+template <int TH> struct K3mShape {
+    static constexpr int RH = TH + 4, NWV = 2 * TH, NTHR = 64 * NWV, NBUF = TH == 8 ? 2 : 1;
+    static constexpr int GIMG_BYTES = K3M_CHK * RH * K3M_RX * 2;       // 30720 / 20480 per buffer
+    static constexpr int RPITCH = K3M_TW * TH + 4;                     // dwords per channel-pair plane of r (lane groups g land 16 banks apart)
+    static constexpr int R_BYTES = (K3M_C / 2) * RPITCH * 4;           // 66048 / 33280
+    static constexpr int RED_BYTES = NWV * 32 * 4;
+    static constexpr int LDS = K3M_TAB_BYTES + NBUF * GIMG_BYTES + R_BYTES + RED_BYTES;      // 155136 / 80384
+};
 
-__global__ __launch_bounds__(1024) void dw5m_gemm_gate_kernel(const bf16_t* __restrict__ g1p, const float* __restrict__ ca_in,
-                                                            const uint32_t* __restrict__ ttab, const uint4* __restrict__ wfrag,
-                                                            bf16_t* g2, float* pool, int T, int h, int w, int wr, const int dbg,
-                                                            unsigned long long* prof) {
-    constexpr int C = K3M_C, TW = K3M_TW, TH = K3M_TH, RH = K3M_RH, RX = K3M_RX, CHK = K3M_CHK, KS = 2, RP = K3M_RPITCH;
-    constexpr int NIT = 2, NITEMS = CHK * RH * (RX / 8);               // 1920 staging items of 16 B per chunk, <= 2 per thread
+template <int TH>
+__global__ __launch_bounds__(K3mShape<TH>::NTHR, TH == 8 ? 1 : 4)
+void dw5m_gemm_gate_kernel(const bf16_t* __restrict__ g1p, const float* __restrict__ ca_in, const uint32_t* __restrict__ ttab,
+                           const uint4* __restrict__ wfrag, bf16_t* g2, float* pool, int T, int h, int w, int wr, const int dbg,
+                           unsigned long long* prof) {
+    using SH = K3mShape<TH>;
+    constexpr int C = K3M_C, TW = K3M_TW, RH = SH::RH, RX = K3M_RX, CHK = K3M_CHK, KS = 2, RP = SH::RPITCH;
+    constexpr int NWV = SH::NWV, NTHR = SH::NTHR, NBUF = SH::NBUF, GIMG_BYTES = SH::GIMG_BYTES;
+    constexpr int NITEMS = CHK * RH * (RX / 8), NIT = (NITEMS + NTHR - 1) / NTHR;     // staging items of 16 B per chunk: 1920 -> 2, 1280 -> 3 per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t* tab = (const uint32_t*)smem;
-    char* gimg = smem + K3M_TAB_BYTES;                                 // [2][CHK][RH][RX] bf16
-    uint32_t* lds_r = (uint32_t*)(gimg + 2 * K3M_GIMG_BYTES);          // [32 channel pairs][RP]: dword = (channel 2q, 2q+1) of one pixel
-    float* red = (float*)((char*)lds_r + K3M_R_BYTES);
+    char* gimg = smem + K3M_TAB_BYTES;                                 // [NBUF][CHK][RH][RX] bf16
+    uint32_t* lds_r = (uint32_t*)(gimg + NBUF * GIMG_BYTES);           // [32 channel pairs][RP]: dword = (channel 2q, 2q+1) of one pixel
+    float* red = (float*)((char*)lds_r + SH::R_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
     const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH, tpf = tiles_x * tiles_y, ntiles = T * tpf;
     const size_t frame = (size_t)h * C * wr;                 // elements per frame of the planar tensor
 
-    for (int e = tid; e < K3M_TAB_BYTES / 4; e += 1024) ((uint32_t*)smem)[e] = ttab[e];
+    for (int e = tid; e < K3M_TAB_BYTES / 4; e += NTHR) ((uint32_t*)smem)[e] = ttab[e];
     // phase 2 role of this wave: pixels of N-tiles 4 ng .. 4 ng + 3, M-tiles 4 mh .. 4 mh + 3 (gate pairs 2 mh, 2 mh + 1)
     const int ng = wv >> 1, mh = wv & 1;
     bf16x8_t A2[4][KS];
@@ -64,7 +74,7 @@ __global__ __launch_bounds__(1024) void dw5m_gemm_gate_kernel(const bf16_t* __re
 
     // ---- staging: item = (channel of the chunk, region row, 8-column piece) ----
     auto item = [&](int k, int& cl, int& row, int& xc) {               // cheap (mul-shift divisions), recomputed instead of kept live
-        int idx = tid + k * 1024;
+        int idx = tid + k * NTHR;
         asm volatile("" : "+v"(idx));                                  // opaque: keeps LICM from hoisting (and then spilling) the results
         cl = idx / (RH * (RX / 8));
         const int rem = idx - cl * (RH * (RX / 8));
@@ -97,12 +107,12 @@ __global__ __launch_bounds__(1024) void dw5m_gemm_gate_kernel(const bf16_t* __re
     auto write_gimg = [&](int buf, const uint4* stg, const int* gofs) {
 #pragma unroll
         for (int k = 0; k < NIT; ++k)
-            if (lofs[k] >= 0) *(uint4*)(gimg + buf * K3M_GIMG_BYTES + lofs[k]) = gofs[k] < 0 ? make_uint4(0, 0, 0, 0) : stg[k];
+            if (lofs[k] >= 0) *(uint4*)(gimg + buf * GIMG_BYTES + lofs[k]) = gofs[k] < 0 ? make_uint4(0, 0, 0, 0) : stg[k];
     };
 
     // ---- phase 1 role: channel pair pr of the chunk, rows 4 hf .. 4 hf + 3; lane column n = p -> (x-tile xt, row rr) ----
     // A row m = p, k-block g: the lane's 8 band values start at element s0 = 1 - p + 8 g of the padded band (all-zero window: 12)
-    const int pr = wv >> 1, hf = wv & 1, xt = p & 3, rr = p >> 2;
+    const int pr = wv / (TH / 4), hf = wv % (TH / 4), xt = p & 3, rr = p >> 2;
     // Only the FIRST and LAST dword of the window are read from LDS (W: elements s0, s0+1; X: s0+6, s0+7).  The windows of
     // neighbouring lanes are the same band shifted by one element, so dword 1 = W of lane m-2 (or X of lane m+4 at the row's
     // low edge) and dword 2 = X of lane m+2 (or W of lane m-4 at the high edge): DPP row shifts, 8 bytes of LDS per fragment.
@@ -118,15 +128,18 @@ __global__ __launch_bounds__(1024) void dw5m_gemm_gate_kernel(const bf16_t* __re
     const int seg0 = (blockIdx.x % nxcd) * seg, seg1 = seg0 + seg < ntiles ? seg0 + seg : ntiles;
     int tile = seg0 + blockIdx.x / nxcd;
 
-    // software pipeline over steps (tile, chunk q): HBM -> registers three steps ahead, registers -> LDS one step ahead
+    // software pipeline over steps (tile, chunk q).  NBUF = 2: HBM -> registers three steps ahead, registers -> LDS one step
+    // ahead, one barrier per step.  NBUF = 1: HBM -> registers two steps ahead, registers -> LDS at the start of the step.
     uint4 stgA[NIT], stgB[NIT];                 // data of even / odd steps
     int gofs[NIT], gofs_n[NIT];
     int t = plan_tile(tile < seg1 ? tile : 0, gofs), tn = t;
     issue_loads(stgA, gofs, t, 0);
     issue_loads(stgB, gofs, t, 1);
-    write_gimg(0, stgA, gofs);
-    issue_loads(stgA, gofs, t, 2);
-    __syncthreads();                                          // table and chunk 0 ready
+    if (NBUF == 2) {
+        write_gimg(0, stgA, gofs);
+        issue_loads(stgA, gofs, t, 2);
+    }
+    __syncthreads();                                          // table (and chunk 0) ready
     for (; tile < seg1; tile += wpx) {
         const int rem = tile - t * tpf, tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
         const int y0 = tyi * TH, x0 = txi * TW;
@@ -134,14 +147,23 @@ __global__ __launch_bounds__(1024) void dw5m_gemm_gate_kernel(const bf16_t* __re
         tick(7);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            // (a) data of the next step: registers -> the other LDS buffer; (b) refill those registers for three steps ahead
-            uint4* stg = (q & 1) ? stgA : stgB;               // step q + 1 has the opposite parity
             if (q == 0) tn = plan_tile(ntile, gofs_n);
-            write_gimg((q + 1) & 1, stg, q == 3 ? gofs_n : gofs);
-            if (q == 0) issue_loads(stg, gofs, t, 3); else issue_loads(stg, gofs_n, tn, q - 1);
+            if (NBUF == 2) {
+                // (a) data of the next step: registers -> the other LDS buffer; (b) refill those registers for three steps ahead
+                uint4* stg = (q & 1) ? stgA : stgB;               // step q + 1 has the opposite parity
+                write_gimg((q + 1) & 1, stg, q == 3 ? gofs_n : gofs);
+                if (q == 0) issue_loads(stg, gofs, t, 3); else issue_loads(stg, gofs_n, tn, q - 1);
+            } else {
+                // (a) data of THIS step: registers -> the LDS buffer (free since the barrier that ended the previous step);
+                // (b) refill those registers for two steps ahead
+                uint4* stg = (q & 1) ? stgB : stgA;
+                write_gimg(0, stg, gofs);
+                __syncthreads();
+                if (q < 2) issue_loads(stg, gofs, t, q + 2); else issue_loads(stg, gofs_n, tn, q - 2);
+            }
             tick(0);
             // (c) Toeplitz MFMAs of this step from buffer q & 1
-            const char* gb = gimg + (q & 1) * K3M_GIMG_BYTES + boff;
+            const char* gb = gimg + (NBUF == 2 ? (q & 1) : 0) * GIMG_BYTES + boff;
             f32x4_t D[2];
 #pragma unroll
             for (int ci = 0; ci < 2; ++ci) {
@@ -217,7 +239,7 @@ __global__ __launch_bounds__(1024) void dw5m_gemm_gate_kernel(const bf16_t* __re
         if (pool && tid < C) {                                // channel tid = g*16 + mh*8 + j*4 + r4, summed over the 8 pixel groups
             float sm = 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) sm += red[(2 * k + ((tid >> 3) & 1)) * 32 + (tid >> 4) * 8 + (tid & 7)];
+            for (int k = 0; k < NWV / 2; ++k) sm += red[(2 * k + ((tid >> 3) & 1)) * 32 + (tid >> 4) * 8 + (tid & 7)];
             pool[((size_t)t * tpf + rem) * C + tid] = sm;
         }
         // red is rewritten only after the next tile's first __syncthreads()
@@ -468,6 +490,27 @@ __global__ __launch_bounds__(256) void nhwc_to_planar_kernel(const bf16_t* __res
 }  // namespace
 
 extern "C" {
+int sn_planar_pitch(int w);
+int sn_debug_get(void);
+void* sn_debug_buf_get(void);
+}
+
+template <int TH>
+static int launch_k3m(const void* g1p, const float* ca_in, const void* ttab, const void* wfrag, void* g2, float* pool, int T, int h, int w,
+                      void* stream) {
+    using SH = K3mShape<TH>;
+    const int ntiles = T * ((h + TH - 1) / TH) * ((w + K3M_TW - 1) / K3M_TW);
+    const int maxwg = 256 * (TH == 8 ? 1 : 2);              // persistent: one / two workgroups per CU (LDS-limited)
+    const int nwg = ntiles < maxwg ? ntiles : maxwg;
+    (void)hipFuncSetAttribute((const void*)dw5m_gemm_gate_kernel<TH>, hipFuncAttributeMaxDynamicSharedMemorySize, SH::LDS);
+    sn_clear_error();
+    hipLaunchKernelGGL(dw5m_gemm_gate_kernel<TH>, dim3(nwg), dim3(SH::NTHR), SH::LDS, (hipStream_t)stream, (const bf16_t*)g1p, ca_in,
+                       (const uint32_t*)ttab, (const uint4*)wfrag, (bf16_t*)g2, pool, T, h, w, sn_planar_pitch(w), sn_debug_get(),
+                       (unsigned long long*)((sn_debug_get() & 512) ? sn_debug_buf_get() : nullptr));
+    return sn_check_launch();
+}
+
+extern "C" {
 
 int sn_debug_get(void);
 void* sn_debug_buf_get(void);
@@ -507,19 +550,26 @@ int sn_ln_gemm_gate_m(const sn_unit_src* s, const void* hw, const void* wfrag, c
     return sn_check_launch();
 }
 
-int sn_dw5m_blocks(int h, int w) { return ((h + K3M_TH - 1) / K3M_TH) * ((w + K3M_TW - 1) / K3M_TW); }
+// shape of sn_dw5m_gemm_gate: tile height 8 (one 1024-thread workgroup per CU, default: 381 us at level 1) or 4 (two
+// 512-thread workgroups per CU: 432 us, the extra halo rows and barriers cost more than the interleaving gains);
+// SN_K3M_TH overrides it for A/B measurements.  Read once: the pool layout (sn_dw5m_blocks) depends on it.
+static int k3m_th() {
+    static int th = 0;
+    if (!th) {
+        const char* e = getenv("SN_K3M_TH");
+        th = (e && atoi(e) == 4) ? 4 : 8;
+    }
+    return th;
+}
+
+int sn_dw5m_blocks(int h, int w) { const int th = k3m_th(); return ((h + th - 1) / th) * ((w + K3M_TW - 1) / K3M_TW); }
 
 int sn_dw5m_gemm_gate(const void* g1p, const float* ca_in, const void* ttab, const void* wfrag, void* g2, float* pool,
                       int T, int h, int w, int C, void* stream) {
     sn_clear_error();
     if (!g1p || !ttab || !wfrag || !g2 || C != 64 || T < 1 || h < 1 || w < 1) return SN_EINVAL;
-    const int ntiles = T * sn_dw5m_blocks(h, w);
-    const int nwg = ntiles < 256 ? ntiles : 256;              // one 1024-thread workgroup per CU (LDS-limited), persistent
-    (void)hipFuncSetAttribute((const void*)dw5m_gemm_gate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, K3M_LDS);
-    sn_clear_error();
-    hipLaunchKernelGGL(dw5m_gemm_gate_kernel, dim3(nwg), dim3(1024), K3M_LDS, (hipStream_t)stream, (const bf16_t*)g1p, ca_in,
-                       (const uint32_t*)ttab, (const uint4*)wfrag, (bf16_t*)g2, pool, T, h, w, sn_planar_pitch(w), sn_debug_get(), (unsigned long long*)((sn_debug_get() & 512) ? sn_debug_buf_get() : nullptr));
-    return sn_check_launch();
+    return k3m_th() == 8 ? launch_k3m<8>(g1p, ca_in, ttab, wfrag, g2, pool, T, h, w, stream)
+                         : launch_k3m<4>(g1p, ca_in, ttab, wfrag, g2, pool, T, h, w, stream);
 }
 
 }  // extern "C"

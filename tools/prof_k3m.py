@@ -29,7 +29,7 @@ def main():
     wg = prep.pack_gate_gemm(torch.randn(2 * C, C, 1, 1) * 0.1, C).to(dev)
     g2 = torch.empty(T, h, w, C, dtype=torch.bfloat16, device=dev)
     pool = torch.empty(T, lib.sn_dw5m_blocks(h, w), C, dtype=torch.float32, device=dev)
-    buf = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
+    buf = torch.zeros(512 * 8 * 8, dtype=torch.int64, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     lib.sn_debug_set(args.dbg)
 
@@ -53,7 +53,8 @@ def main():
     lib.sn_debug_buf_set(None)
     lib.sn_debug_set(0)
     print(f"instrumented: {e0.elapsed_time(e1) * 1e3:.1f} us")
-    a = buf.view(256, 8, 8).double()
+    a = buf.view(512, 8, 8).double()
+    a = a[a.sum((1, 2)) > 0]                      # workgroups that ran (256 or 512, depending on the kernel shape)
     names = ["stage(write+issue)", "barrier_after_gemm", "-", "toeplitz", "-", "barrier_step", "gemm", "tile_top"]
     tot = a.sum(-1).mean().item()
     print(f"mean wave cycles (100 MHz ticks?) total {tot:.0f}")
