@@ -178,3 +178,25 @@ def test_toeplitz_band_table(k):
             ref = np.array([sum(w[ch, dy, dx] * x[ch, oy + dy, 8 + m + dx - k // 2] for dy in range(k) for dx in range(k))
                             for m in range(16)])
             np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_toeplitz_dw3_chunk_records():
+    """prep.pack_toeplitz_dw3_chunks: plane (half, n) of chunk q must carry the band of the channel that row n of the
+    gate-paired weight blocks 2q / 2q+1 produces (prep.rows_gate), with the RepConv2 identity folded into the centre tap."""
+    c = 64
+    rng = np.random.default_rng(11)
+    w = torch.from_numpy(rng.standard_normal((2 * c, 1, 3, 3)).astype(np.float32))
+    rec = prep.pack_toeplitz_dw3_chunks(w, c).float().numpy()          # [4][32][3][2][20]
+    assert rec.shape == (c // 16, 32, 3, 2, 20)
+    rows = prep.rows_gate(c)                                           # channel o -> row index in the 16*MT padded matrix
+    wn = w.bfloat16().float().numpy().reshape(2 * c, 3, 3).copy()
+    for o in range(2 * c):
+        row = rows[o]
+        mt, n = row // 16, row % 16
+        q, half = mt // 2, mt % 2
+        band = rec[q, half * 16 + n]                                   # [3][2][20]
+        ref = wn[o].copy()
+        ref[1, 1] = (w[o, 0, 1, 1] + 1.0).bfloat16().float().item()
+        np.testing.assert_array_equal(band[:, 0, 7:10], ref)           # copy 0: taps at elements 7..9
+        np.testing.assert_array_equal(band[:, 1, 6:9], ref)            # copy 1: shifted left by one
+        assert np.count_nonzero(band[:, 0, :7]) == 0 and np.count_nonzero(band[:, 0, 10:]) == 0
