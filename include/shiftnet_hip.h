@@ -147,8 +147,15 @@ int sn_lngate_blocks(int h, int w);
 
 /* sn_dw_gemm_gate for the depthwise variants (C = 64) with the channel-blocked g1 tile staged through LDS; pool: [T][sn_dw5_blocks][C]. */
 int sn_dw5_blocks(int h, int w);
-/* profiling aid: bit mask of kernel phases to skip in sn_dw5_gemm_gate (results are then wrong); default 0 */
+/* Profiling aids (tools/ only; process-global, default 0 / NULL = production behaviour):
+ *   sn_debug_set(mask): bits 1,2,4,8 (sn_dw5_gemm_gate / sn_dw5m_gemm_gate) and 8,16,32 (sn_ln_gemm_gate) skip a phase of
+ *     the kernel (results are then wrong) for ablation timing; bit 256 / 512 make sn_ln_gemm_gate(_m) / sn_dw5m_gemm_gate
+ *     write per-wave s_memtime phase accumulators ([workgroup][8 waves][8 slots] u64) to the buffer set below.
+ *   sn_debug_buf_set(dev_ptr): device buffer for those accumulators (tools/prof_k12.py, tools/prof_k3m.py). */
 int sn_debug_set(int v);
+int sn_debug_get(void);
+int sn_debug_buf_set(void* dev_ptr);
+void* sn_debug_buf_get(void);
 int sn_dw5_gemm_gate(const void* g1, const float* ca_in, const uint32_t* w5, const void* wfrag, void* g2, float* pool,
                      int T, int h, int w, int C, void* stream);
 

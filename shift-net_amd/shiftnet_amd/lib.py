@@ -19,7 +19,7 @@ SYMBOLS = [
     "sn_abi_version", "sn_selftest_mfma", "sn_ingest", "sn_conv2d", "sn_conv_pool_blocks", "sn_ca_mlp",
     "sn_scale_residual", "sn_cab_ca", "sn_cab_ca_scratch_floats", "sn_planar_pitch", "sn_nhwc_to_planar", "sn_dw5m_blocks", "sn_dw5m_gemm_gate", "sn_lngatem_blocks", "sn_ln_gemm_gate_m", "sn_gsts_gather", "sn_temporal_roll", "sn_gsts_shiftconv", "sn_ln_gemm", "sn_dw_gate",
     "sn_dwgate_blocks", "sn_dw_gemm_gate", "sn_dwgemm_blocks", "sn_scale_gemm_res",
-    "sn_ln_gemm_gate", "sn_lngate_blocks", "sn_dw5_gemm_gate", "sn_dw5_blocks", "sn_debug_set", "sn_grp5_gemm_gate", "sn_grp5_blocks",
+    "sn_ln_gemm_gate", "sn_lngate_blocks", "sn_dw5_gemm_gate", "sn_dw5_blocks", "sn_debug_set", "sn_debug_get", "sn_debug_buf_set", "sn_debug_buf_get", "sn_grp5_gemm_gate", "sn_grp5_blocks",
 ]
 
 
@@ -91,12 +91,16 @@ def load() -> C.CDLL:
     lib.sn_lngate_blocks.argtypes = [ci, ci]
     lib.sn_dw5_blocks.argtypes = [ci, ci]
     lib.sn_debug_set.argtypes = [ci]
+    lib.sn_debug_get.argtypes = []
+    lib.sn_debug_buf_set.argtypes = [vp]
+    lib.sn_debug_buf_get.argtypes = []
     lib.sn_grp5_gemm_gate.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.sn_grp5_blocks.argtypes = [ci, ci]
     lib.sn_dw5_gemm_gate.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.sn_scale_gemm_res.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp, vp]
     for s in SYMBOLS:
         getattr(lib, s).restype = ci
+    lib.sn_debug_buf_get.restype = vp
     if lib.sn_abi_version() != 1:
         raise ShiftNetLibError("ABI version mismatch between shiftnet_amd/lib.py and libshiftnet_hip.so")
     _lib = lib
