@@ -214,3 +214,84 @@ def scale_gemm_res(x, g2, ca, wfrag, bias, mode, wrap):
                     b = bias[co0:co0 + 4] if bias is not None else 0.0
                     y[t, i, co0:co0 + 4] = sc + regs[mt, lane] + b
     return y.reshape(T, h, w, C)
+
+
+def toeplitz_frag(rec, m, g, k):
+    """A fragment (8 values) of lane (m, g) from one band record [2][20], built the way dw5m_gemm_gate_kernel / ln_gemm_gate_m
+    do it: only the first (W) and last (X) dword of the lane's window are read, dwords 1 and 2 come from neighbouring lanes
+    (DPP row shifts with the opposite-edge fallback).  k = stencil size (window start s0 = k//2 - 1 - m + 8g)."""
+    flat = rec.reshape(40)
+
+    def s0_of(mm):
+        return k // 2 - 1 - mm + 8 * g
+
+    def X(mm):                                   # elements (s0+6, s0+7) of lane mm, zero when out of the band's reach
+        s0 = s0_of(mm)
+        if s0 < 0 or s0 > 5:
+            return flat[0:2]
+        tw = 10 + (s0 + 5) // 2 if s0 & 1 else (s0 + 6) // 2
+        return flat[2 * tw:2 * tw + 2]
+
+    def W(mm):                                   # elements (s0, s0+1)
+        s0 = s0_of(mm)
+        if s0 < 6 or s0 > 11:
+            return flat[0:2]
+        tw = 10 + (s0 - 1) // 2 if s0 & 1 else s0 // 2
+        return flat[2 * tw:2 * tw + 2]
+    d0, d3 = W(m), X(m)
+    d1 = W(m - 2) if m >= 2 else X(m + 4)        # row_shr:2, lanes 0..1 keep row_shl:4 of X
+    d2 = X(m + 2) if m <= 13 else W(m - 4)       # row_shl:2, lanes 14..15 keep row_shr:4 of W
+    return np.concatenate([d0, d1, d2, d3])
+
+
+def dw5m_gemm_gate(g1, ttab, wfrag, ca_in=None):
+    """sn_dw5m_gemm_gate (TH = 8 shape) -> (g2 [T,h,w,C], channel sums [T,C]).  g1 is given NHWC here; the planar image
+    [channel][row][x] of one 64 x 8 tile (+2 rows, columns x0-8 .. x0+71) is what the Toeplitz MFMAs read."""
+    wfrag = frag_to_np(wfrag); MT, KS = wfrag.shape[:2]
+    tab = ttab.float().numpy()                                       # [C][5][2][20]
+    T, h, w, C = g1.shape
+    TW, TH = 64, 8
+    g2 = np.zeros((T, h, w, C), np.float32)
+    A = np.zeros((C, 5, 16, 32), np.float32)
+    for c in range(C):
+        for dy in range(5):
+            for m in range(16):
+                for g in range(4):
+                    A[c, dy, m, 8 * g:8 * g + 8] = toeplitz_frag(tab[c, dy], m, g, 5)
+    for t in range(T):
+        for y0 in range(0, h, TH):
+            for x0 in range(0, w, TW):
+                img = np.zeros((C, TH + 4, 80), np.float32)              # rows y0-2.., columns x0-8..
+                for ry in range(TH + 4):
+                    gy = y0 - 2 + ry
+                    if gy < 0 or gy >= h:
+                        continue
+                    for rx in range(80):
+                        gx = x0 - 8 + rx
+                        if 0 <= gx < w:
+                            img[:, ry, rx] = g1[t, gy, gx]
+                r = np.zeros((TH * TW, C), np.float32)                   # pair planes in the kernel; plain [px][ch] here
+                for c in range(C):
+                    sc = 1.0 if ca_in is None else ca_in[t, c]
+                    for row in range(TH):
+                        for xt in range(4):
+                            acc = sum(A[c, dy] @ img[c, row + dy, 16 * xt:16 * xt + 32] for dy in range(5))
+                            r[row * TW + 16 * xt:row * TW + 16 * xt + 16, c] = acc * sc
+                for nt in range(TH * TW // 16):
+                    bfrag = np.zeros((KS, 64, 8), np.float32)
+                    for lane in range(64):
+                        g, p = lane >> 4, lane & 15
+                        for s in range(KS):
+                            bfrag[s, lane] = r[nt * 16 + p, 32 * s + 8 * g:32 * s + 8 * g + 8]
+                    regs = mfma_tiles(wfrag, bfrag)
+                    for lane in range(64):
+                        g, p = lane >> 4, lane & 15
+                        tp = nt * 16 + p
+                        oy, ox = y0 + tp // TW, x0 + tp % TW
+                        if oy >= h or ox >= w:
+                            continue
+                        for mp in range(MT // 2):
+                            b1, b2 = regs[2 * mp, lane], regs[2 * mp + 1, lane]
+                            c0 = g * 2 * MT + mp * 4
+                            g2[t, oy, ox, c0:c0 + 4] = b1 / (1.0 + np.exp(-b2))
+    return g2, g2.reshape(T, h * w, C).sum(1)

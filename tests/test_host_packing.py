@@ -200,3 +200,21 @@ def test_toeplitz_dw3_chunk_records():
         np.testing.assert_array_equal(band[:, 0, 7:10], ref)           # copy 0: taps at elements 7..9
         np.testing.assert_array_equal(band[:, 1, 6:9], ref)            # copy 1: shifted left by one
         assert np.count_nonzero(band[:, 0, :7]) == 0 and np.count_nonzero(band[:, 0, 10:]) == 0
+
+
+def test_matrix_core_stencil_emulation_matches_valu_path():
+    """sn_dw5m_gemm_gate's conventions (band records read as first/last dword + DPP neighbours, planar window starting 8
+    columns left of the tile, natural-K gate GEMM) against the already oracle-checked emulation of the VALU kernel."""
+    name = "gshift_deblur2"
+    sd = synth_state_dict(name)
+    C, T, h, w = 64, 1, 11, 70                                         # ragged in both directions, two tiles in x and y
+    q = "stage1.decoder_level1.encoder_level1.0."
+    rng = np.random.default_rng(3)
+    g1 = torch.from_numpy(rng.standard_normal((T, h, w, C)).astype(np.float32)).bfloat16().float().numpy()
+    w5 = prep.pack_dw5(sd[f"{q}body.3.conv_1.weight"], sd[f"{q}body.3.conv_2.weight"])
+    wg = prep.pack_gate_gemm(sd[f"{q}body.4.weight"], C)
+    ca = rng.uniform(0.5, 1.5, (T, C)).astype(np.float32)
+    ref, ref_sums = emu.dw_gemm_gate(g1, w5.to(torch.bfloat16).float().numpy(), wg, ca)
+    got, got_sums = emu.dw5m_gemm_gate(g1, prep.pack_toeplitz(w5, 5), wg, ca)
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(got_sums, ref_sums, rtol=1e-4, atol=1e-3)
