@@ -218,3 +218,26 @@ def test_matrix_core_stencil_emulation_matches_valu_path():
     got, got_sums = emu.dw5m_gemm_gate(g1, prep.pack_toeplitz(w5, 5), wg, ca)
     np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(got_sums, ref_sums, rtol=1e-4, atol=1e-3)
+
+
+def test_cab_pooled_mean_closed_form():
+    """The algebra behind sn_cab_ca: the spatial mean of res = conv3x3(mid) (zero padding, no bias) follows from the channel
+    sums of `mid`, its first/last rows and columns and its four corners -- so the CALayer scale of a CAB is known before the
+    second conv runs.  Tap (ky, kx) reads mid(p + (ky-1, kx-1)): dy = +1 never reaches row 0, dy = -1 never reaches row h-1."""
+    rng = np.random.default_rng(9)
+    c, h, w = 6, 7, 9
+    mid = torch.from_numpy(rng.standard_normal((1, c, h, w)).astype(np.float32))
+    w2 = torch.from_numpy(rng.standard_normal((c, c, 3, 3)).astype(np.float32))
+    ref = torch.nn.functional.conv2d(mid, w2, padding=1).mean((2, 3))[0].numpy()
+    m = mid[0].numpy()
+    tot, r0, r1, c0, c1 = m.sum((1, 2)), m[:, 0].sum(1), m[:, -1].sum(1), m[:, :, 0].sum(1), m[:, :, -1].sum(1)
+    k00, k01, k10, k11 = m[:, 0, 0], m[:, 0, -1], m[:, -1, 0], m[:, -1, -1]
+    rowex = [r1, 0.0, r0]                    # excluded row for ky = 0, 1, 2
+    colex = [c1, 0.0, c0]
+    cor = [[k11, 0.0, k10], [0.0, 0.0, 0.0], [k01, 0.0, k00]]
+    got = np.zeros(c, np.float32)
+    for ky in range(3):
+        for kx in range(3):
+            s_tap = tot - rowex[ky] - colex[kx] + cor[ky][kx]            # [cin]
+            got += w2[:, :, ky, kx].numpy() @ s_tap
+    np.testing.assert_allclose(got / (h * w), ref, rtol=1e-4, atol=1e-5)
