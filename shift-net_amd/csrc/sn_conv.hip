@@ -116,6 +116,28 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK P) {
         const int nn = wv * NTW + n, row = nn / XB, xb = nn - row * XB;
         pixbase[n] = ((row * P.stride) * P.rw + (xb * 16 + p) * P.stride) * P.ps;
     }
+    // Residual operand of the epilogue, fetched NOW (unconditional loads at clamped addresses: a load inside the epilogue's
+    // divergent `valid` branch is waited for on the spot -- one HBM round trip per N-tile, four in a row per wave); it lands
+    // while the MFMAs run.  Without a residual the lanes read one dummy 8-byte word of the weight buffer.
+    // Only for MT = 1 (the full-resolution 16-channel convs): for wider outputs the extra registers cost more occupancy
+    // than the hidden round trips win (measured: mt1 22.4 -> 21.0 ms, mt2 19.3 -> 19.8 ms per window).
+    constexpr bool PRE_RES = MT == 1;
+    uint2 rres[PRE_RES ? MT : 1][PRE_RES ? NTW : 1];
+    if constexpr (PRE_RES) {
+        const bf16_t* rb = P.res ? P.res : (const bf16_t*)P.wfrag;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            const int nn = wv * NTW + n, row = nn / XB, xb = nn - row * XB;
+            const int oy = oy0 + row, ox = ox0 + xb * 16 + p;
+            const bool valid = P.res && (oy < P.hout) && (ox < P.wout);
+            const size_t opix = ((size_t)t * P.hout + oy) * P.wout + ox;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int co0 = g * 4 * MT + m * 4;
+                rres[m][n] = *(const uint2*)(rb + ((valid && co0 < P.cs_out) ? opix * P.cs_out + co0 : 0));
+            }
+        }
+    }
     // weight fragments one k-step AHEAD (they come from L1/L2; loaded at the point of use every k-step would pay the full
     // load latency, and the trip count is a run-time value, so the compiler cannot pipeline this itself)
     for (int s = 0; s < P.ks; ++s) {
@@ -166,7 +188,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK P) {
                 for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : v[r] * P.prelu;
             }
             v[0] *= osc[m].x; v[1] *= osc[m].y; v[2] *= osc[m].z; v[3] *= osc[m].w;
-            if (P.res && valid && co0 < P.cs_out) {
+            if constexpr (PRE_RES) {
+                if (P.res) {                   // wave-uniform; out-of-range lanes add a dummy value that is never stored
+                    const uint2 rr = rres[m][n];
+                    v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
+                }
+            } else if (P.res && valid && co0 < P.cs_out) {
                 const uint2 rr = *(const uint2*)(P.res + opix * P.cs_out + co0);
                 v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
             }
