@@ -70,6 +70,8 @@ typedef struct sn_conv_desc {
     const float* oscale; /* NULL or [T][oscale_stride] f32: out = conv * oscale[t][c] (+ res) -- the CALayer scale of a CAB
                             applied in the epilogue of its second conv ("res = self.CA(res); res += x", :155-157) */
     int oscale_stride;
+    const void* res2;    /* NULL or a second NHWC residual of the same shape as `res`, added after it: the "+ shortcut" that
+                            follows the last TFR_UNet of a stage (gshift_deblur1.py:769,779) rides on that UNet's last conv */
 } sn_conv_desc;
 int sn_conv2d(const sn_conv_desc* d, void* stream);   /* d is a HOST pointer, read during the call */
 /* number of workgroups per frame sn_conv2d launches for this descriptor (= rows of `pool` per frame); host only */
@@ -193,6 +195,56 @@ int sn_dw5m_gemm_gate(const void* g1p, const float* ca_in, const void* ttab, con
  * into wfrag/bias; the shortcut is the ROLLED tensor for CAB2 (mode 1/2) and x for CAB1 (mode 0). */
 int sn_scale_gemm_res(const sn_unit_src* s, const void* g2, const float* ca, const void* wfrag, const float* bias,
                       void* y, void* stream);
+
+
+/* ---- fp32-storage path (csrc/sn_f32.hip) -----------------------------------------------------------------------
+ * The arithmetic type upstream runs the "+" denoiser in (inference/test_denoise.py:83-85: the .half() is commented out)
+ * and the validation build of the engine: activations fp32 NHWC [T][H][W][C] with an explicit pixel stride `cs`
+ * (elements) so that channel slices of a wider tensor can be read / written in place, weights = the checkpoint's fp32
+ * values re-ordered to [k][k][cin/groups][cout].  Direct fp32 FMA kernels (no MFMA): correctness first. */
+typedef struct sn32_conv_desc {
+    const float* in[3];  /* 1..3 inputs concatenated along channels (groups == 1), pre-offset to their first channel */
+    int c_in[3];         /* logical channels taken from each input */
+    int cs_in[3];        /* pixel stride of each input, elements */
+    int n_in;
+    int T, h_in, w_in;   /* spatial size the convolution sees */
+    int in_mode;         /* 0 as is; 1 inputs are [T][h_in/2][w_in/2] upsampled x2 bilinearly while reading (gshift_deblur1.py:344) */
+    int k, stride, pad, groups;   /* nn.Conv2d(.., groups): 1, C/8 (RepConv "+", :160-161) or C (depthwise) */
+    int h_out, w_out, c_out;
+    const float* w;      /* [k][k][cin_total/groups][c_out] */
+    const float* bias;   /* [c_out] or NULL */
+    int act; float prelu;                      /* as sn_conv_desc */
+    const float* oscale; int oscale_stride;    /* NULL or [T][oscale_stride] (stride 0: one row for all frames): out = (conv+bias) * oscale (+ res) */
+    const float* res; int cs_res;              /* NULL or NHWC tensor added last */
+    void* out; int cs_out;
+    int out_mode;        /* 0 NHWC fp32; 1 pixel_shuffle(2) NHWC fp32; 2 NCHW of nchw_dtype + shortcut sc (as sn_conv_desc) */
+    int nchw_dtype; const void* sc;
+} sn32_conv_desc;
+int sn32_conv2d(const sn32_conv_desc* d, void* stream);
+/* channel_shift (gshift_deblur1.py:504-528) materialised in fp32: offs != NULL: u [T][h][w][3C/2] = cat(roll(x), shift(borrowed));
+ * offs == NULL: the temporal roll alone, [T][h][w][C] (Shift_CAB, gshift_denoise1.py:167-179).  s->x is a float tensor. */
+int sn32_gsts_gather(const sn_unit_src* s, const int8_t* offs, float* u, void* stream);
+/* LayerNorm2d (gshift_deblur1.py:19-28,44-53) over K channels per pixel. */
+int sn32_layernorm(const float* x, int cs_x, int K, const float* w, const float* b, float* out, int cs_out, long long npix, void* stream);
+/* SimpleGate (mode 0, :175-178) / SimpleGate2 (mode 1, :179-182): a:[npix][2C] -> out:[npix][C]. */
+int sn32_gate(const float* a, int C, int mode, float* out, long long npix, void* stream);
+/* AdaptiveAvgPool2d(1) first half: partial:[T][nblk][cpad] sums (cpad >= C, <= 256), finished by sn_ca_mlp. */
+int sn32_chan_sum(const float* x, int cs, int C, int cpad, int T, int hw, int nblk, float* partial, void* stream);
+/* out = r * ca[t][c] (+ x if x != NULL). */
+int sn32_scale_residual(const float* r, const float* x, const float* ca, int ca_stride, float* out, int T, int hw, int C, void* stream);
+/* NCHW (src_dtype) [+ noise map] -> NHWC fp32 [T][H][W][C(+1)]. */
+int sn32_ingest(const void* src, int src_dtype, const void* noise, float* dst, int T, int C, int H, int W, void* stream);
+
+
+/* ---- I/O edges of the CLIs (csrc/sn_io.hip) ---------------------------------------------------------------------
+ * numpy2tensor + .to(device) + .half() (inference/test_deblur.py:191-200,128,134) with the uint8 frames crossing PCIe:
+ * src:[T][H][W][3] u8 (device) -> dst:[T][3][H][W] of dst_dtype, value = round(float(v) * (1/255)). */
+int sn_ingest_u8(const uint8_t* src, void* dst, int dst_dtype, int T, int H, int W, void* stream);
+/* clamp(0,1) * 255 of the network output (test_deblur.py:140-141): img:[T][H][W][3] u8 rounded to nearest even (what
+ * cv2.imwrite stores, :152) or NULL; gt:[T][H][W][3] u8 or NULL; sse:[T][sn_egress_blocks()] f32 partial sums of the
+ * squared error of the UNROUNDED value vs gt (skimage PSNR, data_range 255, :142). */
+int sn_egress_blocks(void);
+int sn_egress_u8(const void* out, int out_dtype, const uint8_t* gt, uint8_t* img, float* sse, int T, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

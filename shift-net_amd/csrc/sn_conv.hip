@@ -23,7 +23,7 @@ struct ConvK {
     const uint4* wfrag; int ks;
     const float* bias; int act; float prelu;
     const bf16_t* res; bf16_t* out; int cs_out, out_mode, c_out, nchw_dtype;
-    const void* sc; float* pool; const float* oscale; int oscale_stride;
+    const void* sc; float* pool; const float* oscale; int oscale_stride; const bf16_t* res2;
     int rh, rw, ps;
     unsigned m_nblk8, m_rw, m_csb, m_cv, m_k;   // ceil(2^24/d) multipliers: integer division by runtime constants without v_div
 };
@@ -189,12 +189,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK P) {
             }
             v[0] *= osc[m].x; v[1] *= osc[m].y; v[2] *= osc[m].z; v[3] *= osc[m].w;
             if constexpr (PRE_RES) {
-                if (P.res) {                   // wave-uniform; out-of-range lanes add a dummy value that is never stored
+                if (P.res && valid && co0 < P.cs_out) {   // out-of-range lanes hold a dummy word: it must reach neither a store nor psum
                     const uint2 rr = rres[m][n];
                     v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
                 }
             } else if (P.res && valid && co0 < P.cs_out) {
                 const uint2 rr = *(const uint2*)(P.res + opix * P.cs_out + co0);
+                v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
+            }
+            if (P.res2 && valid && co0 < P.cs_out) {       // wave-uniform pointer test; two launches per window use it
+                const uint2 rr = *(const uint2*)(P.res2 + opix * P.cs_out + co0);
                 v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
             }
             if (valid) {
@@ -250,6 +254,244 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Specialisation for the workhorse of the encoder-decoder: 3x3, stride 1, ONE input, no upsampling, NHWC output
+// (both convs of every CAB, conv_trans: ~95 % of the dense-conv time).  Same algorithm, operand layouts and epilogue
+// arithmetic as conv_mfma_kernel (results are bit identical); what changes is the instruction count:
+//   * channels per pixel (CS) and the tile are template constants: every division in the staging plan is by a
+//     compile-time constant, the k-loop is fully unrolled (weight fragments are prefetched by the compiler's own
+//     scheduling) and there are no in_mode / n_in branches in the staging loop;
+//   * a region row is ONE contiguous run of (TW+2)*CS*2 bytes in memory: lane i of the staging loop loads the i-th 16-byte
+//     piece of its row, so consecutive lanes read consecutive addresses and the only per-item math is idx -> (row, piece);
+//   * tiles whose ring lies inside the image (all but the frame border) take a path without bounds masks.
+template <int MT, int CS, int TH>
+__global__ __launch_bounds__(256) void conv3_fast_kernel(const ConvK P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TW = 32, RH = TH + 2, RW = TW + 2, NPB = CS / 8;
+    constexpr int PS = (NPB & 1) ? CS * 2 : CS * 2 + 16;              // LDS bytes per pixel: an odd number of 16-byte slots
+    constexpr int KTOT = 9 * CS, KS = (KTOT + 31) / 32;
+    constexpr int NTW = (TH * TW) / 64, XB = TW / 16;
+    constexpr int ROWP = RW * NPB, NITEM = RH * ROWP, NIT = (NITEM + 255) / 256;
+    constexpr int TILE_BYTES = RH * RW * PS;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wv = wave_id();     // (& 255: lets the compiler fold the idx < NITEM guards)
+    const int g = lane >> 4, p = lane & 15;
+    const int t = blockIdx.z, oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+    float* red = (float*)(smem + TILE_BYTES);
+
+    {
+        const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+        const bf16_t* inb = P.in0 + (size_t)t * P.hin * P.win * CS;
+        const bool interior = iy0 >= 0 && iy0 + RH <= P.hin && ix0 >= 0 && ix0 + RW <= P.win;    // workgroup-uniform
+        uint4 v[NIT];
+        if (interior) {
+            const bf16_t* base = inb + ((size_t)iy0 * P.win + ix0) * CS;
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int idx = tid + k * 256, idc = idx < NITEM ? idx : NITEM - 1;
+                const int r = idc / ROWP, i = idc - r * ROWP;
+                v[k] = *(const uint4*)(base + (size_t)r * P.win * CS + i * 8);
+            }
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int idx = tid + k * 256;
+                const int r = idx / ROWP, i = idx - r * ROWP, px = i / NPB, blk = i - px * NPB;
+                if (idx < NITEM) *(uint4*)(smem + (r * RW + px) * PS + blk * 16) = v[k];
+            }
+        } else {
+            bool in[NIT];
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int idx = tid + k * 256, idc = idx < NITEM ? idx : NITEM - 1;
+                const int r = idc / ROWP, i = idc - r * ROWP, px = i / NPB;
+                const int gy = iy0 + r, gx = ix0 + px;
+                in[k] = gy >= 0 && gy < P.hin && gx >= 0 && gx < P.win;
+                v[k] = *(const uint4*)(inb + (in[k] ? ((size_t)gy * P.win + ix0) * CS + i * 8 : 0));   // branch-free, clamped
+            }
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int idx = tid + k * 256;
+                const int r = idx / ROWP, i = idx - r * ROWP, px = i / NPB, blk = i - px * NPB;
+                if (idx < NITEM) *(uint4*)(smem + (r * RW + px) * PS + blk * 16) = in[k] ? v[k] : make_uint4(0, 0, 0, 0);
+            }
+        }
+    }
+
+    // Output / residual addressing: ONE 64-bit wave-uniform base per tensor (scalar registers) plus a 32-bit per-lane element
+    // offset (a frame has < 2^31 elements), instead of a 64-bit multiply chain per N-tile.
+    const bool full = (oy0 + TH <= P.hout) && (ox0 + TW <= P.wout);           // workgroup-uniform: no bounds masks at all
+    const size_t tbase = (((size_t)t * P.hout + oy0) * P.wout + ox0) * P.cs_out;
+    bf16_t* const outb = P.out + tbase;
+    const bf16_t* const resb = P.res ? P.res + tbase : nullptr;
+    const bf16_t* const res2b = P.res2 ? P.res2 + tbase : nullptr;
+    const int c0 = g * 4 * MT;                                      // this lane's 4*MT consecutive channels of its pixel
+    int loff[NTW];
+    bool valid[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        const int nn = wv * NTW + n, row = nn / XB, xb = nn - row * XB;
+        loff[n] = (row * P.wout + xb * 16 + p) * P.cs_out + c0;
+        valid[n] = full || ((oy0 + row < P.hout) && (ox0 + xb * 16 + p < P.wout));
+    }
+    // Residual operand of the epilogue, fetched before the MFMAs (see conv_mfma_kernel); only for the 16-channel convs
+    constexpr bool PRE_RES = MT == 1;
+    uint2 rres[PRE_RES ? NTW : 1];
+    if constexpr (PRE_RES) {
+        const bf16_t* rb = resb ? resb : (const bf16_t*)P.wfrag;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) rres[n] = *(const uint2*)(rb + ((resb && valid[n] && c0 < P.cs_out) ? loff[n] : 0));
+    }
+    __syncthreads();
+
+    f32x4_t acc[MT][NTW];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    int pixbase[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        const int nn = wv * NTW + n, row = nn / XB, xb = nn - row * XB;
+        pixbase[n] = (row * RW + xb * 16 + p) * PS;
+    }
+    // K walk: lane group g reads k-slots [(4s+g)*8, +8) = 8 channels starting at cc0 of tap (dy,dx); compile-time per (s, g)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        int toff = 0;
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            const int kk0 = (s * 4 + gg) * 8;
+            const int tap = kk0 / CS, cc0 = kk0 - tap * CS, dy = tap / 3, dx = tap - dy * 3;
+            const int o = kk0 < KTOT ? (dy * RW + dx) * PS + cc0 * 2 : 0;
+            toff = g == gg ? o : toff;
+        }
+        bf16x8_t a[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = as_frag(P.wfrag[(m * KS + s) * 64 + lane]);
+        bf16x8_t b[NTW];
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) b[n] = as_frag(*(const uint4*)(smem + pixbase[n] + toff));
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) acc[m][n] = mfma16(a[m], b[n], acc[m][n]);
+    }
+
+    // ---------------- epilogue (arithmetic identical to conv_mfma_kernel, out_mode 0 only) ----------------
+    float psum[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) psum[m][r] = 0.f;
+    float4 bia[MT], osc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        bia[m] = P.bias ? *(const float4*)(P.bias + c0 + m * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        osc[m] = P.oscale ? *(const float4*)(P.oscale + (size_t)t * P.oscale_stride + c0 + m * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+    const float slope = P.prelu;
+    // PReLU: for a slope in [0, 1] (every trained / synthetic checkpoint of this family) x >= 0 ? x : a*x == max(x, a*x):
+    // two instructions per value; any other slope takes the general max(x,0) + a*min(x,0) form.  Wave-uniform choice.
+    const int act = P.act != 1 ? 0 : ((slope >= 0.f && slope <= 1.f) ? 1 : 2);
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        float v[MT][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            v[m][0] = acc[m][n][0] + bia[m].x; v[m][1] = acc[m][n][1] + bia[m].y;
+            v[m][2] = acc[m][n][2] + bia[m].z; v[m][3] = acc[m][n][3] + bia[m].w;
+            if (act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[m][r] = fmaxf(v[m][r], slope * v[m][r]);
+            } else if (act == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[m][r] = fmaf(slope, fminf(v[m][r], 0.f), fmaxf(v[m][r], 0.f));
+            }
+            v[m][0] *= osc[m].x; v[m][1] *= osc[m].y; v[m][2] *= osc[m].z; v[m][3] *= osc[m].w;
+        }
+        const bool ok = valid[n];
+        if constexpr (PRE_RES) {
+            if (resb && ok && c0 < P.cs_out) {
+                const uint2 rr = rres[n];
+                v[0][0] += bf_lo(rr.x); v[0][1] += bf_hi(rr.x); v[0][2] += bf_lo(rr.y); v[0][3] += bf_hi(rr.y);
+            }
+        }
+        if (ok) {
+            const bf16_t* rp[2] = {PRE_RES ? nullptr : resb, res2b};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (!rp[q]) continue;                               // wave-uniform
+                const bf16_t* src = rp[q] + loff[n];
+                if constexpr (MT == 2 || MT == 4) {                 // the lane's run is 16-byte aligned: 16-byte loads
+#pragma unroll
+                    for (int m = 0; m < MT; m += 2) {
+                        if (c0 + m * 4 < P.cs_out) {
+                            const uint4 rr = *(const uint4*)(src + m * 4);
+                            v[m][0] += bf_lo(rr.x); v[m][1] += bf_hi(rr.x); v[m][2] += bf_lo(rr.y); v[m][3] += bf_hi(rr.y);
+                            v[m + 1][0] += bf_lo(rr.z); v[m + 1][1] += bf_hi(rr.z); v[m + 1][2] += bf_lo(rr.w); v[m + 1][3] += bf_hi(rr.w);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        if (c0 + m * 4 < P.cs_out) {
+                            const uint2 rr = *(const uint2*)(src + m * 4);
+                            v[m][0] += bf_lo(rr.x); v[m][1] += bf_hi(rr.x); v[m][2] += bf_lo(rr.y); v[m][3] += bf_hi(rr.y);
+                        }
+                    }
+                }
+            }
+            bf16_t* dst = outb + loff[n];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) psum[m][r] += v[m][r];
+            if constexpr (MT == 2 || MT == 4) {
+#pragma unroll
+                for (int m = 0; m < MT; m += 2)
+                    if (c0 + m * 4 < P.cs_out)
+                        *(uint4*)(dst + m * 4) = make_uint4(pack_bf2(v[m][0], v[m][1]), pack_bf2(v[m][2], v[m][3]),
+                                                            pack_bf2(v[m + 1][0], v[m + 1][1]), pack_bf2(v[m + 1][2], v[m + 1][3]));
+            } else {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    if (c0 + m * 4 < P.cs_out) {
+                        uint2 o; o.x = pack_bf2(v[m][0], v[m][1]); o.y = pack_bf2(v[m][2], v[m][3]);
+                        *(uint2*)(dst + m * 4) = o;
+                    }
+            }
+        }
+    }
+    if (P.pool) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float sm = psum[m][r];
+                sm = row_sum16(sm);
+                if (p == 0) red[wv * 16 * MT + g * 4 * MT + m * 4 + r] = sm;
+            }
+        __syncthreads();
+        if (tid < 16 * MT) {
+            const float sm = red[tid] + red[16 * MT + tid] + red[2 * 16 * MT + tid] + red[3 * 16 * MT + tid];
+            const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
+            P.pool[((size_t)t * nblk + blk) * (16 * MT) + tid] = sm;
+        }
+    }
+}
+
+template <int MT, int CS>
+int launch_conv3_fast(const ConvK& K, int T, hipStream_t st) {
+    constexpr int TH = 8, TW = 32, NPB = CS / 8, PS = (NPB & 1) ? CS * 2 : CS * 2 + 16;
+    dim3 grid((K.wout + TW - 1) / TW, (K.hout + TH - 1) / TH, T);
+    const size_t lds = (size_t)(TH + 2) * (TW + 2) * PS + 4 * 16 * MT * sizeof(float);
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)conv3_fast_kernel<MT, CS, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return SN_ELAUNCH;
+    }
+    hipLaunchKernelGGL((conv3_fast_kernel<MT, CS, TH>), grid, dim3(256), lds, st, K);
+    return sn_check_launch();
+}
+
 template <int TH, int TW>
 int launch_conv(const ConvK& K, int mt, int T, hipStream_t st) {
     dim3 grid((K.wout + TW - 1) / TW, (K.hout + TH - 1) / TH, T);
@@ -260,7 +502,7 @@ int launch_conv(const ConvK& K, int mt, int T, hipStream_t st) {
     const size_t lds = (size_t)rh * rw * P.ps + ((P.ks * 16 + 15) & ~15) + 4 * 16 * mt * sizeof(float);
     if (lds > 160 * 1024) return SN_EINVAL;
 #define SN_CONV_CASE(M) case M: \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<M, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv_mfma_kernel<M, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH; \
         hipLaunchKernelGGL((conv_mfma_kernel<M, TH, TW>), grid, dim3(256), lds, st, P); break;
     switch (mt) {
         SN_CONV_CASE(1) SN_CONV_CASE(2) SN_CONV_CASE(3) SN_CONV_CASE(4) SN_CONV_CASE(5) SN_CONV_CASE(6)
@@ -503,6 +745,7 @@ int sn_conv2d(const sn_conv_desc* d, void* stream) {
     if (d->out_mode == 2 && (!d->sc || d->c_out > 4 * d->mt)) return SN_EINVAL;
     if (d->ks * 32 < d->k * d->k * d->n_in * d->cs_in) return SN_EINVAL;
     if (d->oscale && d->oscale_stride < 16 * d->mt) return SN_EINVAL;
+    if ((d->res || d->res2) && d->out_mode != 0) return SN_EINVAL;
     ConvK K;
     K.in0 = (const bf16_t*)d->in[0]; K.in1 = (const bf16_t*)d->in[1]; K.in2 = (const bf16_t*)d->in[2];
     K.n_in = d->n_in; K.cs = d->cs_in; K.cv = d->n_in * d->cs_in;
@@ -510,11 +753,25 @@ int sn_conv2d(const sn_conv_desc* d, void* stream) {
     K.hout = d->h_out; K.wout = d->w_out;
     K.wfrag = (const uint4*)d->wfrag; K.ks = d->ks; K.bias = d->bias; K.act = d->act; K.prelu = d->prelu;
     K.res = (const bf16_t*)d->res; K.out = (bf16_t*)d->out; K.cs_out = d->cs_out; K.out_mode = d->out_mode;
-    K.c_out = d->c_out; K.nchw_dtype = d->nchw_dtype; K.sc = d->sc; K.pool = d->pool; K.oscale = d->oscale; K.oscale_stride = d->oscale_stride;
+    K.c_out = d->c_out; K.nchw_dtype = d->nchw_dtype; K.sc = d->sc; K.pool = d->pool; K.oscale = d->oscale; K.oscale_stride = d->oscale_stride; K.res2 = (const bf16_t*)d->res2;
     const int blocks = K.cv >> 3;
     K.ps = (blocks & 1) ? K.cv * 2 : K.cv * 2 + 16;
     K.rh = K.rw = 0;
     int th, tw; conv_tile(d, &th, &tw);
+    if (d->k == 3 && d->stride == 1 && d->pad == 1 && d->n_in == 1 && d->in_mode == 0 && d->out_mode == 0 && d->ks == (9 * d->cs_in + 31) / 32) {
+        // the specialised 3x3 path (same tile shape: sn_conv_pool_blocks is unchanged)
+        hipStream_t st = (hipStream_t)stream;
+        const int key = d->mt * 1000 + d->cs_in;
+        switch (key) {
+            case 1016: return launch_conv3_fast<1, 16>(K, d->T, st);
+            case 2024: return launch_conv3_fast<2, 24>(K, d->T, st);
+            case 4064: return launch_conv3_fast<4, 64>(K, d->T, st);
+            case 3040: return launch_conv3_fast<3, 40>(K, d->T, st);
+            case 3048: return launch_conv3_fast<3, 48>(K, d->T, st);
+            case 5080: return launch_conv3_fast<5, 80>(K, d->T, st);
+            default: break;                       // any other width: the generic kernel below
+        }
+    }
     if (th == 16) return launch_conv<16, 32>(K, d->mt, d->T, (hipStream_t)stream);
     if (th == 8) return launch_conv<8, 32>(K, d->mt, d->T, (hipStream_t)stream);
     return launch_conv<4, 16>(K, d->mt, d->T, (hipStream_t)stream);

@@ -62,19 +62,32 @@ class GShiftNetBase(nn.Module):
         mod.register_parameter(parts[-1], p)
 
     # ------------------------------------------------------------------------------------------------------
-    def _signature(self) -> Tuple:
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+    # The device weight plan is rebuilt only when the parameters can have changed: nn.Module funnels .to()/.half()/.cuda()
+    # through _apply and checkpoint loading through load_state_dict, so both drop the plan (no per-forward walk over the
+    # ~2000 parameters).  Code that edits parameters in place must call invalidate_plan() itself.
+    def invalidate_plan(self) -> None:
+        self._plan = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self._plan = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._plan = None
+        return super().load_state_dict(*args, **kwargs)
 
     def prepare(self):
-        """(Re)build the device weight plan if any parameter changed since the last call."""
-        from .engine import Engine, Plan
-        dev = next(self.parameters()).device
+        """Build the device weight plan on first use after a load / dtype / device change."""
+        from .engine import make_engine
+        p0 = next(self.parameters())
+        dev = p0.device
         if dev.type != "cuda":
             raise RuntimeError("GShiftNet runs on the MI355X HIP kernels only: move the module to a HIP ('cuda') device. "
                                "There is no CPU fallback.")
-        sig = (dev, self._signature())
+        sig = (dev, p0.dtype)
         if self._plan is None or self._plan_sig != sig:
-            self._plan = Engine(Plan(self.V, self.state_dict(), dev))
+            with torch.cuda.device(dev):
+                self._plan = make_engine(self.V, self.state_dict(), dev, p0.dtype)
             self._plan_sig = sig
         return self._plan
 

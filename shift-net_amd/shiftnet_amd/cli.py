@@ -4,7 +4,10 @@ Same flags, directory layout, window arithmetic, metric definitions and log line
 (test_deblur.py:91-177,271-291 ; test_denoise.py:91-232,318-351), plus:
   --synthetic H W N   run on an in-memory synthetic clip (no dataset ships with the reference, none can be fetched here)
   --checkpoint PATH   override the checkpoint; 'synthetic' uses the deterministic synthetic weights
-  --dtype {fp16,bf16,fp32}  I/O dtype of the module (upstream: fp16 except the "+" denoiser); kernels store bf16 either way
+  --dtype {fp16,bf16,fp32}  dtype of the module (upstream: fp16 except the "+" denoiser, which stays float32): fp16 / bf16
+                      modules run the bf16-storage MFMA kernels, fp32 modules the fp32 kernels (engine32.py)
+  --host_io           convert uint8 <-> float on the host exactly like upstream (default: on the device, csrc/sn_io.hip:
+                      same values bit for bit, 3 instead of 12 bytes per pixel over PCIe, PSNR sums reduced on the GPU)
 Image I/O uses PIL (imageio / cv2 / skimage are not in this image); PSNR / SSIM restate the upstream formulas.
 """
 from __future__ import annotations
@@ -22,6 +25,7 @@ import torch
 from . import synth
 from .arch import CLASSES
 from .clip_parallel import window_ranges
+from .io_edges import egress_u8, ingest_u8
 from .weights import synth_state_dict
 
 DTYPES = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}
@@ -45,7 +49,8 @@ def read_image(path: str) -> np.ndarray:
 
 def write_image(path: str, img_rgb_float: np.ndarray) -> None:
     from PIL import Image
-    Image.fromarray(np.clip(img_rgb_float, 0, 255).astype(np.uint8)).save(path)      # cv2.imwrite truncates floats
+    # cv2.imwrite converts float arrays with saturate_cast<uchar> = round to nearest (half to even), not truncation
+    Image.fromarray(np.rint(np.clip(img_rgb_float, 0, 255)).astype(np.uint8)).save(path)
 
 
 def psnr_255(img: np.ndarray, gt: np.ndarray) -> float:
@@ -161,28 +166,43 @@ class Inference:
                 nh, nw = h - h % 4, w - w % 4
                 inputs = [im[:nh, :nw] for im in inputs]
                 gtf = [im[:nh, :nw] for im in gtf]
-                x = numpy2tensor(inputs)
                 name = os.path.basename(ins[start + 2]).split(".")[0] if isinstance(ins[start + 2], str) else "%05d" % (start + 2)
+                dev_io = not a.host_io and not self.denoise       # (the denoise CLI draws its noise on the host, test_denoise.py:145-147)
                 if self.denoise:
+                    x = numpy2tensor(inputs)
                     sigma = a.sigma / 255.0
                     x = x + torch.empty_like(x).normal_(mean=0, std=sigma)
                     x = x.to("cuda").to(self.dtype)
                     t1 = time.time()
                     output = quadrant_forward(self.net, x, sigma)
+                elif dev_io:
+                    x = ingest_u8(torch.from_numpy(np.stack(inputs)).to("cuda"), self.dtype)
+                    t1 = time.time()
+                    output = self.net(x)
                 else:
-                    x = x.to("cuda").to(self.dtype)
+                    x = numpy2tensor(inputs).to("cuda").to(self.dtype)
                     t1 = time.time()
                     output = self.net(x).float()
                 torch.cuda.synchronize()
                 t2 = time.time()
                 psnr = ssim = float("nan")
+                img_u8 = psnrs = None
+                if dev_io:      # clamp * 255, rounding and the PSNR sums on the device; SSIM (Gaussian statistics) stays on the host
+                    img_u8, psnrs = egress_u8(output, torch.from_numpy(np.stack(gtf)).to("cuda"), want_image=a.save_image)
+                    img_u8 = img_u8.cpu().numpy() if img_u8 is not None else None
+                    output = output.float()
                 for e in range(n_out):
                     img = output[e].clamp(0, 1.0).permute(1, 2, 0).cpu().numpy() * 255
-                    psnr, ssim = psnr_255(img, gtf[e]), ssim_calculate(img, gtf[e])
+                    psnr = psnrs[e] if psnrs is not None else psnr_255(img, gtf[e])
+                    ssim = ssim_calculate(img, gtf[e])
                     vp.append(psnr); vs.append(ssim)
                     if a.save_image:
                         os.makedirs(os.path.join(self.result_path, v), exist_ok=True)
-                        write_image(os.path.join(self.result_path, v, "%03d.png" % index), img)
+                        if img_u8 is not None:
+                            from PIL import Image
+                            Image.fromarray(img_u8[e]).save(os.path.join(self.result_path, v, "%03d.png" % index))
+                        else:
+                            write_image(os.path.join(self.result_path, v, "%03d.png" % index), img)
                     index += 1
                 t3 = time.time()
                 del output, x
@@ -192,14 +212,17 @@ class Inference:
                     .format(v, name, psnr, ssim, t1 - t0, t2 - t1, t3 - t2, t3 - t0))
             if vp:
                 total_psnr[v], total_ssim[v] = vp, vs
-        sp = ss = 0.0
-        n = 0
+        sp = ss = sp2 = ss2 = 0.0
+        n = n2 = 0
         for k in total_psnr:
             self.logger.write_log("# Video:{} AVG-PSNR={:.5}, AVG-SSIM={:.4}".format(
                 k, sum(total_psnr[k]) / len(total_psnr[k]), sum(total_ssim[k]) / len(total_ssim[k])))
             sp += sum(total_psnr[k]); ss += sum(total_ssim[k]); n += len(total_psnr[k])
+            sp2 += sum(total_psnr[k]) / len(total_psnr[k]); ss2 += sum(total_ssim[k]) / len(total_ssim[k]); n2 += 1
         if n:
             self.logger.write_log("# Total AVG-PSNR={:.5}, AVG-SSIM={:.4}".format(sp / n, ss / n))
+            if self.denoise:       # the denoise CLIs also log the mean of the per-video means (test_denoise.py:222-223)
+                self.logger.write_log("# Total AVG-PSNR={:.5}, AVG-SSIM={:.4}".format(sp2 / n2, ss2 / n2))
         return (sp / n, ss / n) if n else (float("nan"), float("nan"))
 
 
@@ -219,6 +242,7 @@ def main(variant: str, argv: Optional[Sequence[str]] = None) -> Tuple[float, flo
     ap.add_argument("--checkpoint", type=str, default=None)
     ap.add_argument("--dtype", choices=list(DTYPES), default="fp32" if variant == "gshift_denoise1" else "fp16")
     ap.add_argument("--result_path", type=str, default=None)
+    ap.add_argument("--host_io", action="store_true", help="uint8<->float conversion and PSNR on the host, as upstream")
     a = ap.parse_args(argv)
     sfx = "_small" if small else ""
     a.data_path, a.model_path, rp = ".", "synthetic" if a.synthetic else "", "infer_results/synthetic"

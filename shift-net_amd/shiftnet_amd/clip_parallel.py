@@ -25,11 +25,12 @@ def assemble_window(own: torch.Tensor, first_edge: Optional[torch.Tensor], last_
                     rank: int = 0, world: int = 1, group=None) -> torch.Tensor:
     """own:[L,3,H,W] -> this rank's input window [L+4,3,H,W].
 
-    ``first_edge`` ([2,3,H,W]) is required on rank 0, ``last_edge`` on rank world-1.  With world == 1 there is no
-    communication at all.
+    ``first_edge`` ([2,3,H,W]) is required on rank 0, ``last_edge`` on rank world-1.  Without a process group (plain
+    single-GPU run) there is no communication at all.
     """
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return torch.cat((first_edge, own, last_edge), 0)
+    # (a one-rank process group still goes through the collective: the RCCL path is exercised on a single-GPU box too)
     send = torch.cat((own[:2], own[-2:]), 0).contiguous()
     bufs = [torch.empty_like(send) for _ in range(world)]
     dist.all_gather(bufs, send, group=group)

@@ -185,8 +185,11 @@ class Plan:
 
 
 class Engine:
-    def __init__(self, plan: Plan) -> None:
+    """bf16-storage engine (fp16 / bf16 modules).  fp32 modules run on engine32.Engine32 (same control flow, fp32 kernels)."""
+
+    def __init__(self, plan: Plan, dtype: torch.dtype = torch.bfloat16) -> None:
         self.P = plan
+        self.dtype = dtype
         self.V = plan.V
         self.lib = L.load()
         self.dev = plan.device
@@ -216,7 +219,7 @@ class Engine:
 
     def conv(self, name: str, ins: Sequence[Act], *, stride: int = 1, pad: Optional[int] = None, prelu: Optional[float] = None,
              res: Optional[Act] = None, out_mode: int = 0, pool: bool = False, in_mode: int = 0, oscale: Optional[torch.Tensor] = None,
-             nchw_out: Optional[torch.Tensor] = None, nchw_sc: Optional[torch.Tensor] = None):
+             nchw_out: Optional[torch.Tensor] = None, nchw_sc: Optional[torch.Tensor] = None, res2: Optional[Act] = None):
         p = self.P.convs[name]
         k, cout = int(p["k"]), int(p["cout"])
         T, hs, ws, cs_in = ins[0].dims
@@ -250,6 +253,9 @@ class Engine:
         if res is not None:
             assert out_mode == 0 and res.dims == out_act.dims
             d.res = res.t.data_ptr()
+        if res2 is not None:
+            assert out_mode == 0 and res2.dims == out_act.dims
+            d.res2 = res2.t.data_ptr()
         if oscale is not None:
             d.oscale, d.oscale_stride = oscale.data_ptr(), oscale.shape[1]
         if pool:
@@ -270,7 +276,8 @@ class Engine:
                                    p["wb"].data_ptr(), ca.data_ptr(), T, self._stream())
         return ca
 
-    def scale_residual(self, r: Act, x: Act, ca: torch.Tensor) -> Act:
+    def scale_residual(self, r: Act, x: Act, ca: torch.Tensor, extra: Optional[Act] = None) -> Act:
+        assert extra is None, "the bf16 CAB tail with a second residual goes through the conv epilogue (cab_v >= 1)"
         T, h, w, cs = r.dims
         o = self._new(T, h, w, cs)
         self._meta = ("ew", T, h, w, cs)
@@ -279,7 +286,7 @@ class Engine:
         return Act(o, r.c)
 
     # ---- blocks (oracle/shiftnet_oracle.py has the same names) ----------------------------------------------
-    def cab(self, pre: str, x: Act) -> Act:
+    def cab(self, pre: str, x: Act, extra: Optional[Act] = None) -> Act:
         """CAB: 3x3 -> PReLU -> 3x3 -> CALayer -> +x (gshift_deblur1.py:141-156).
 
         cab_v 1: the CALayer scale is known BEFORE the second conv (its pooled input is linear in `mid`, sn_cab_ca), so
@@ -293,10 +300,10 @@ class Engine:
             scratch = torch.empty((self.lib.sn_cab_ca_scratch_floats(T),), dtype=torch.float32, device=self.dev)
             self._call("sn_cab_ca", f"sn_cab_ca[{pre}]", pool.data_ptr(), nblk, cpad, mid.t.data_ptr(), cs, p["c"], p["cr"], h, w,
                        p["w2"].data_ptr(), p["wa"].data_ptr(), p["wb"].data_ptr(), scratch.data_ptr(), ca.data_ptr(), T, self._stream())
-            return self.conv(pre + "body.2", [mid], res=x, oscale=ca)
+            return self.conv(pre + "body.2", [mid], res=x, oscale=ca, res2=extra)
         r = self.conv(pre + "body.0", [x], prelu=self.P.scalar(pre + "body.1.weight"))
         r, pool, npix = self.conv(pre + "body.2", [r], pool=True)
-        return self.scale_residual(r, x, self.ca_mlp(pre + "CA", pool, npix))
+        return self.scale_residual(r, x, self.ca_mlp(pre + "CA", pool, npix), extra)
 
     def _unit_src(self, x: Act, mode: int) -> L.UnitSrc:
         T, h, w, cs = x.dims
@@ -421,11 +428,12 @@ class Engine:
         """SkipUpSample: bilinear x2 -> 1x1 -> + y (gshift_deblur1.py:341-350), upsample fused into the conv loader."""
         return self.conv(name, [x], in_mode=1, res=y)
 
-    def tfr_unet(self, pre: str, x: Act) -> Act:
-        """TFR_UNet.forward (gshift_deblur1.py:709-722)."""
-        def seq(nm: str, n: int, t: Act) -> Act:
+    def tfr_unet(self, pre: str, x: Act, extra: Optional[Act] = None) -> Act:
+        """TFR_UNet.forward (gshift_deblur1.py:709-722).  `extra` is added to the result in the epilogue of the last CAB's
+        second conv: the "+ shortcut" that follows the last orb / rorb (:769,779) costs no pass of its own."""
+        def seq(nm: str, n: int, t: Act, ex: Optional[Act] = None) -> Act:
             for i in range(n):
-                t = self.cab(f"{pre}{nm}.{i}.", t)
+                t = self.cab(f"{pre}{nm}.{i}.", t, ex if i == n - 1 else None)
             return t
         enc1 = seq("encoder_level1", 1, x)
         enc2 = seq("encoder_level2", 3, self.down(pre + "down12.", enc1))
@@ -434,7 +442,7 @@ class Engine:
         t = self.skip_up(pre + "up32", dec3, self.cab(pre + "skip_attn2.", enc2))
         dec2 = seq("decoder_level2", 3, t)
         t = self.skip_up(pre + "up21", dec2, self.cab(pre + "skip_attn1.", enc1))
-        return seq("decoder_level1", 1, t)
+        return seq("decoder_level1", 1, t, extra)
 
     def stage1(self, x: Act) -> Act:
         """Encoder2.forward (gshift_deblur1.py:613-642, gshift_deblur2.py:587-613, gshift_denoise1.py:640-670)."""
@@ -480,9 +488,24 @@ class Engine:
             out = self.conv(p + "conv_hr0", [up], res=skip)
         return self.cab(p + "out_conv.", out)
 
+    def _ingest(self, x: torch.Tensor, noise_map: Optional[torch.Tensor]) -> Act:
+        """x = x[0]; cat((x, noise_map), 1) into the kernel layout (gshift_deblur1.py:784-787, gshift_denoise1.py:828-831)."""
+        T, cin, H, W = x.shape
+        nm_ptr = None
+        if self.V.denoise:
+            noise_map = noise_map.to(x.dtype).expand(T, 1, H, W).contiguous()
+            nm_ptr = noise_map.data_ptr()
+        x8 = self._new(T, H, W, 8)
+        self._call("sn_ingest", "sn_ingest", x.data_ptr(), _dtype_code(x.dtype), nm_ptr, x8.data_ptr(), T, cin, H, W, self._stream())
+        return Act(x8, self.V.in_ch)
+
     @torch.no_grad()
     def forward(self, x: torch.Tensor, noise_map: Optional[torch.Tensor], past: int, future: int) -> torch.Tensor:
         """GShiftNet.forward; x:[T,C,H,W] (already x[0]) on this engine's device, any of fp32/fp16/bf16."""
+        with torch.cuda.device(self.dev):      # launches, events and allocations all belong to the engine's device
+            return self._forward(x, noise_map, past, future)
+
+    def _forward(self, x: torch.Tensor, noise_map: Optional[torch.Tensor], past: int, future: int) -> torch.Tensor:
         V = self.V
         x = x.contiguous()
         T, cin, H, W = x.shape
@@ -493,21 +516,11 @@ class Engine:
         out = torch.empty((n_out, 3, H, W), dtype=x.dtype, device=x.device)
         if n_out == 0:
             return out                      # T <= past+future yields an empty tensor upstream as well
-        nm_ptr = None
-        if V.denoise:
-            noise_map = noise_map.to(x.dtype).expand(T, 1, H, W).contiguous()
-            nm_ptr = noise_map.data_ptr()
-        x8 = self._new(T, H, W, 8)
-        self._call("sn_ingest", "sn_ingest", x.data_ptr(), _dtype_code(x.dtype), nm_ptr, x8.data_ptr(), T, cin, H, W, self._stream())
-        x0 = self.cab("feat_extract.1.", self.conv("feat_extract.0", [Act(x8, V.in_ch)]))
+        x0 = self.cab("feat_extract.1.", self.conv("feat_extract.0", [self._ingest(x, noise_map)]))
         t = x0
-        for i in range(1, V.n_orb + 1):
-            t = self.tfr_unet(f"orb{i}.", t)
-        if V.denoise:
-            res0 = t
-        else:           # res0 = orbN(..) + shortcut (gshift_deblur1.py:769)
-            ones = torch.ones((T, 16 * 6), dtype=torch.float32, device=self.dev)
-            res0 = self.scale_residual(t, x0, ones)
+        for i in range(1, V.n_orb + 1):     # deblur: res0 = orbN(..) + shortcut (gshift_deblur1.py:769), folded into the last CAB
+            t = self.tfr_unet(f"orb{i}.", t, x0 if (i == V.n_orb and not V.denoise) else None)
+        res0 = t
         sam = self.conv("conv_trans", [res0])
         dec = self.stage1(sam)
         lo, hi = past, T - future
@@ -517,10 +530,16 @@ class Engine:
             return Act(a.t[lo:hi], a.c)
         y = self.conv("rconcat", [cut(x0), cut(feats), cut(dec)], prelu=self.P.scalar("lrelu.weight") if V.denoise else None)
         sc = y
-        for i in range(1, V.n_orb + 1):
-            y = self.tfr_unet(f"rorb{i}.", y)
-        if not V.denoise:
-            ones = torch.ones((n_out, 16 * 6), dtype=torch.float32, device=self.dev)
-            y = self.scale_residual(y, sc, ones)
+        for i in range(1, V.n_orb + 1):     # deblur: "+ shortcut" after the last rorb (:779), same folding
+            y = self.tfr_unet(f"rorb{i}.", y, sc if (i == V.n_orb and not V.denoise) else None)
         self.conv("conv_last", [y], out_mode=2, nchw_out=out, nchw_sc=x[lo:hi].contiguous())
         return out
+
+
+def make_engine(V: Variant, sd: Dict[str, torch.Tensor], device: torch.device, dtype: torch.dtype):
+    """Engine for a module of `dtype`: fp32 modules compute in fp32 end to end (what upstream's denoise CLI does for the
+    "+" model, inference/test_denoise.py:83-85); fp16 / bf16 modules run the bf16-storage MFMA kernels."""
+    if dtype == torch.float32:
+        from .engine32 import Engine32, Plan32
+        return Engine32(Plan32(V, sd, device))
+    return Engine(Plan(V, sd, device), dtype)

@@ -1,0 +1,217 @@
+"""fp32 engine: GShiftNet.forward with fp32 activations and the checkpoint's fp32 weights (csrc/sn_f32.hip).
+
+Why it exists
+  * upstream runs the "+" denoiser in float32 (inference/test_denoise.py:83-85: ``.half()`` is commented out), so a
+    float32 module must compute in float32, not in bf16 behind a cast;
+  * it is the validation build of the engine: ``Engine32`` inherits the whole control flow of ``engine.Engine``
+    (stage 0 / 1 / 2, TFR_UNet, shift blocks, unit directions, frame trimming) and replaces only the leaf operators, so
+    agreement with the CPU oracle to fp32 round-off (tests: <= 1e-4 of the tensor scale) pins that control flow and the
+    weight bookkeeping independently of bf16 rounding noise.
+
+Leaf operators follow the reference modules one to one (no fusion, no repacking beyond a weight transpose); every
+activation is NHWC fp32 ``[T, H, W, C]`` with C the logical channel count.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from . import lib as L
+from . import prep
+from .engine import Act, Engine, Plan, _dtype_code
+from .spec import Variant, shift_table
+
+
+class Plan32(Plan):
+    """fp32 weights on the device in natural (checkpoint) order; convs are looked up by the same names as in ``Plan``."""
+
+    def __init__(self, V: Variant, sd: Dict[str, torch.Tensor], device: torch.device) -> None:
+        self.V = V
+        self.device = device
+        self.sd = {k: v.detach().float().cpu() for k, v in sd.items()}
+        self.dsd = {k: v.to(device) for k, v in self.sd.items()}
+        self.convs: Dict[str, Dict[str, object]] = {}
+        self.cas: Dict[str, Dict[str, object]] = {}
+        self.units: Dict[str, Dict[str, object]] = {}
+        self._wt: Dict[str, torch.Tensor] = {}
+        self.offs = prep.shift_offsets_i8(shift_table(V.c1)).to(device)
+        self._build()
+
+    def add_conv(self, name: str, key: str, cins: Sequence[int], weight: Optional[torch.Tensor] = None) -> None:
+        if weight is None:                       # (the packed block-diagonal copy of the grouped RepConv is a bf16-path artefact)
+            self.convs[name] = {"key": key, "cins": list(cins)}
+
+    def add_cab(self, pre: str, c: int) -> None:
+        self.add_conv(pre + "body.0", pre + "body.0.", [c])
+        self.add_conv(pre + "body.2", pre + "body.2.", [c])
+        self.add_ca(pre + "CA", pre + "CA.")
+
+    def add_naf(self, pre: str, c: int, with_shift: bool) -> None:
+        i = 2                                    # body.0 1x1, body.1 RepConv2, (SimpleGate has no entry in the checkpoint)
+        i += 1
+        if self.V.denoise:
+            self.add_ca(f"{pre}ca1", f"{pre}body.{i}."); i += 1
+        rep = i; i += 1
+        gate = i; i += 2
+        self.add_ca(f"{pre}ca2", f"{pre}body.{i}."); i += 1
+        self.units[pre] = {"rep": rep, "gate": gate, "out": i}
+
+    def wt(self, key: str) -> torch.Tensor:
+        """conv weight [co][ci/g][k][k] -> [k][k][ci/g][co] (consecutive lanes read consecutive output channels)."""
+        if key not in self._wt:
+            self._wt[key] = self.dsd[key].permute(2, 3, 1, 0).contiguous()
+        return self._wt[key]
+
+
+class Engine32(Engine):
+    def __init__(self, plan: Plan32) -> None:
+        super().__init__(plan, torch.float32)
+        self.cab_v = 0
+
+    def _new(self, T: int, h: int, w: int, cs: int) -> torch.Tensor:
+        return torch.empty((T, h, w, cs), dtype=torch.float32, device=self.dev)
+
+    # ---- leaf operators ------------------------------------------------------------------------------------
+    def _conv32(self, wkey: str, bkey: Optional[str], ins: Sequence[torch.Tensor], cins: Sequence[int], *, k: int, stride: int = 1,
+                pad: Optional[int] = None, groups: int = 1, prelu: Optional[float] = None, res: Optional[torch.Tensor] = None,
+                oscale: Optional[torch.Tensor] = None, oscale_stride: int = 0, out: Optional[torch.Tensor] = None, out_mode: int = 0,
+                in_mode: int = 0, c_out: Optional[int] = None, nchw_out: Optional[torch.Tensor] = None,
+                nchw_sc: Optional[torch.Tensor] = None, label: str = "") -> torch.Tensor:
+        """ins: NHWC fp32 tensors (possibly channel-slice views of wider tensors: the pixel stride is taken from .stride(2))."""
+        P = self.P
+        w = P.wt(wkey)
+        T, hs, ws = ins[0].shape[:3]
+        h_in, w_in = (2 * hs, 2 * ws) if in_mode == 1 else (hs, ws)
+        if pad is None:
+            pad = k // 2
+        h_out = (h_in + 2 * pad - k) // stride + 1
+        w_out = (w_in + 2 * pad - k) // stride + 1
+        co = int(w.shape[3]) if c_out is None else c_out
+        d = L.Conv32Desc()
+        for i, (t, c) in enumerate(zip(ins, cins)):
+            assert t.dtype == torch.float32 and t.stride(3) == 1 and t.stride(1) == t.shape[2] * t.stride(2)
+            d.inp[i], d.c_in[i], d.cs_in[i] = t.data_ptr(), c, t.stride(2)
+        d.n_in, d.T, d.h_in, d.w_in, d.in_mode = len(ins), T, h_in, w_in, in_mode
+        d.k, d.stride, d.pad, d.groups, d.h_out, d.w_out, d.c_out = k, stride, pad, groups, h_out, w_out, co
+        d.w = w.data_ptr()
+        d.bias = P.dsd[bkey].data_ptr() if bkey is not None and bkey in P.dsd else None
+        d.act, d.prelu = (1, prelu) if prelu is not None else (0, 0.0)
+        if oscale is not None:
+            d.oscale, d.oscale_stride = oscale.data_ptr(), oscale_stride
+        if res is not None:
+            d.res, d.cs_res = res.data_ptr(), res.stride(2)
+        if out_mode == 2:
+            d.out, d.sc, d.nchw_dtype, d.cs_out = nchw_out.data_ptr(), nchw_sc.data_ptr(), _dtype_code(nchw_out.dtype), 0
+            o = nchw_out
+        else:
+            if out is None:
+                out = self._new(T, 2 * h_out, 2 * w_out, co // 4) if out_mode == 1 else self._new(T, h_out, w_out, co)
+            d.out, d.cs_out = out.data_ptr(), out.stride(2)
+            o = out
+        d.out_mode = out_mode
+        self._meta = ("conv32", T, h_out, w_out, sum(cins), co, k, stride, in_mode, out_mode)
+        self._call("sn32_conv2d", f"sn32_conv2d[{label or wkey}]", C.byref(d), self._stream())
+        return o
+
+    def conv(self, name: str, ins: Sequence[Act], *, stride: int = 1, pad: Optional[int] = None, prelu: Optional[float] = None,
+             res: Optional[Act] = None, out_mode: int = 0, pool: bool = False, in_mode: int = 0, oscale: Optional[torch.Tensor] = None,
+             nchw_out: Optional[torch.Tensor] = None, nchw_sc: Optional[torch.Tensor] = None, res2: Optional[Act] = None):
+        p = self.P.convs[name]
+        key = p["key"]
+        k = int(self.P.sd[key + "weight"].shape[-1])
+        assert oscale is None and res2 is None
+        o = self._conv32(key + "weight", key + "bias", [a.t for a in ins], [a.c for a in ins], k=k, stride=stride, pad=pad,
+                         prelu=prelu, res=res.t if res is not None else None, out_mode=out_mode, in_mode=in_mode,
+                         nchw_out=nchw_out, nchw_sc=nchw_sc, label=name)
+        if out_mode == 2:
+            return None
+        a = Act(o, o.shape[3])
+        if pool:
+            T, h, w, c = o.shape
+            return a, self._chan_sum(o), h * w
+        return a
+
+    def _chan_sum(self, x: torch.Tensor) -> torch.Tensor:
+        T, h, w, c = x.shape
+        cpad = max(16, prep.ceil8(c))
+        nblk = 64
+        part = torch.empty((T, nblk, cpad), dtype=torch.float32, device=self.dev)
+        self._call("sn32_chan_sum", "sn32_chan_sum", x.data_ptr(), x.stride(2), c, cpad, T, h * w, nblk, part.data_ptr(), self._stream())
+        return part
+
+    def scale_residual(self, r: Act, x: Optional[Act], ca: torch.Tensor, extra: Optional[Act] = None) -> Act:
+        T, h, w, c = r.dims
+        o = self._new(T, h, w, c)
+        self._call("sn32_scale_residual", "sn32_scale_residual", r.t.data_ptr(), x.t.data_ptr() if x is not None else None, ca.data_ptr(),
+                   ca.shape[1], o.data_ptr(), T, h * w, c, self._stream())
+        if extra is not None:                     # "+ shortcut" after the last TFR_UNet of a stage (gshift_deblur1.py:769,779)
+            ones = torch.ones((T, c), dtype=torch.float32, device=self.dev)
+            o2 = self._new(T, h, w, c)
+            self._call("sn32_scale_residual", "sn32_add", o.data_ptr(), extra.t.data_ptr(), ones.data_ptr(), c, o2.data_ptr(), T, h * w, c,
+                       self._stream())
+            o = o2
+        return Act(o, c)
+
+    def temporal_roll(self, x: Act, reverse: bool) -> Act:
+        T, h, w, c = x.dims
+        y = self._new(T, h, w, c)
+        s = L.UnitSrc(x.t.data_ptr(), T, h, w, c, 2 if reverse else 1, 0)
+        self._call("sn32_gsts_gather", "sn32_temporal_roll", C.byref(s), None, y.data_ptr(), self._stream())
+        return Act(y, c)
+
+    def _ca(self, name: str, g: torch.Tensor) -> torch.Tensor:
+        T, h, w, _ = g.shape
+        return self.ca_mlp(name, self._chan_sum(g), h * w)
+
+    def naf(self, pre: str, x: Act, mode: int) -> Act:
+        """CAB2 (mode 1/2) / CAB1 (mode 0), operator by operator as the reference module lists them (gshift_deblur1.py:183-255)."""
+        P, V, st = self.P, self.V, self._stream()
+        T, h, w, c = x.dims
+        npix = T * h * w
+        u = P.units[pre]
+        dsd = P.dsd
+        self._meta = ("naf32", T, h, w, c, mode)
+        if mode:
+            ug = self._new(T, h, w, c + c // 2)                                   # cat(roll(x), spatial_shift2(borrowed half))
+            s = L.UnitSrc(x.t.data_ptr(), T, h, w, c, mode, 1 if V.wrap else 0)
+            self._call("sn32_gsts_gather", "sn32_gsts_gather", C.byref(s), P.offs.data_ptr(), ug.data_ptr(), st)
+            shortcut = ug[..., :c]
+            vin = self._new(T, h, w, c + c // 2)                                  # cat(shortcut, conv1(shifted)): a second gather fills
+            self._call("sn32_gsts_gather", "sn32_gsts_gather", C.byref(s), P.offs.data_ptr(), vin.data_ptr(), st)   # [:c], conv1 overwrites [c:]
+            self._conv32(pre + "conv1.weight", None, [ug[..., c:]], [c // 2], k=3, groups=c // 2, out=vin[..., c:])
+            kk = c + c // 2
+        else:
+            shortcut, vin, kk = x.t, x.t, c
+        v = self._new(T, h, w, kk)
+        self._call("sn32_layernorm", "sn32_layernorm", vin.data_ptr(), vin.stride(2), kk, dsd[pre + "norm.weight"].data_ptr(),
+                   dsd[pre + "norm.bias"].data_ptr(), v.data_ptr(), kk, npix, st)
+        a = self._conv32(pre + "body.0.weight", None, [v], [kk], k=1)                                             # 1x1 -> 2C
+        a = self._conv32(pre + "body.1.conv_2.weight", None, [a], [2 * c], k=3, groups=2 * c, res=a)              # RepConv2
+        g1 = self._new(T, h, w, c)
+        self._call("sn32_gate", "sn32_gate", a.data_ptr(), c, 0, g1.data_ptr(), npix, st)                         # SimpleGate
+        if V.denoise:                                                                                               # CALayer2 on g1
+            g1 = self.scale_residual(Act(g1, c), None, self._ca(f"{pre}ca1", g1)).t
+        grp = c // 8 if V.grouped_rep else c
+        rp = f"{pre}body.{u['rep']}."
+        r = self._conv32(rp + "conv_1.weight", None, [g1], [c], k=5, groups=grp, res=g1)                           # RepConv: 5x5 + id
+        r = self._conv32(rp + "conv_2.weight", None, [g1], [c], k=3, groups=grp, res=r)                            #          + 3x3
+        b = self._conv32(f"{pre}body.{u['gate']}.weight", None, [r], [c], k=1)                                     # 1x1 -> 2C
+        g2 = self._new(T, h, w, c)
+        self._call("sn32_gate", "sn32_gate", b.data_ptr(), c, 1, g2.data_ptr(), npix, st)                         # SimpleGate2
+        g2 = self.scale_residual(Act(g2, c), None, self._ca(f"{pre}ca2", g2)).t                                    # CALayer2
+        ok = f"{pre}body.{u['out']}."
+        beta = dsd[pre + "beta"].reshape(1, c)
+        y = self._conv32(ok + "weight", ok + "bias", [g2], [c], k=1, oscale=beta, oscale_stride=0, res=shortcut)  # shortcut + res * beta
+        return Act(y, c)
+
+    def _ingest(self, x: torch.Tensor, noise_map: Optional[torch.Tensor]) -> Act:
+        T, cin, H, W = x.shape
+        nm_ptr = None
+        if self.V.denoise:
+            noise_map = noise_map.to(x.dtype).expand(T, 1, H, W).contiguous()
+            nm_ptr = noise_map.data_ptr()
+        xi = self._new(T, H, W, self.V.in_ch)
+        self._call("sn32_ingest", "sn32_ingest", x.data_ptr(), _dtype_code(x.dtype), nm_ptr, xi.data_ptr(), T, cin, H, W, self._stream())
+        return Act(xi, self.V.in_ch)

@@ -19,6 +19,8 @@ SYMBOLS = [
     "sn_abi_version", "sn_selftest_mfma", "sn_ingest", "sn_conv2d", "sn_conv_pool_blocks", "sn_ca_mlp",
     "sn_scale_residual", "sn_cab_ca", "sn_cab_ca_scratch_floats", "sn_planar_pitch", "sn_nhwc_to_planar", "sn_dw5m_blocks", "sn_dw5m_gemm_gate", "sn_lngatem_blocks", "sn_ln_gemm_gate_m", "sn_gsts_gather", "sn_temporal_roll", "sn_gsts_shiftconv", "sn_ln_gemm", "sn_dw_gate",
     "sn_dwgate_blocks", "sn_dw_gemm_gate", "sn_dwgemm_blocks", "sn_scale_gemm_res",
+    "sn_ingest_u8", "sn_egress_blocks", "sn_egress_u8",
+    "sn32_conv2d", "sn32_gsts_gather", "sn32_layernorm", "sn32_gate", "sn32_chan_sum", "sn32_scale_residual", "sn32_ingest",
     "sn_ln_gemm_gate", "sn_lngate_blocks", "sn_dw5_gemm_gate", "sn_dw5_blocks", "sn_debug_set", "sn_debug_get", "sn_debug_buf_set", "sn_debug_buf_get", "sn_grp5_gemm_gate", "sn_grp5_blocks",
 ]
 
@@ -31,7 +33,19 @@ class ConvDesc(C.Structure):
         ("wfrag", C.c_void_p), ("mt", C.c_int), ("ks", C.c_int), ("bias", C.c_void_p),
         ("act", C.c_int), ("prelu", C.c_float), ("res", C.c_void_p), ("out", C.c_void_p),
         ("cs_out", C.c_int), ("out_mode", C.c_int), ("c_out", C.c_int), ("nchw_dtype", C.c_int),
-        ("sc", C.c_void_p), ("pool", C.c_void_p), ("oscale", C.c_void_p), ("oscale_stride", C.c_int),
+        ("sc", C.c_void_p), ("pool", C.c_void_p), ("oscale", C.c_void_p), ("oscale_stride", C.c_int), ("res2", C.c_void_p),
+    ]
+
+
+class Conv32Desc(C.Structure):
+    _fields_ = [
+        ("inp", C.c_void_p * 3), ("c_in", C.c_int * 3), ("cs_in", C.c_int * 3), ("n_in", C.c_int),
+        ("T", C.c_int), ("h_in", C.c_int), ("w_in", C.c_int), ("in_mode", C.c_int),
+        ("k", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("groups", C.c_int),
+        ("h_out", C.c_int), ("w_out", C.c_int), ("c_out", C.c_int),
+        ("w", C.c_void_p), ("bias", C.c_void_p), ("act", C.c_int), ("prelu", C.c_float),
+        ("oscale", C.c_void_p), ("oscale_stride", C.c_int), ("res", C.c_void_p), ("cs_res", C.c_int),
+        ("out", C.c_void_p), ("cs_out", C.c_int), ("out_mode", C.c_int), ("nchw_dtype", C.c_int), ("sc", C.c_void_p),
     ]
 
 
@@ -98,6 +112,17 @@ def load() -> C.CDLL:
     lib.sn_grp5_blocks.argtypes = [ci, ci]
     lib.sn_dw5_gemm_gate.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.sn_scale_gemm_res.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp, vp]
+    lib.sn_ingest_u8.argtypes = [vp, vp, ci, ci, ci, ci, vp]
+    lib.sn_egress_blocks.argtypes = []
+    lib.sn_egress_u8.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci, vp]
+    ll = C.c_longlong
+    lib.sn32_conv2d.argtypes = [C.POINTER(Conv32Desc), vp]
+    lib.sn32_gsts_gather.argtypes = [C.POINTER(UnitSrc), vp, vp, vp]
+    lib.sn32_layernorm.argtypes = [vp, ci, ci, vp, vp, vp, ci, ll, vp]
+    lib.sn32_gate.argtypes = [vp, ci, ci, vp, ll, vp]
+    lib.sn32_chan_sum.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, vp]
+    lib.sn32_scale_residual.argtypes = [vp, vp, vp, ci, vp, ci, ci, ci, vp]
+    lib.sn32_ingest.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, vp]
     for s in SYMBOLS:
         getattr(lib, s).restype = ci
     lib.sn_debug_buf_get.restype = vp

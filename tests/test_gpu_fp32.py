@@ -1,0 +1,122 @@
+"""-m gpu: the fp32 engine (csrc/sn_f32.hip + shiftnet_amd/engine32.py) against the CPU oracle and the reference fixtures.
+
+fp32 storage, fp32 weights, fp32 FMA chains: the only differences from the oracle are summation order and the
+exp / rsqrt implementations, so the tolerance is max-abs <= 1e-4 * scale (SURVEY.md 8c "HIP fp32 vs oracle"), four
+orders of magnitude below what a wrong tap / slab / gate half / weight row would produce.  ``Engine32`` shares every line
+of control flow with the bf16 engine (it only overrides the leaf operators), so these tests pin the logic of both; they
+also are the float32 path upstream's denoise CLI uses for the "+" model (inference/test_denoise.py:83-85).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import shiftnet_oracle as O
+from shiftnet_amd import synth
+from shiftnet_amd.spec import VARIANTS
+from shiftnet_amd.weights import synth_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+TOL = 1e-4
+
+
+def to_dev(t_nchw):
+    return t_nchw.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def to_cpu(t_nhwc):
+    return t_nhwc.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def close(name, got, ref, tol=TOL):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = max(1.0, ref.abs().max().item())
+    err = (got - ref).abs().max().item()
+    assert np.isfinite(err) and err <= tol * scale, f"{name}: max-abs {err:.3g} > {tol} * {scale:.3g}"
+
+
+@pytest.fixture(scope="module")
+def engines():
+    from shiftnet_amd.engine import make_engine
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            sd = synth_state_dict(name)
+            cache[name] = (make_engine(VARIANTS[name], sd, DEV, torch.float32), sd)
+        return cache[name]
+    return get
+
+
+def act(t):
+    from shiftnet_amd.engine import Act
+    return Act(t, t.shape[3])
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_blocks_fp32(name, engines):
+    eng, sd = engines(name)
+    V = O.VARIANTS[name]
+    C, T, h, w = V.c1, 4, 20, 44
+    x = torch.from_numpy(synth.unit_noise((T, C, h, w), seed=81))
+    xd = act(to_dev(x))
+    blk = "stage1.decoder_level1."
+    with torch.no_grad():
+        for mode, rev, unit in ((1, False, "encoder_level1."), (2, True, "encoder_level1_1.")):
+            pre = blk + unit + "0."
+            close(f"cab2_{name}_{mode}", to_cpu(eng.naf(pre, xd, mode).t), O.cab2(sd, pre, O.gsts_gather(x, rev, V.wrap), V))
+        pre = blk + "encoder_level1.1."
+        close(f"cab1_{name}", to_cpu(eng.naf(pre, xd, 0).t), O.cab1(sd, pre, x, V))
+        close(f"unit_rev_{name}", to_cpu(eng.gsts_unit(blk + "encoder_level1_1.", xd, True).t), O.gsts_unit(sd, blk + "encoder_level1_1.", x, True, V))
+        close(f"shift_block_{name}", to_cpu(eng.shift_block(blk, xd).t), O.shift_block(sd, blk, x, V))
+        x2 = torch.from_numpy(synth.unit_noise((2, C, 13, 70), seed=82))
+        close(f"unit_fwd_ragged_{name}", to_cpu(eng.gsts_unit(blk + "encoder_level1.", act(to_dev(x2)), False).t),
+              O.gsts_unit(sd, blk + "encoder_level1.", x2, False, V))
+        x0 = torch.from_numpy(synth.unit_noise((3, V.c0, 24, 40), seed=91))
+        close(f"cab_{name}", to_cpu(eng.cab("stage1.concat.", act(to_dev(x0))).t), O.cab(sd, "stage1.concat.", x0))
+        close(f"tfr_unet_{name}", to_cpu(eng.tfr_unet("orb1.", act(to_dev(x0))).t), O.tfr_unet(sd, "orb1.", x0, V))
+        close(f"stage1_{name}", to_cpu(eng.stage1(act(to_dev(x0))).t), O.stage1(sd, x0, V))
+        if V.shift_cab:
+            close(f"shift_cab_{name}", to_cpu(eng.shift_cab("stage1.encoder_level1.", xd, True).t),
+                  O.shift_cab(sd, "stage1.encoder_level1.", x, True))
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_whole_net_fp32_vs_reference_fixture(name, golden_dir):
+    """float32 module through the drop-in class against the REFERENCE's fp32 output (tests/golden/net_*.npz)."""
+    import importlib
+    mod = importlib.import_module(f"basicsr.models.archs.{name}")
+    V = O.VARIANTS[name]
+    g = np.load(os.path.join(golden_dir, f"net_{name}.npz"))
+    blur, _ = synth.blurred_clip(7, 48, 64, seed=3)
+    assert synth.crc(blur) == int(g["in_crc"])
+    x = O.frames_to_tensor(list(blur))
+    net = mod.GShiftNet(future_frames=2, past_frames=2)
+    net.load_state_dict(synth_state_dict(name), strict=True)
+    net = net.to("cuda").eval()
+    assert next(net.parameters()).dtype == torch.float32
+    nm = torch.full((1, 7, 1, 48, 64), 30.0 / 255.0) if V.denoise else None
+    with torch.no_grad():
+        out = net(x.cuda(), nm.cuda()) if V.denoise else net(x.cuda())
+    assert out.dtype == torch.float32
+    close(f"net32_{name}", out, torch.from_numpy(g["p2f2"]))
+    from shiftnet_amd.engine32 import Engine32
+    assert isinstance(net.prepare(), Engine32)
+
+
+def test_config1_fp32(golden_dir):
+    """BASELINE config 1 (Shift-Net-s, fp32, 1 clip of T=5 256x256): the reference's CPU-runnable case, here on the GPU in fp32."""
+    from basicsr.models.archs.gshift_deblur2 import GShiftNet
+    name = "gshift_deblur2"
+    net = GShiftNet(future_frames=2, past_frames=2)
+    net.load_state_dict(synth_state_dict(name), strict=True)
+    net = net.cuda().eval()
+    g = np.load(os.path.join(golden_dir, f"config1_{name}.npz"))
+    blur, _ = synth.blurred_clip(5, 256, 256, seed=5)
+    assert synth.crc(blur) == int(g["in_crc"])
+    with torch.no_grad():
+        out = net(O.frames_to_tensor(list(blur)).cuda())
+    close("config1_fp32", out, torch.from_numpy(g["out"]))

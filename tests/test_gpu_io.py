@@ -1,0 +1,32 @@
+"""-m gpu: device-side I/O edges (csrc/sn_io.hip) against the host formulas of the CLI (which restate upstream's)."""
+import numpy as np
+import pytest
+import torch
+
+from shiftnet_amd import cli, synth
+from shiftnet_amd.io_edges import egress_u8, ingest_u8
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16, torch.float32])
+def test_ingest_u8_is_numpy2tensor_bit_for_bit(dt):
+    blur, _ = synth.blurred_clip(3, 36, 52, seed=31)
+    blur[0, 0, :256 // 52 + 1] = 0
+    blur[1].reshape(-1)[:256] = np.arange(256, dtype=np.uint8)          # every uint8 value occurs
+    ref = cli.numpy2tensor(list(blur)).to("cuda").to(dt)              # what upstream feeds the network (test_deblur.py:128,134)
+    got = ingest_u8(torch.from_numpy(blur).cuda(), dt)
+    assert got.shape == ref.shape and got.dtype == dt and torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16, torch.float32])
+def test_egress_u8_matches_host_metrics(dt):
+    T, H, W = 3, 40, 56
+    g = torch.Generator().manual_seed(5)
+    out = (torch.rand(T, 3, H, W, generator=g) * 1.4 - 0.2).to(dt)     # values below 0 and above 1: the clamp matters
+    _, sharp = synth.blurred_clip(T, H, W, seed=32)
+    img, psnr = egress_u8(out.cuda(), torch.from_numpy(sharp).cuda())
+    for e in range(T):
+        host = out[e].float().clamp(0, 1.0).permute(1, 2, 0).numpy() * 255       # test_deblur.py:140-141
+        assert abs(psnr[e] - cli.psnr_255(host, sharp[e])) < 1e-3
+        assert np.array_equal(img[e].cpu().numpy(), np.rint(host).astype(np.uint8))

@@ -1,15 +1,20 @@
-"""Parity of the HIP path (through the C ABI) against the CPU oracle and the committed golden fixtures.  -m gpu.
+"""Parity of the bf16-storage HIP path (through the C ABI) against the CPU oracle and the committed golden fixtures.  -m gpu.
 
-Everything the kernels store is bf16, all accumulation is fp32.  Tolerances (stated per test, relative to the
-reference tensor's max-abs ``scale``):
+Everything these kernels store is bf16, all accumulation is fp32.  Tolerances (stated per test, relative to the
+reference tensor's max-abs ``scale``; each is <= 2x the error measured on MI355X, see gpurun_out/parity_report.json):
   * pure index work (GSTS gather, temporal roll): bit exact;
-  * single kernels fed bf16-rounded inputs:            max-abs <= 1.5e-2 * scale
-  * blocks (CAB, GSTS unit, shift block, TFR_UNet):    max-abs <= 4e-2 * scale (tens of bf16 roundings in series)
-  * long chains (stage 1, whole network): random-weight LayerNorm/gate networks amplify rounding noise, so the
-    yardstick is the REFERENCE'S OWN bf16 run (net.bfloat16() on CPU, stored in the golden fixtures / recomputed with
-    the oracle in bf16): the HIP path must be at least as close to the fp32 reference as that run, within 1 dB
-    (it keeps fp32 accumulators, LayerNorm statistics and pooling sums, so in practice it is closer), and
-    |PSNR(out, gt) - PSNR(ref_out, gt)| <= 0.1 dB on the synthetic ground truth.
+  * single kernels fed bf16-rounded inputs:            max-abs <= 8e-3 * scale (observed 2.4e-3 .. 4.2e-3: one output
+    rounding of a value near the top of a bf16 binade is 2^-8 = 3.9e-3 relative on its own);
+  * blocks (CAB, CAB2, CAB1, GSTS unit):               max-abs <= 8e-3 * scale (observed 2.5e-3 .. 2.7e-3 for CABs);
+  * shift block, TFR_UNet, stage 1:                    max-abs <= 1.6e-2 * scale (4..8 units / 20 CABs in series);
+  * whole network (synthetic checkpoint recipe v2, weights.py): the contract of BASELINE.json / SURVEY.md 8c:
+        PSNR(hip, reference fp32 output) >= 48 dB   and   |PSNR(hip, gt) - PSNR(ref, gt)| <= 0.01 dB,
+    the second for fp16 modules (upstream's CLI dtype: I/O tensors in fp16) against the fp32 reference output, and for
+    bf16 modules against the reference evaluated with the SAME bf16 input / output tensors (the oracle run on the
+    bf16-rounded clip, output rounded to bf16): a bf16 image tensor quantises intensities above 0.5 to 1/256 steps, an
+    intensity-dependent bias of ~1e-3 that moves PSNR-vs-gt by 0.02 .. 0.06 dB for ANY implementation, the reference's
+    own ``net.bfloat16()`` run included (measured in the build container).
+The fp32 engine (tests/test_gpu_fp32.py) pins the shared control flow to 1e-4 independently of all of this.
 Every measured error is also appended to gpurun_out/parity_report.json.
 """
 import ctypes
@@ -149,7 +154,7 @@ def test_conv(case, hw, engines):
     torch.cuda.synchronize()
     ref = torch.nn.functional.conv2d(torch.cat(xs, 1), sd[wkey + "weight"], sd.get(wkey + "bias"), stride=stride, padding=pad)
     ref = torch.where(ref >= 0, ref, 0.2 * ref)
-    check(f"conv_{case}_{H}x{W}", to_cpu(out.t, out.c), ref, 1.5e-2)
+    check(f"conv_{case}_{H}x{W}", to_cpu(out.t, out.c), ref, 8e-3)
     if out.t.shape[-1] > out.c:
         assert out.t[..., out.c:].float().abs().max().item() == 0.0
 
@@ -163,21 +168,21 @@ def test_conv_epilogues(engines):
     r = bf(torch.from_numpy(synth.unit_noise((T, 14, H, W), seed=62)))
     out, pool, npix = eng.conv("conv_trans", [act(to_dev(x), 14)], res=act(to_dev(r), 14), pool=True)
     ref = F.conv2d(x, sd["conv_trans.weight"], sd["conv_trans.bias"], padding=1) + r
-    check("conv_res", to_cpu(out.t, 14), ref, 1.5e-2)
-    check("conv_pool", pool.sum(1)[:, :14] / npix, ref.mean((2, 3)), 1.5e-2)
+    check("conv_res", to_cpu(out.t, 14), ref, 8e-3)
+    check("conv_pool", pool.sum(1)[:, :14] / npix, ref.mean((2, 3)), 8e-3)
     # bilinear x2 + 1x1 + skip  (SkipUpSample)
     lo = bf(torch.from_numpy(synth.unit_noise((T, 64, H // 2, W // 2), seed=63)))
     sk = bf(torch.from_numpy(synth.unit_noise((T, 64, H, W), seed=64)))
     out = eng.skip_up("stage1.up21", act(to_dev(lo), 64), act(to_dev(sk), 64))
-    check("skip_up", to_cpu(out.t, 64), O.skip_up_sample(sd, "stage1.up21.", lo, sk), 1.5e-2)
+    check("skip_up", to_cpu(out.t, 64), O.skip_up_sample(sd, "stage1.up21.", lo, sk), 8e-3)
     lo = bf(torch.from_numpy(synth.unit_noise((T, 18, H // 2, W // 2), seed=65)))
     sk = bf(torch.from_numpy(synth.unit_noise((T, 14, H, W), seed=66)))
     out = eng.skip_up("orb1.up21", act(to_dev(lo), 18), act(to_dev(sk), 14))
-    check("skip_up_unet", to_cpu(out.t, 14), O.skip_up_sample(sd, "orb1.up21.", lo, sk), 1.5e-2)
+    check("skip_up_unet", to_cpu(out.t, 14), O.skip_up_sample(sd, "orb1.up21.", lo, sk), 8e-3)
     # pixel shuffle
     x = bf(torch.from_numpy(synth.unit_noise((T, 64, H, W), seed=67)))
     out = eng.conv("stage1.upsample0", [act(to_dev(x), 64)], out_mode=1)
-    check("pixshuf", to_cpu(out.t, 14), O.pixel_shuffle_pack(sd, "stage1.upsample0.", x), 1.5e-2)
+    check("pixshuf", to_cpu(out.t, 14), O.pixel_shuffle_pack(sd, "stage1.upsample0.", x), 8e-3)
     assert out.t[..., 14:].float().abs().max().item() == 0.0
     # NCHW egress: conv_last + shortcut, three dtypes
     x = bf(torch.from_numpy(synth.unit_noise((T, 14, H, W), seed=68)))
@@ -186,7 +191,7 @@ def test_conv_epilogues(engines):
         o = torch.empty((T, 3, H, W), dtype=dt, device=DEV)
         eng.conv("conv_last", [act(to_dev(x), 14)], out_mode=2, nchw_out=o, nchw_sc=sc.to(DEV))
         ref = F.conv2d(x, sd["conv_last.weight"], None, padding=2) + sc.float()
-        check(f"conv_last_{dt}", o, ref, 1.5e-2)
+        check(f"conv_last_{dt}", o, ref, 8e-3)
     # ingest
     from shiftnet_amd import lib as L
     xin = torch.rand(T, 3, H, W)
@@ -204,7 +209,7 @@ def test_cab(name, pre, c, engines):
     eng, sd = engines(name)
     x = bf(torch.from_numpy(synth.unit_noise((3, c, 20, 44), seed=71)))
     out = eng.cab(pre, act(to_dev(x), c))
-    check(f"cab_{name}_{pre}", to_cpu(out.t, c), O.cab(sd, pre, x), 4e-2)
+    check(f"cab_{name}_{pre}", to_cpu(out.t, c), O.cab(sd, pre, x), 8e-3)
 
 
 @pytest.mark.parametrize("gsts_v", [3, 2, 1, 0])
@@ -229,25 +234,41 @@ def test_gsts_pieces(name, gsts_v, engines):
                                           torch.cuda.current_stream().cuda_stream), "shiftconv")
         _, hw_ref = O.temporal_roll(x, rev, V.wrap)
         hw_ref = torch.nn.functional.conv2d(O.spatial_shift(hw_ref.contiguous()), sd[pre + "conv1.weight"], padding=1, groups=C // 2)
-        check(f"shiftconv_{name}_{mode}", to_cpu(hwb, C // 2), hw_ref, 1.5e-2)
+        check(f"shiftconv_{name}_{mode}", to_cpu(hwb, C // 2), hw_ref, 8e-3)
         out = eng.naf(pre, xd, mode)
-        check(f"cab2_v{gsts_v}_{name}_{mode}", to_cpu(out.t, C), O.cab2(sd, pre, O.gsts_gather(x, rev, V.wrap), V), 4e-2)
+        check(f"cab2_v{gsts_v}_{name}_{mode}", to_cpu(out.t, C), O.cab2(sd, pre, O.gsts_gather(x, rev, V.wrap), V), 8e-3)
     pre = blk + "encoder_level1.1."
     out = eng.naf(pre, xd, 0)
-    check(f"cab1_v{gsts_v}_{name}", to_cpu(out.t, C), O.cab1(sd, pre, x, V), 4e-2)
+    check(f"cab1_v{gsts_v}_{name}", to_cpu(out.t, C), O.cab1(sd, pre, x, V), 8e-3)
     out = eng.gsts_unit(blk + "encoder_level1_1.", xd, True)
-    check(f"unit_rev_v{gsts_v}_{name}", to_cpu(out.t, C), O.gsts_unit(sd, blk + "encoder_level1_1.", x, True, V), 4e-2)
+    check(f"unit_rev_v{gsts_v}_{name}", to_cpu(out.t, C), O.gsts_unit(sd, blk + "encoder_level1_1.", x, True, V), 8e-3)
     out = eng.shift_block(blk, xd)
-    check(f"shift_block_v{gsts_v}_{name}", to_cpu(out.t, C), O.shift_block(sd, blk, x, V), 6e-2)
+    check(f"shift_block_v{gsts_v}_{name}", to_cpu(out.t, C), O.shift_block(sd, blk, x, V), 1.6e-2)
     # ragged sizes: partial tiles in both kernels' tilings
     x2 = bf(torch.from_numpy(synth.unit_noise((2, C, 13, 70), seed=82)))
     out = eng.gsts_unit(blk + "encoder_level1.", act(to_dev(x2), C), False)
-    check(f"unit_fwd_ragged_v{gsts_v}_{name}", to_cpu(out.t, C), O.gsts_unit(sd, blk + "encoder_level1.", x2, False, V), 4e-2)
+    check(f"unit_fwd_ragged_v{gsts_v}_{name}", to_cpu(out.t, C), O.gsts_unit(sd, blk + "encoder_level1.", x2, False, V), 8e-3)
     eng.gsts_v = 2
 
 
 def C_byref(s):
     return ctypes.byref(s)
+
+
+@pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_deblur1"])
+@pytest.mark.parametrize("T,h,w", [(3, 184, 328), (3, 40, 200)])
+def test_unit_parity_at_production_tile_counts(name, T, h, w, engines):
+    """A whole GSTS unit against the oracle at sizes where the persistent, XCD-partitioned schedule of the matrix-core
+    stencil kernel really loops: 184x328x3 = 414 tiles of 64x8 (> 256 workgroups, ragged right and bottom tiles, a
+    segment boundary in the middle of a frame); 40x200x3 = 60 tiles (a workgroup count that is not a multiple of 8, so
+    the XCD partition falls back to one segment)."""
+    eng, sd = engines(name)
+    V = O.VARIANTS[name]
+    x = bf(torch.from_numpy(synth.unit_noise((T, V.c1, h, w), seed=83)))
+    blk = "stage1.decoder_level1."
+    for unit, rev in (("encoder_level1.", False), ("encoder_level1_1.", True)):
+        out = eng.gsts_unit(blk + unit, act(to_dev(x), V.c1), rev)
+        check(f"unit_{'rev' if rev else 'fwd'}_{name}_{T}x{h}x{w}", to_cpu(out.t, V.c1), O.gsts_unit(sd, blk + unit, x, rev, V), 8e-3)
 
 
 @pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_deblur1", "gshift_denoise1"])
@@ -256,16 +277,11 @@ def test_unet_and_stage1(name, engines):
     V = O.VARIANTS[name]
     x0 = bf(torch.from_numpy(synth.unit_noise((3, V.c0, 24, 40), seed=91)))
     out = eng.tfr_unet("orb1.", act(to_dev(x0), V.c0))
-    check(f"tfr_unet_{name}", to_cpu(out.t, V.c0), O.tfr_unet(sd, "orb1.", x0, V), 6e-2)
+    check(f"tfr_unet_{name}", to_cpu(out.t, V.c0), O.tfr_unet(sd, "orb1.", x0, V), 1.6e-2)
     out = to_cpu(eng.stage1(act(to_dev(x0), V.c0)).t, V.c0)
     with torch.no_grad():
         ref = O.stage1(sd, x0, V)
-        sdb = {k: v.bfloat16() for k, v in sd.items()}
-        ref_b = O.stage1(sdb, x0.bfloat16(), V).float()          # the same graph evaluated in bf16 on the CPU
-    rms = lambda a: (a - ref).pow(2).mean().sqrt().item() / ref.pow(2).mean().sqrt().item()
-    e_hip, e_b = rms(out), rms(ref_b)
-    REPORT.append({"name": f"stage1_{name}", "rel_rms_hip": e_hip, "rel_rms_cpu_bf16": e_b})
-    assert e_hip <= 1.25 * e_b + 1e-3, (name, e_hip, e_b)
+    check(f"stage1_{name}", out, ref, 3e-2)                      # absolute bound: 48..56 GSTS units + ~20 CABs in series
 
 
 def _psnr(a, b):
@@ -295,18 +311,26 @@ def test_whole_net_vs_golden(name, dt, golden_dir):
     out = out.float().cpu()
     gt = torch.from_numpy(sharp[2:5]).permute(0, 3, 1, 2).float() / 255
     p_oo = _psnr(out, ref)
-    yard = float(g["p2f2_ref_bf16_psnr"])
-    dpsnr = abs(_psnr(out.clamp(0, 1), gt) - _psnr(ref.clamp(0, 1), gt))
-    REPORT.append({"name": f"net_{name}_{dt}", "psnr_vs_ref": p_oo, "ref_own_bf16_psnr": yard, "delta_psnr_gt": dpsnr,
-                   "max_abs": (out - ref).abs().max().item()})
-    assert p_oo >= yard - 1.0 and dpsnr <= 0.1, (name, p_oo, yard, dpsnr)
+    dpsnr_raw = abs(_psnr(out.clamp(0, 1), gt) - _psnr(ref.clamp(0, 1), gt))
+    if dt == torch.float16:
+        dpsnr = dpsnr_raw                                  # upstream's CLI dtype: compared with the fp32 reference output directly
+    else:
+        # a bf16 module's input and output TENSORS are bf16: compare with the reference evaluated under the same I/O
+        # quantisation (fp32 oracle on the bf16-rounded clip, output rounded to bf16) -- see the module docstring
+        with torch.no_grad():
+            sd = synth_state_dict(name)
+            ref_q = O.forward(V, sd, x.bfloat16().float(), nm.bfloat16().float() if V.denoise else None, 2, 2).bfloat16().float()
+        dpsnr = abs(_psnr(out.clamp(0, 1), gt) - _psnr(ref_q.clamp(0, 1), gt))
+    REPORT.append({"name": f"net_{name}_{dt}", "psnr_vs_ref": p_oo, "ref_own_bf16_psnr": float(g["p2f2_ref_bf16_psnr"]),
+                   "delta_psnr_gt": dpsnr, "delta_psnr_gt_vs_fp32_ref": dpsnr_raw, "max_abs": (out - ref).abs().max().item()})
+    assert p_oo >= 48.0 and dpsnr <= 0.01, (name, dt, p_oo, dpsnr, dpsnr_raw)
     # default past/future of the ctor
     net2 = mod.GShiftNet()
     net2.load_state_dict(synth_state_dict(name), strict=True)
     net2 = net2.to(dt).to("cuda").eval()
     with torch.no_grad():
         out2 = net2(x.to(dt).cuda(), nm.to(dt).cuda()) if V.denoise else net2(x.to(dt).cuda())
-    assert _psnr(out2.float().cpu(), torch.from_numpy(g["default"])) >= float(g["default_ref_bf16_psnr"]) - 1.0
+    assert _psnr(out2.float().cpu(), torch.from_numpy(g["default"])) >= 48.0
     # T <= past+future -> empty
     with torch.no_grad():
         e = net(x[:, :4].to(dt).cuda(), nm[:, :4].to(dt).cuda()) if V.denoise else net(x[:, :4].to(dt).cuda())
@@ -325,7 +349,7 @@ def test_config1_and_cli_windows(golden_dir):
         out = net(O.frames_to_tensor(list(blur)).bfloat16().cuda()).float().cpu()
     p = _psnr(out, torch.from_numpy(g["out"]))
     REPORT.append({"name": "config1", "psnr_vs_ref": p, "ref_own_bf16_psnr": float(g["ref_bf16_psnr"])})
-    assert p >= float(g["ref_bf16_psnr"]) - 1.0
+    assert p >= 48.0
     g = np.load(os.path.join(golden_dir, f"windows_{name}.npz"))
     blur, _ = synth.blurred_clip(12, 32, 40, seed=7)
     outs = []
@@ -334,7 +358,7 @@ def test_config1_and_cli_windows(golden_dir):
             outs.append(net(O.frames_to_tensor(list(blur[a.start:a.stop])).bfloat16().cuda()).float().cpu())
     p = _psnr(torch.cat(outs), torch.from_numpy(g["out"]))
     REPORT.append({"name": "cli_windows", "psnr_vs_ref": p, "ref_own_bf16_psnr": float(g["ref_bf16_psnr"])})
-    assert p >= float(g["ref_bf16_psnr"]) - 1.0
+    assert p >= 48.0
 
 
 def test_full_size_properties():
@@ -390,7 +414,7 @@ def test_odd_sizes_small_variant():
         ref_b = O.forward(O.VARIANTS[name], {k: v.bfloat16() for k, v in sd.items()}, x.bfloat16(), None, 2, 2).float()
     p_hip, p_yard = _psnr(out, ref), _psnr(ref_b, ref)
     REPORT.append({"name": "odd_68x100", "psnr_vs_ref": p_hip, "cpu_bf16_oracle_psnr": p_yard})
-    assert out.shape == ref.shape and p_hip >= p_yard - 1.0
+    assert out.shape == ref.shape and p_hip >= 48.0
     with pytest.raises(ValueError):
         net(torch.zeros(1, 5, 3, 66, 100, dtype=torch.bfloat16, device="cuda"))
 

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     from shiftnet_amd import lib as L
     lib = L.load()
     header = open(os.path.join(ROOT, "include", "shiftnet_hip.h")).read()
-    declared = sorted(set(re.findall(r"^(?:int|void\*) (sn_\w+)\(", header, flags=re.M)))
+    declared = sorted(set(re.findall(r"^(?:int|void\*) (sn\d*_\w+)\(", header, flags=re.M)))
     assert declared == sorted(L.SYMBOLS), (declared, sorted(L.SYMBOLS))
     for s in declared:
         assert hasattr(lib, s)
@@ -71,19 +71,36 @@ def _halo_worker(rank, world, port, L):
     sys.path.insert(0, os.path.join(ROOT, "shift-net_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from shiftnet_amd.clip_parallel import assemble_window
+    from shiftnet_amd.clip_parallel import assemble_window, window_ranges
     n = world * L + 4
-    clip = torch.arange(n * 3 * 4 * 6, dtype=torch.float32).reshape(n, 3, 4, 6)      # frame f is identifiable
+    # a 1080p-shaped (16:9) clip, small; frame f is identifiable from any of its pixels
+    clip = torch.arange(n * 3 * 9 * 16, dtype=torch.float32).reshape(n, 3, 9, 16)
     own = clip[rank * L + 2: rank * L + 2 + L]
     win = assemble_window(own, clip[:2] if rank == 0 else None, clip[-2:] if rank == world - 1 else None, rank, world)
-    assert torch.equal(win, clip[rank * L: rank * L + L + 4]), rank
+    # window r of the clip-parallel run == window r of the single-GPU CLI loop (inference/test_deblur.py:111-120)
+    rin, rout = window_ranges(n, L)[rank]
+    assert torch.equal(win, clip[rin.start:rin.stop]), rank
+    assert torch.equal(win[2:-2], clip[rout.start:rout.stop]) and torch.equal(win[2:-2], own), rank
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_halo_exchange_world2_gloo():
+@pytest.mark.parametrize("world,L", [(2, 5), (4, 16), (8, 12)])     # 8 x one_len 12 = BASELINE config 5's partition of 96 frames
+def test_halo_exchange_gloo(world, L):
     port = _free_port()
-    mp.spawn(_halo_worker, args=(2, port, 5), nprocs=2, join=True)
+    mp.spawn(_halo_worker, args=(world, port, L), nprocs=world, join=True)
+
+
+def test_bench_refuses_fewer_gpus_than_asked():
+    """`bench.py --gpus N` must never print an N-GPU line from fewer devices (this container has none)."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "refusing" in r.stderr and not r.stdout.strip().startswith("{")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
 
 
 def test_cli_window_arithmetic_and_metrics():
