@@ -5,8 +5,10 @@ reference tensor's max-abs ``scale``; each is <= 2x the error measured on MI355X
   * pure index work (GSTS gather, temporal roll): bit exact;
   * single kernels fed bf16-rounded inputs:            max-abs <= 8e-3 * scale (observed 2.4e-3 .. 4.2e-3: one output
     rounding of a value near the top of a bf16 binade is 2^-8 = 3.9e-3 relative on its own);
-  * blocks (CAB, CAB2, CAB1, GSTS unit):               max-abs <= 8e-3 * scale (observed 2.5e-3 .. 2.7e-3 for CABs);
-  * shift block, TFR_UNet, stage 1:                    max-abs <= 1.6e-2 * scale (4..8 units / 20 CABs in series);
+  * CAB, CAB2, CAB1:                                   max-abs <= 8e-3 * scale (observed <= 2.7e-3 / 4.7e-3 / 3.9e-3);
+  * GSTS unit (CAB2 + CAB1):                           max-abs <= 1.2e-2 * scale (observed <= 6.4e-3, 184x328 case);
+  * TFR_UNet (20 CABs):                                max-abs <= 1.4e-2 * scale (observed <= 6.7e-3);
+  * shift block (4 / 8 units), stage 1 (48..56 units): max-abs <= 4e-2 * scale (observed <= 1.96e-2 for both);
   * whole network (synthetic checkpoint recipe v2, weights.py): the contract of BASELINE.json / SURVEY.md 8c:
         PSNR(hip, reference fp32 output) >= 48 dB   and   |PSNR(hip, gt) - PSNR(ref, gt)| <= 0.01 dB,
     the second for fp16 modules (upstream's CLI dtype: I/O tensors in fp16) against the fp32 reference output, and for
@@ -241,13 +243,13 @@ def test_gsts_pieces(name, gsts_v, engines):
     out = eng.naf(pre, xd, 0)
     check(f"cab1_v{gsts_v}_{name}", to_cpu(out.t, C), O.cab1(sd, pre, x, V), 8e-3)
     out = eng.gsts_unit(blk + "encoder_level1_1.", xd, True)
-    check(f"unit_rev_v{gsts_v}_{name}", to_cpu(out.t, C), O.gsts_unit(sd, blk + "encoder_level1_1.", x, True, V), 8e-3)
+    check(f"unit_rev_v{gsts_v}_{name}", to_cpu(out.t, C), O.gsts_unit(sd, blk + "encoder_level1_1.", x, True, V), 1.2e-2)
     out = eng.shift_block(blk, xd)
-    check(f"shift_block_v{gsts_v}_{name}", to_cpu(out.t, C), O.shift_block(sd, blk, x, V), 1.6e-2)
+    check(f"shift_block_v{gsts_v}_{name}", to_cpu(out.t, C), O.shift_block(sd, blk, x, V), 4e-2)
     # ragged sizes: partial tiles in both kernels' tilings
     x2 = bf(torch.from_numpy(synth.unit_noise((2, C, 13, 70), seed=82)))
     out = eng.gsts_unit(blk + "encoder_level1.", act(to_dev(x2), C), False)
-    check(f"unit_fwd_ragged_v{gsts_v}_{name}", to_cpu(out.t, C), O.gsts_unit(sd, blk + "encoder_level1.", x2, False, V), 8e-3)
+    check(f"unit_fwd_ragged_v{gsts_v}_{name}", to_cpu(out.t, C), O.gsts_unit(sd, blk + "encoder_level1.", x2, False, V), 1.2e-2)
     eng.gsts_v = 2
 
 
@@ -268,7 +270,7 @@ def test_unit_parity_at_production_tile_counts(name, T, h, w, engines):
     blk = "stage1.decoder_level1."
     for unit, rev in (("encoder_level1.", False), ("encoder_level1_1.", True)):
         out = eng.gsts_unit(blk + unit, act(to_dev(x), V.c1), rev)
-        check(f"unit_{'rev' if rev else 'fwd'}_{name}_{T}x{h}x{w}", to_cpu(out.t, V.c1), O.gsts_unit(sd, blk + unit, x, rev, V), 8e-3)
+        check(f"unit_{'rev' if rev else 'fwd'}_{name}_{T}x{h}x{w}", to_cpu(out.t, V.c1), O.gsts_unit(sd, blk + unit, x, rev, V), 1.2e-2)
 
 
 @pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_deblur1", "gshift_denoise1"])
@@ -277,11 +279,11 @@ def test_unet_and_stage1(name, engines):
     V = O.VARIANTS[name]
     x0 = bf(torch.from_numpy(synth.unit_noise((3, V.c0, 24, 40), seed=91)))
     out = eng.tfr_unet("orb1.", act(to_dev(x0), V.c0))
-    check(f"tfr_unet_{name}", to_cpu(out.t, V.c0), O.tfr_unet(sd, "orb1.", x0, V), 1.6e-2)
+    check(f"tfr_unet_{name}", to_cpu(out.t, V.c0), O.tfr_unet(sd, "orb1.", x0, V), 1.4e-2)
     out = to_cpu(eng.stage1(act(to_dev(x0), V.c0)).t, V.c0)
     with torch.no_grad():
         ref = O.stage1(sd, x0, V)
-    check(f"stage1_{name}", out, ref, 3e-2)                      # absolute bound: 48..56 GSTS units + ~20 CABs in series
+    check(f"stage1_{name}", out, ref, 4e-2)                      # absolute bound: 48..56 GSTS units + ~20 CABs in series
 
 
 def _psnr(a, b):
