@@ -102,7 +102,11 @@ typedef struct sn_unit_src {
     const void* x;       /* [T][h][w][C] the unit's input */
     int T, h, w, C;      /* C in {64, 80} */
     int mode;            /* 0: CAB1 (no shift, u = x[t]); 1: CAB2 of a forward unit; 2: CAB2 of a reverse unit */
-    int wrap;            /* 1: circular temporal roll (gshift_deblur2.py:504-505); 0: boundary frame kept (:513,517) */
+    int wrap;            /* 0: boundary frame kept (gshift_deblur1.py:513,517); 1: circular temporal roll (gshift_deblur2.py:504-505);
+                            2: the neighbour of the boundary frame lives in the HALO slot just outside x -- frame index -1 for
+                            a forward unit, T for a reverse unit -- i.e. x points at frame 1 of a [T+2]-frame allocation whose
+                            outer frames were filled by the adjacent rank of a temporally split window (only the borrowed
+                            half-channels of the slot are read) */
 } sn_unit_src;
 
 /* validation op: materialise u = cat(y, spatial_shift2(hw)) : [T][h][w][3C/2] exactly as channel_shift returns it

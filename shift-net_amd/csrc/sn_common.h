@@ -90,6 +90,13 @@ __device__ __forceinline__ float sum_rows4(float x) {
     return c + d;
 }
 
+// Temporal neighbour of frame t for the half-channel roll (gshift_deblur1.py:504-518).  `wrap`: 0 = the boundary frame is kept
+// (callers never ask for its neighbour), 1 = circular inside the tensor (gshift_deblur2.py:504-505), 2 = the neighbour lives in
+// the HALO slot just outside the tensor -- frame index -1 / T -- filled by the adjacent rank of a temporally split window
+// (shiftnet_amd/temporal_split.py); frame offsets are therefore computed in ptrdiff_t.
+__device__ __forceinline__ int sn_prev_frame(int t, int T, int wrap) { return t > 0 ? t - 1 : (wrap == 2 ? -1 : T - 1); }
+__device__ __forceinline__ int sn_next_frame(int t, int T, int wrap) { return t < T - 1 ? t + 1 : (wrap == 2 ? T : 0); }
+
 // wave-uniform wave index (threadIdx-derived values are "divergent" to the compiler; make it provably uniform)
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 

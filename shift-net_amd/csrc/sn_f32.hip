@@ -99,21 +99,21 @@ __global__ void gather32_kernel(const Unit32 U, const int8_t* offs, float* u, co
     const int t = blockIdx.y, Ch = U.C >> 1, hw = U.h * U.w;
     int f0 = t, o0 = 0, f1 = t, o1 = Ch, fb = t, ob = 0;      // SURVEY.md 8a-1 table (same as sn_gsts.hip::unit_slabs)
     if (U.mode == 1) {
-        if (t > 0 || U.wrap) { f0 = (t - 1 + U.T) % U.T; o0 = Ch; f1 = t; o1 = 0; fb = f0; ob = Ch; }
+        if (t > 0 || U.wrap) { f0 = sn_prev_frame(t, U.T, U.wrap); o0 = Ch; f1 = t; o1 = 0; fb = f0; ob = Ch; }
     } else if (U.mode == 2) {
-        if (t < U.T - 1 || U.wrap) { f0 = t; o0 = Ch; f1 = (t + 1) % U.T; o1 = 0; fb = f1; ob = 0; }
+        if (t < U.T - 1 || U.wrap) { f0 = t; o0 = Ch; f1 = sn_next_frame(t, U.T, U.wrap); o1 = 0; fb = f1; ob = 0; }
         else { fb = t; ob = Ch; }
     }
     const size_t n = (size_t)hw * CU;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const int i = (int)(e / CU), c = (int)(e - (size_t)i * CU);
         float v = 0.f;
-        if (c < Ch) v = U.x[((size_t)f0 * hw + i) * U.C + o0 + c];
-        else if (c < U.C) v = U.x[((size_t)f1 * hw + i) * U.C + o1 + c - Ch];
+        if (c < Ch) v = U.x[((ptrdiff_t)f0 * hw + i) * U.C + o0 + c];
+        else if (c < U.C) v = U.x[((ptrdiff_t)f1 * hw + i) * U.C + o1 + c - Ch];
         else {
             const int k = c - U.C, y = i / U.w, x = i - y * U.w;
             const int sy = y + offs[2 * k], sx = x + offs[2 * k + 1];
-            if (sy >= 0 && sy < U.h && sx >= 0 && sx < U.w) v = U.x[(((size_t)fb * U.h + sy) * U.w + sx) * U.C + ob + k];
+            if (sy >= 0 && sy < U.h && sx >= 0 && sx < U.w) v = U.x[(((ptrdiff_t)fb * U.h + sy) * U.w + sx) * U.C + ob + k];
         }
         u[(size_t)t * n + e] = v;
     }

@@ -30,10 +30,10 @@ __device__ __forceinline__ Slabs unit_slabs(const UnitK& U, int t) {
     Slabs s;
     s.f0 = t; s.o0 = 0; s.f1 = t; s.o1 = Ch; s.fb = t; s.ob = 0;
     if (U.mode == 1) {
-        if (t > 0 || U.wrap) { s.f0 = (t - 1 + U.T) % U.T; s.o0 = Ch; s.f1 = t; s.o1 = 0; s.fb = s.f0; s.ob = Ch; }
+        if (t > 0 || U.wrap) { s.f0 = sn_prev_frame(t, U.T, U.wrap); s.o0 = Ch; s.f1 = t; s.o1 = 0; s.fb = s.f0; s.ob = Ch; }
         else { s.fb = t; s.ob = 0; }
     } else if (U.mode == 2) {
-        if (t < U.T - 1 || U.wrap) { s.f0 = t; s.o0 = Ch; s.f1 = (t + 1) % U.T; s.o1 = 0; s.fb = s.f1; s.ob = 0; }
+        if (t < U.T - 1 || U.wrap) { s.f0 = t; s.o0 = Ch; s.f1 = sn_next_frame(t, U.T, U.wrap); s.o1 = 0; s.fb = s.f1; s.ob = 0; }
         else { s.fb = t; s.ob = Ch; }
     }
     return s;
@@ -48,12 +48,12 @@ __global__ void gather_kernel(const UnitK U, const int8_t* offs, bf16_t* u, cons
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const int i = (int)(e / CU), c = (int)(e - (size_t)i * CU);
         bf16_t v = 0;
-        if (c < Ch) v = U.x[((size_t)s.f0 * hw + i) * U.C + s.o0 + c];
-        else if (c < U.C) v = U.x[((size_t)s.f1 * hw + i) * U.C + s.o1 + c - Ch];
+        if (c < Ch) v = U.x[((ptrdiff_t)s.f0 * hw + i) * U.C + s.o0 + c];
+        else if (c < U.C) v = U.x[((ptrdiff_t)s.f1 * hw + i) * U.C + s.o1 + c - Ch];
         else {
             const int k = c - U.C, y = i / U.w, x = i - y * U.w;
             const int sy = y + offs[2 * k], sx = x + offs[2 * k + 1];
-            if (sy >= 0 && sy < U.h && sx >= 0 && sx < U.w) v = U.x[(((size_t)s.fb * U.h + sy) * U.w + sx) * U.C + s.ob + k];
+            if (sy >= 0 && sy < U.h && sx >= 0 && sx < U.w) v = U.x[(((ptrdiff_t)s.fb * U.h + sy) * U.w + sx) * U.C + s.ob + k];
         }
         u[(size_t)t * n + e] = v;
     }
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const int
     constexpr int PCS = CH / 8;
     const int tid = threadIdx.x, t = blockIdx.z, y0 = blockIdx.y * 16, x0 = blockIdx.x * 16;
     const Slabs s = unit_slabs(U, t);
-    const bf16_t* src = U.x + (size_t)s.fb * U.h * U.w * U.C + s.ob;
+    const bf16_t* src = U.x + (ptrdiff_t)s.fb * U.h * U.w * U.C + s.ob;
     {   // staging: issue ALL global loads first (branch-free, clamped addresses), then mask + write to LDS: one memory
         // round trip per workgroup instead of one per loop iteration
         constexpr int NIT = (RW * RW * PCS + 255) / 256;
@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256) void ln_gemm_kernel(const UnitK U, const bf16_
         for (int s = 0; s < KS; ++s) {
             const int kk0 = s * 32 + g * 8;
             const bf16_t* src = nullptr;
-            if (kk0 < CH) src = U.x + ((size_t)sl.f0 * hw + ii) * C + sl.o0 + kk0;
-            else if (kk0 < C) src = U.x + ((size_t)sl.f1 * hw + ii) * C + sl.o1 + kk0 - CH;
+            if (kk0 < CH) src = U.x + ((ptrdiff_t)sl.f0 * hw + ii) * C + sl.o0 + kk0;
+            else if (kk0 < C) src = U.x + ((ptrdiff_t)sl.f1 * hw + ii) * C + sl.o1 + kk0 - CH;
             else if (WITH_HW && kk0 < K) src = hwb + ((size_t)t * hw + ii) * CH + kk0 - C;
             if (src) {
                 unpack8(*(const uint4*)src, xv[s]);
@@ -448,8 +448,8 @@ __global__ __launch_bounds__(256) void scale_gemm_res_kernel(const UnitK U, cons
         // lane (g,p) owns channels [g*4*MT, (g+1)*4*MT): one contiguous 8*MT-byte run of the shortcut and of y
         uint32_t sc[2 * MT], o[2 * MT];
         const int c0 = g * 4 * MT;
-        const bf16_t* sp = c0 < CH ? U.x + ((size_t)sl.f0 * hw + i) * C + sl.o0 + c0
-                                   : U.x + ((size_t)sl.f1 * hw + i) * C + sl.o1 + c0 - CH;
+        const bf16_t* sp = c0 < CH ? U.x + ((ptrdiff_t)sl.f0 * hw + i) * C + sl.o0 + c0
+                                   : U.x + ((ptrdiff_t)sl.f1 * hw + i) * C + sl.o1 + c0 - CH;
 #pragma unroll
         for (int m = 0; m + 1 < MT; m += 2) { const uint4 q = *(const uint4*)(sp + m * 4); sc[2 * m] = q.x; sc[2 * m + 1] = q.y; sc[2 * m + 2] = q.z; sc[2 * m + 3] = q.w; }
         if (MT & 1) { const uint2 q = *(const uint2*)(sp + (MT - 1) * 4); sc[2 * MT - 2] = q.x; sc[2 * MT - 1] = q.y; }

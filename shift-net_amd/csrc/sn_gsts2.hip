@@ -24,8 +24,8 @@ struct Slabs2 { int f0, o0, f1, o1; };
 __device__ __forceinline__ Slabs2 unit_slabs2(const UnitK2& U, int t) {
     const int Ch = U.C >> 1;
     Slabs2 s; s.f0 = t; s.o0 = 0; s.f1 = t; s.o1 = Ch;
-    if (U.mode == 1) { if (t > 0 || U.wrap) { s.f0 = (t - 1 + U.T) % U.T; s.o0 = Ch; s.f1 = t; s.o1 = 0; } }
-    else if (U.mode == 2) { if (t < U.T - 1 || U.wrap) { s.f0 = t; s.o0 = Ch; s.f1 = (t + 1) % U.T; s.o1 = 0; } }
+    if (U.mode == 1) { if (t > 0 || U.wrap) { s.f0 = sn_prev_frame(t, U.T, U.wrap); s.o0 = Ch; s.f1 = t; s.o1 = 0; } }
+    else if (U.mode == 2) { if (t < U.T - 1 || U.wrap) { s.f0 = t; s.o0 = Ch; s.f1 = sn_next_frame(t, U.T, U.wrap); s.o1 = 0; } }
     return s;
 }
 
@@ -88,8 +88,8 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
             // branch-free: pick the address with selects and ALWAYS load (a load inside a divergent branch is waited
             // for on the spot, one memory round trip per slab); padding slabs re-read x and are zeroed afterwards
             const bool has = kk0 < K && !(dbg & 8);
-            const bf16_t* s0 = U.x + ((size_t)sl.f0 * hw + ii) * C + sl.o0 + (kk0 < CH ? kk0 : 0);
-            const bf16_t* s1 = U.x + ((size_t)sl.f1 * hw + ii) * C + sl.o1 + (kk0 >= CH && kk0 < C ? kk0 - CH : 0);
+            const bf16_t* s0 = U.x + ((ptrdiff_t)sl.f0 * hw + ii) * C + sl.o0 + (kk0 < CH ? kk0 : 0);
+            const bf16_t* s1 = U.x + ((ptrdiff_t)sl.f1 * hw + ii) * C + sl.o1 + (kk0 >= CH && kk0 < C ? kk0 - CH : 0);
             const bf16_t* src = kk0 < CH ? s0 : s1;
             if (WITH_HW) {
                 const bf16_t* s2 = hwb + ((size_t)t * hw + ii) * CH + (kk0 >= C && kk0 < K ? kk0 - C : 0);

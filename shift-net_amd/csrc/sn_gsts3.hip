@@ -274,8 +274,8 @@ struct Slabs3 { int f0, o0, f1, o1; };
 __device__ __forceinline__ Slabs3 unit_slabs3(const UnitK3& U, int t) {      // same table as sn_gsts2.hip::unit_slabs2
     const int Ch = U.C >> 1;
     Slabs3 s; s.f0 = t; s.o0 = 0; s.f1 = t; s.o1 = Ch;
-    if (U.mode == 1) { if (t > 0 || U.wrap) { s.f0 = (t - 1 + U.T) % U.T; s.o0 = Ch; s.f1 = t; s.o1 = 0; } }
-    else if (U.mode == 2) { if (t < U.T - 1 || U.wrap) { s.f0 = t; s.o0 = Ch; s.f1 = (t + 1) % U.T; s.o1 = 0; } }
+    if (U.mode == 1) { if (t > 0 || U.wrap) { s.f0 = sn_prev_frame(t, U.T, U.wrap); s.o0 = Ch; s.f1 = t; s.o1 = 0; } }
+    else if (U.mode == 2) { if (t < U.T - 1 || U.wrap) { s.f0 = t; s.o0 = Ch; s.f1 = sn_next_frame(t, U.T, U.wrap); s.o1 = 0; } }
     return s;
 }
 
@@ -341,8 +341,8 @@ __global__ __launch_bounds__(512) void ln_gemm_gate_m_kernel(const UnitK3 U, con
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int kk0 = s * 32 + g * 8;                   // K is a multiple of 32 here: every slab is real
-            const bf16_t* s0 = U.x + ((size_t)sl.f0 * hw + ii) * C + sl.o0 + (kk0 < CH ? kk0 : 0);
-            const bf16_t* s1 = U.x + ((size_t)sl.f1 * hw + ii) * C + sl.o1 + (kk0 >= CH && kk0 < C ? kk0 - CH : 0);
+            const bf16_t* s0 = U.x + ((ptrdiff_t)sl.f0 * hw + ii) * C + sl.o0 + (kk0 < CH ? kk0 : 0);
+            const bf16_t* s1 = U.x + ((ptrdiff_t)sl.f1 * hw + ii) * C + sl.o1 + (kk0 >= CH && kk0 < C ? kk0 - CH : 0);
             const bf16_t* src = kk0 < CH ? s0 : s1;
             if (WITH_HW) {
                 const bf16_t* s2 = hwb + ((size_t)t * hw + ii) * CH + (kk0 >= C ? kk0 - C : 0);

@@ -76,6 +76,15 @@ class GShiftNetBase(nn.Module):
         self._plan = None
         return super().load_state_dict(*args, **kwargs)
 
+    def set_temporal_split(self, rank: int, world: int, group=None) -> None:
+        """Make this module process frames [a, b) of ONE long window sharded over `world` ranks (temporal_split.py):
+        ``forward`` then takes the rank's own frames and returns the frames it restores; results equal the single-GPU run on
+        the whole window.  ``world == 1`` switches back to the ordinary behaviour."""
+        from .temporal_split import TemporalSplit
+        self._split = TemporalSplit(rank, world, self.V.wrap, group) if world > 1 else None
+        if self._plan is not None:
+            self._plan.split = self._split
+
     def prepare(self):
         """Build the device weight plan on first use after a load / dtype / device change."""
         from .engine import make_engine
@@ -89,6 +98,7 @@ class GShiftNetBase(nn.Module):
             with torch.cuda.device(dev):
                 self._plan = make_engine(self.V, self.state_dict(), dev, p0.dtype)
             self._plan_sig = sig
+        self._plan.split = getattr(self, "_split", None)
         return self._plan
 
     def forward(self, x, noise_map=None, k1=None, k2=None, k3=None):

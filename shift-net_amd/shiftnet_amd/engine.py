@@ -197,6 +197,7 @@ class Engine:
         self.gsts_v = int(os.environ.get("SN_GSTS_V", "2"))   # 0 = five-kernel chain, 1 = fused K12 + LDS-staged VALU K3, 2 = K12 (planar g1) + matrix-core K3m
         self.prof: Optional[list] = None      # bench.py attaches a list to collect (fn, label, meta, ev0, ev1)
         self._meta: Tuple = ()
+        self.split = None                     # temporal_split.TemporalSplit: this engine holds a frame range of a longer window
 
     # ---- low level wrappers --------------------------------------------------------------------------------
     def _stream(self) -> int:
@@ -214,8 +215,12 @@ class Engine:
         e1.record()
         self.prof.append((fn, label, self._meta, e0, e1))
 
+    act_dtype = torch.bfloat16
+
     def _new(self, T: int, h: int, w: int, cs: int) -> torch.Tensor:
-        return torch.empty((T, h, w, cs), dtype=torch.bfloat16, device=self.dev)
+        if self.split is not None:            # one spare frame on each side: the halo slots of temporal_split.TemporalSplit
+            return torch.empty((T + 2, h, w, cs), dtype=self.act_dtype, device=self.dev)[1:T + 1]
+        return torch.empty((T, h, w, cs), dtype=self.act_dtype, device=self.dev)
 
     def conv(self, name: str, ins: Sequence[Act], *, stride: int = 1, pad: Optional[int] = None, prelu: Optional[float] = None,
              res: Optional[Act] = None, out_mode: int = 0, pool: bool = False, in_mode: int = 0, oscale: Optional[torch.Tensor] = None,
@@ -305,16 +310,25 @@ class Engine:
         r, pool, npix = self.conv(pre + "body.2", [r], pool=True)
         return self.scale_residual(r, x, self.ca_mlp(pre + "CA", pool, npix), extra)
 
+    def _wrap_flag(self, mode: int, circular: bool) -> int:
+        """sn_unit_src.wrap: 0 keep the boundary frame, 1 circular, 2 neighbour frame in the halo slot (temporal split)."""
+        if self.split is not None and mode:
+            return self.split.wrap_flag(mode) if (circular or self.split.wrap_flag(mode) == 2) else 0
+        return 1 if circular else 0
+
     def _unit_src(self, x: Act, mode: int) -> L.UnitSrc:
         T, h, w, cs = x.dims
         assert cs == x.c
-        return L.UnitSrc(x.t.data_ptr(), T, h, w, x.c, mode, 1 if self.V.wrap else 0)
+        return L.UnitSrc(x.t.data_ptr(), T, h, w, x.c, mode, self._wrap_flag(mode, self.V.wrap))
 
     def temporal_roll(self, x: Act, reverse: bool) -> Act:
         T, h, w, cs = x.dims
         assert cs == x.c, "Shift_CAB widths (24, 80) are stored unpadded"
         y = self._new(T, h, w, cs)
-        s = L.UnitSrc(x.t.data_ptr(), T, h, w, x.c, 2 if reverse else 1, 0)
+        mode = 2 if reverse else 1
+        if self.split is not None:
+            self.split.exchange(x.t, mode)
+        s = L.UnitSrc(x.t.data_ptr(), T, h, w, x.c, mode, self._wrap_flag(mode, False))
         self._call("sn_temporal_roll", "sn_temporal_roll", C.byref(s), y.data_ptr(), self._stream())
         return Act(y, x.c)
 
@@ -328,6 +342,8 @@ class Engine:
         u = P.units[pre]
         T, h, w, c = x.dims
         self._meta = ("naf", T, h, w, c, mode)
+        if mode and self.split is not None:
+            self.split.exchange(x.t, mode)              # neighbour rank's half-frame into the halo slot (one per shifted unit)
         src = self._unit_src(x, mode)
         hw_ptr = None
         if mode:
@@ -512,9 +528,14 @@ class Engine:
         div = 8 if V.topo == "plus" else 4
         if H % div or W % div:
             raise ValueError(f"{V.name}: H and W must be multiples of {div} (got {H}x{W})")
-        n_out = max(T - past - future, 0)
+        sp = self.split
+        lo = past if (sp is None or sp.rank == 0) else 0                         # a split window trims on its outer ranks only
+        hi = T - (future if (sp is None or sp.rank == sp.world - 1) else 0)
+        n_out = max(hi - lo, 0)
         out = torch.empty((n_out, 3, H, W), dtype=x.dtype, device=x.device)
         if n_out == 0:
+            if sp is not None:
+                raise ValueError("temporal split: every rank must restore at least one frame (the halo exchanges are collective)")
             return out                      # T <= past+future yields an empty tensor upstream as well
         x0 = self.cab("feat_extract.1.", self.conv("feat_extract.0", [self._ingest(x, noise_map)]))
         t = x0
@@ -523,7 +544,6 @@ class Engine:
         res0 = t
         sam = self.conv("conv_trans", [res0])
         dec = self.stage1(sam)
-        lo, hi = past, T - future
         feats = sam if V.denoise else res0
 
         def cut(a: Act) -> Act:

@@ -70,8 +70,7 @@ class Engine32(Engine):
         super().__init__(plan, torch.float32)
         self.cab_v = 0
 
-    def _new(self, T: int, h: int, w: int, cs: int) -> torch.Tensor:
-        return torch.empty((T, h, w, cs), dtype=torch.float32, device=self.dev)
+    act_dtype = torch.float32
 
     # ---- leaf operators ------------------------------------------------------------------------------------
     def _conv32(self, wkey: str, bkey: Optional[str], ins: Sequence[torch.Tensor], cins: Sequence[int], *, k: int, stride: int = 1,
@@ -157,7 +156,10 @@ class Engine32(Engine):
     def temporal_roll(self, x: Act, reverse: bool) -> Act:
         T, h, w, c = x.dims
         y = self._new(T, h, w, c)
-        s = L.UnitSrc(x.t.data_ptr(), T, h, w, c, 2 if reverse else 1, 0)
+        mode = 2 if reverse else 1
+        if self.split is not None:
+            self.split.exchange(x.t, mode)
+        s = L.UnitSrc(x.t.data_ptr(), T, h, w, c, mode, self._wrap_flag(mode, False))
         self._call("sn32_gsts_gather", "sn32_temporal_roll", C.byref(s), None, y.data_ptr(), self._stream())
         return Act(y, c)
 
@@ -174,8 +176,10 @@ class Engine32(Engine):
         dsd = P.dsd
         self._meta = ("naf32", T, h, w, c, mode)
         if mode:
+            if self.split is not None:
+                self.split.exchange(x.t, mode)
             ug = self._new(T, h, w, c + c // 2)                                   # cat(roll(x), spatial_shift2(borrowed half))
-            s = L.UnitSrc(x.t.data_ptr(), T, h, w, c, mode, 1 if V.wrap else 0)
+            s = L.UnitSrc(x.t.data_ptr(), T, h, w, c, mode, self._wrap_flag(mode, V.wrap))
             self._call("sn32_gsts_gather", "sn32_gsts_gather", C.byref(s), P.offs.data_ptr(), ug.data_ptr(), st)
             shortcut = ug[..., :c]
             vin = self._new(T, h, w, c + c // 2)                                  # cat(shortcut, conv1(shifted)): a second gather fills
