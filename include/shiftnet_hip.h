@@ -6,7 +6,11 @@
  *
  * Conventions
  *   - all pointers are DEVICE pointers unless said otherwise; the caller owns every buffer (outputs and workspaces
- *     included), the library never allocates or frees and keeps no global mutable state (thread compatible);
+ *     included), the library never allocates or frees, reads no environment variable and keeps no global mutable
+ *     state (thread compatible).  Kernels launch on the calling thread's CURRENT HIP device: make the device that owns
+ *     `stream` and the buffers current first (the Python engine wraps every forward in torch.cuda.device(dev));
+ *   - superseded kernel generations and profiling hooks are NOT part of this ABI: they are compiled only with
+ *     -DSN_EXPERIMENTAL and declared in shiftnet_hip_experimental.h;
  *   - work is enqueued on `stream` (a hipStream_t passed as void*) and returns immediately;
  *   - return 0 on success, negative errno-style code otherwise (-22 bad argument, -5 launch failure); nothing throws;
  *   - activations: NHWC bf16 [T][H][W][Cs], Cs a multiple of 8, pad channels must be (and are kept) zero;
@@ -123,47 +127,17 @@ int sn_temporal_roll(const sn_unit_src* s, void* y, void* stream);
  * w1:[C/2][9] u32 words: the bf16 weight in the LOW half, high half zero (operand of v_dot2c_f32_bf16). */
 int sn_gsts_shiftconv(const sn_unit_src* s, const int8_t* offs, const uint32_t* w1, void* hw, void* stream);
 
-/* a = body[0](norm(cat(shortcut, hw))): LayerNorm2d over 3C/2 (CAB2) or C (CAB1) channels, eps 1e-6, affine folded
- * into the 1x1 weights, then the 1x1 conv to 2C (gshift_deblur1.py:19-28,190,225,252).  a:[T][h][w][2C] in
- * "gate-paired" position order (prep.py).  hw may be NULL for mode 0. */
-int sn_ln_gemm(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, void* a, void* stream);
-
-/* g1 = SimpleGate(RepConv2(a)) (gshift_deblur1.py:166-178): (a1 + dw3x3(a1)) * (a2 + dw3x3(a2)); w:[9][2C] f32 in
- * a's position order with the identity folded into the centre tap.  g1:[T][h][w][C] natural order.
- * pool: NULL, or [T][sn_dwgate_blocks][C] per-workgroup sums of g1 (denoise CALayer2, gshift_denoise1.py:224). */
-int sn_dw_gate(const void* a, const float* w, void* g1, float* pool, int T, int h, int w_, int C, void* stream);
-int sn_dwgate_blocks(int h, int w);
-
-/* g2 = SimpleGate2(body[4](RepConv(g1))) (gshift_deblur2.py:159-168,182-185,201): depthwise 5x5 + 3x3 + identity
- * (folded into one 5x5, w5:[25][C] f32), 1x1 C->2C on MFMA, x1*sigmoid(x2); plus per-workgroup channel sums for
- * the CALayer2 that follows.  ca_in: NULL or [T][C] f32 scale applied to g1 first (denoise).  g2:[T][h][w][C]. */
-int sn_dw_gemm_gate(const void* g1, const float* ca_in, const float* w5, const void* wfrag, void* g2, float* pool,
-                    int T, int h, int w, int C, void* stream);
-int sn_dwgemm_blocks(int h, int w);
-
-/* Fused sn_ln_gemm + sn_dw_gate: g1 = SimpleGate(RepConv2(body[0](norm(cat(shortcut, hw))))) with the 2C-channel
- * intermediate kept in LDS (gshift_deblur1.py:190-198,225-233).  Same weight layouts as the two kernels it replaces.
+/* g1 = SimpleGate(RepConv2(body[0](norm(cat(shortcut, hw))))): LayerNorm2d over 3C/2 (CAB2) or C (CAB1) channels (eps 1e-6,
+ * affine folded into the 1x1 weights), the 1x1 conv to 2C on MFMA, depthwise 3x3 + identity and the gate, with the 2C-channel
+ * intermediate kept in LDS (gshift_deblur1.py:19-28,190-198,225-233).  wfrag / bias: prep.pack_ln_gemm (gate-paired rows).
+ * hw may be NULL for mode 0.
  * wdw: [9][2C] u32, the bf16 weight of position j in half (j & 1) of its word, other half zero (v_dot2c operand).
- * g1_blocked = 1 (C = 64 only): g1 is written channel-blocked [T][4][h][w][16], the layout sn_dw5_gemm_gate reads;
+ * g1_blocked = 0: g1 natural NHWC [T][h][w][C] (sn_grp5_gemm_gate); 1 (C = 64 only): channel-blocked [T][4][h][w][16] (experimental K3');
  * g1_blocked = 2 (C = 64 only): channel-planar [T][h][C][sn_planar_pitch(w)], zeros in the pad columns (sn_dw5m_gemm_gate).
  * pool: NULL or [T][sn_lngate_blocks][C]. */
 int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, const uint32_t* wdw,
                     void* g1, float* pool, int g1_blocked, void* stream);
 int sn_lngate_blocks(int h, int w);
-
-/* sn_dw_gemm_gate for the depthwise variants (C = 64) with the channel-blocked g1 tile staged through LDS; pool: [T][sn_dw5_blocks][C]. */
-int sn_dw5_blocks(int h, int w);
-/* Profiling aids (tools/ only; process-global, default 0 / NULL = production behaviour):
- *   sn_debug_set(mask): bits 1,2,4,8 (sn_dw5_gemm_gate / sn_dw5m_gemm_gate) and 8,16,32 (sn_ln_gemm_gate) skip a phase of
- *     the kernel (results are then wrong) for ablation timing; bit 256 / 512 make sn_ln_gemm_gate(_m) / sn_dw5m_gemm_gate
- *     write per-wave s_memtime phase accumulators ([workgroup][8 waves][8 slots] u64) to the buffer set below.
- *   sn_debug_buf_set(dev_ptr): device buffer for those accumulators (tools/prof_k12.py, tools/prof_k3m.py). */
-int sn_debug_set(int v);
-int sn_debug_get(void);
-int sn_debug_buf_set(void* dev_ptr);
-void* sn_debug_buf_get(void);
-int sn_dw5_gemm_gate(const void* g1, const float* ca_in, const uint32_t* w5, const void* wfrag, void* g2, float* pool,
-                     int T, int h, int w, int C, void* stream);
 
 /* "+" variants: RepConv with groups = C/8 (gshift_deblur1.py:157-165) as a block-diagonal MFMA GEMM, then body[4]
  * (1x1 C->2C), SimpleGate2 and the channel sums.  g1:[T][h][w][C] natural NHWC, wgrp: prep.pack_grouped_frag
@@ -179,16 +153,9 @@ int sn_grp5_blocks(int h, int w);
 int sn_planar_pitch(int w);
 int sn_nhwc_to_planar(const void* x, void* xp, int T, int h, int w, int C, void* stream);   /* x:[T][h][w][C] -> xp planar */
 
-/* Same operator as sn_ln_gemm_gate (LayerNorm2d -> body[0] 1x1 -> RepConv2 -> SimpleGate, gshift_deblur1.py:19-28,190-198)
- * for C = 64 with the depthwise 3x3 as Toeplitz MFMAs and g1 written channel-planar [T][h][C][sn_planar_pitch(w)].
- * wfrag / bias: as for sn_ln_gemm_gate; ttab3: bf16 [C/16][32][3][2][20] band records (prep.pack_toeplitz_dw3_chunks).
- * pool: NULL or [T][sn_lngatem_blocks(h,w)][C] per-workgroup sums of g1 (denoise CALayer2). */
-int sn_lngatem_blocks(int h, int w);
-int sn_ln_gemm_gate_m(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, const void* ttab3,
-                      void* g1p, float* pool, void* stream);
-
-/* Same operator as sn_dw5_gemm_gate (RepConv -> body 1x1 -> SimpleGate2 + channel sums, gshift_deblur2.py RepConv /
- * SimpleGate2 / CAB body), C = 64, with g1p channel-planar (natural channel order) and the 5x5 as Toeplitz MFMAs.
+/* g2 = SimpleGate2(body[4](RepConv(g1))) for the depthwise variants (gshift_deblur2.py:159-168,182-185,201): 5x5 + 3x3 +
+ * identity folded into one 5x5 and run as Toeplitz MFMAs on the channel-planar g1p, the 1x1 C -> 2C on MFMA, x1 * sigmoid(x2),
+ * per-workgroup channel sums for the CALayer2 that follows.  ca_in: NULL or [T][C] f32 scale applied first (denoise).  C = 64.
  * ttab: bf16 [C][5][2][20] padded bands (prep.pack_toeplitz), wfrag: body 1x1 fragments, gate-paired rows, natural K.
  * pool: [T][sn_dw5m_blocks(h,w)][C] partial sums of g2. */
 int sn_dw5m_blocks(int h, int w);

@@ -1,12 +1,11 @@
 // Grouped spatial-temporal shift unit (channel_shift -> CAB2 -> CAB1) for gfx950.
 //
-// Round-1 decomposition (one stencil or one GEMM per kernel, every intermediate NHWC bf16 in HBM):
-//   sn_gsts_shiftconv : hw = dw3x3(spatial_shift(borrowed half))         LDS-staged gather, never materialises the shift
-//   sn_ln_gemm        : a  = W1 . LN(cat(roll(x), hw))                   per-pixel, operands straight from HBM -> MFMA
-//   sn_dw_gate        : g1 = (a1 + dw3x3 a1) * (a2 + dw3x3 a2)           VALU stencil, weights in SGPRs
-//   sn_dw_gemm_gate   : g2 = gate2(W2 . (g1 + dw5x5 g1 + dw3x3 g1)) + channel sums     stencil -> LDS -> MFMA
-//   (sn_ca_mlp)       : ca = sigmoid(Wb relu(Wa mean(g2)))
-//   sn_scale_gemm_res : y  = roll(x) + beta * W3 . (ca * g2)             per-pixel MFMA, rolled shortcut
+// Production kernels of this file:
+//   sn_gsts_shiftconv (K0): hw = dw3x3(spatial_shift(borrowed half))     LDS-staged gather, never materialises the shift
+//   sn_scale_gemm_res (K4): y  = roll(x) + beta * W3 . (ca * g2)         per-pixel MFMA, rolled shortcut
+//   sn_gsts_gather / sn_temporal_roll: validation op / Shift_CAB roll (pure index work)
+// -DSN_EXPERIMENTAL additionally builds the round-1 chain (one stencil or one GEMM per kernel, every intermediate in HBM):
+//   sn_ln_gemm, sn_dw_gate, sn_dw_gemm_gate (include/shiftnet_hip_experimental.h)
 // The temporal roll is only ever an address computation (frame/channel-offset pairs below).
 #include "sn_common.h"
 #include "../../include/shiftnet_hip.h"
@@ -148,6 +147,7 @@ __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const int
     }
 }
 
+#ifdef SN_EXPERIMENTAL   // round-1 five-kernel chain (K1, K2, K3): off the production path, kept for A/B measurements
 // ------------------------------------------------------------------------------------------------------------
 // K1: LayerNorm over K channels (affine folded into the weights) + 1x1 conv to 2C, operands straight from HBM.
 template <int C, bool WITH_HW>
@@ -395,6 +395,8 @@ __global__ __launch_bounds__(256) void dw_gemm_gate_kernel(const bf16_t* __restr
     }
 }
 
+#endif  // SN_EXPERIMENTAL
+
 // ------------------------------------------------------------------------------------------------------------
 // K4: y = shortcut + W3' . (ca * g2) (+ bias'), beta folded into W3'/bias'; shortcut = rolled x (CAB2) or x (CAB1)
 template <int C>
@@ -497,16 +499,17 @@ int sn_gsts_shiftconv(const sn_unit_src* s, const int8_t* offs, const uint32_t* 
     dim3 grid((s->w + 15) / 16, (s->h + 15) / 16, s->T);
     if (s->C == 64) {
         const size_t lds = 34 * 34 * (32 * 2 + 4);
-        (void)hipFuncSetAttribute((const void*)shiftconv_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipFuncSetAttribute((const void*)shiftconv_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH;
         hipLaunchKernelGGL(shiftconv_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, to_k(s), offs, w1, (bf16_t*)hw);
     } else {
         const size_t lds = 34 * 34 * (40 * 2 + 4);
-        (void)hipFuncSetAttribute((const void*)shiftconv_kernel<40>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipFuncSetAttribute((const void*)shiftconv_kernel<40>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH;
         hipLaunchKernelGGL(shiftconv_kernel<40>, grid, dim3(256), lds, (hipStream_t)stream, to_k(s), offs, w1, (bf16_t*)hw);
     }
     return sn_check_launch();
 }
 
+#ifdef SN_EXPERIMENTAL
 int sn_ln_gemm(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, void* a, void* stream) {
     sn_clear_error();
     if (!unit_ok(s) || !wfrag || !bias || !a || (s->mode != 0 && !hw)) return SN_EINVAL;
@@ -547,6 +550,8 @@ int sn_dw_gemm_gate(const void* g1, const float* ca_in, const float* w5, const v
     else hipLaunchKernelGGL(dw_gemm_gate_kernel<80>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)g1, ca_in, w5, (const uint4*)wfrag, (bf16_t*)g2, pool, h, w);
     return sn_check_launch();
 }
+
+#endif  // SN_EXPERIMENTAL
 
 int sn_scale_gemm_res(const sn_unit_src* s, const void* g2, const float* ca, const void* wfrag, const float* bias,
                       void* y, void* stream) {

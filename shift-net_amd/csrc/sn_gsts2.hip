@@ -37,7 +37,12 @@ __device__ __forceinline__ Slabs2 unit_slabs2(const UnitK2& U, int t) {
 template <int C, bool WITH_HW>
 __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const UnitK2 U, const bf16_t* __restrict__ hwb, const uint4* __restrict__ wfrag,
                                                          const float* __restrict__ bias, const uint32_t* __restrict__ wdw,
-                                                         bf16_t* g1, float* pool, const int blocked, const int dbg, unsigned long long* prof) {
+                                                         bf16_t* g1, float* pool, const int blocked, const int dbg_, unsigned long long* prof_) {
+#ifdef SN_EXPERIMENTAL
+    const int dbg = dbg_; unsigned long long* const prof = prof_;                 // ablation / phase-clock hooks (tools/prof_k12.py)
+#else
+    constexpr int dbg = 0; constexpr unsigned long long* prof = nullptr;          // production: the hooks fold away
+#endif
     constexpr int CH = C / 2, K = WITH_HW ? C + CH : C, KS = (K + 31) / 32, MT = C / 8, NCHK = MT / 2;
     constexpr int TH = SN_K12_TH, TW = 32, RH = TH + 2, RW = TW + 2, NPX = RH * RW;  // tile + 1-pixel ring (8x32: 340 px, 16x32: 612 px)
     constexpr int NWV = SN_K12_NWV;                                                // waves per workgroup
@@ -246,6 +251,7 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
     }
 }
 
+#ifdef SN_EXPERIMENTAL   // K3': VALU 5x5 stencil, superseded by the matrix-core stencil kernel in sn_gsts3.hip
 // ------------------------------------------------------------------------------------------------------------
 // K3' (C = 64, depthwise RepConv): tile 64 x 4 pixels.  Four passes of 16 channels: stage the g1 region (+2 ring),
 // run the 5x5 stencil (wave = 4-channel block, lane = pixel column, 4 output rows with full vertical reuse, one kernel
@@ -419,6 +425,8 @@ __global__ __launch_bounds__(256) void dw5_gemm_gate_kernel(const bf16_t* __rest
     }
 }
 
+#endif  // SN_EXPERIMENTAL
+
 // ------------------------------------------------------------------------------------------------------------
 // K3g ("+" variants, RepConv with groups = C/8): grouped 5x5 (+3x3 +identity folded) as a block-diagonal MFMA GEMM
 // (one M-tile = two groups of 8 output channels, K = 25 taps x their 16 input channels, half of each A fragment is zero),
@@ -566,17 +574,24 @@ __global__ __launch_bounds__(256) void grp5_gemm_gate_kernel(const bf16_t* __res
 
 extern "C" {
 
-static int g_sn_debug = 0;
+#ifdef SN_EXPERIMENTAL
+static int g_sn_debug = 0;                      /* process-global profiling switches: experimental build only */
 int sn_debug_set(int v) { g_sn_debug = v; return 0; }
 int sn_debug_get(void) { return g_sn_debug; }
 static void* g_sn_debug_buf = nullptr;          /* optional device buffer for in-kernel cycle counters (tools/) */
 int sn_debug_buf_set(void* p) { g_sn_debug_buf = p; return 0; }
-void* sn_debug_buf_get(void) { return g_sn_debug_buf; }   /* profiling ablations only (tools/); 0 in production */
+void* sn_debug_buf_get(void) { return g_sn_debug_buf; }
+#define SN_DBG_MASK g_sn_debug
+#define SN_DBG_BUF(bit) ((unsigned long long*)((g_sn_debug & (bit)) ? g_sn_debug_buf : nullptr))
 
 #ifndef SN_DW5_TY
 #define SN_DW5_TY 4
 #endif
 int sn_dw5_blocks(int h, int w) { return ((h + SN_DW5_TY - 1) / SN_DW5_TY) * ((w + 63) / 64); }
+#else
+#define SN_DBG_MASK 0
+#define SN_DBG_BUF(bit) ((unsigned long long*)nullptr)
+#endif
 
 int sn_lngate_blocks(int h, int w) { return (SN_K12_TH * 32 / 64) * ((h + SN_K12_TH - 1) / SN_K12_TH) * ((w + 31) / 32); }
 
@@ -589,13 +604,14 @@ int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, con
     dim3 grid((s->w + 31) / 32, (s->h + SN_K12_TH - 1) / SN_K12_TH, s->T);
     hipStream_t st = (hipStream_t)stream;
 #define SN_LAUNCH_K12(CC, HW_) hipLaunchKernelGGL((ln_gemm_gate_kernel<CC, HW_>), grid, dim3(SN_K12_NWV * 64), 0, st, u, (const bf16_t*)hw, \
-        (const uint4*)wfrag, bias, wdw, (bf16_t*)g1, pool, g1_blocked, g_sn_debug, (unsigned long long*)((g_sn_debug & 256) ? g_sn_debug_buf : nullptr))
+        (const uint4*)wfrag, bias, wdw, (bf16_t*)g1, pool, g1_blocked, SN_DBG_MASK, SN_DBG_BUF(256))
     if (s->C == 64) { if (s->mode) SN_LAUNCH_K12(64, true); else SN_LAUNCH_K12(64, false); }
     else { if (s->mode) SN_LAUNCH_K12(80, true); else SN_LAUNCH_K12(80, false); }
 #undef SN_LAUNCH_K12
     return sn_check_launch();
 }
 
+#ifdef SN_EXPERIMENTAL
 int sn_dw5_gemm_gate(const void* g1, const float* ca_in, const uint32_t* w5, const void* wfrag, void* g2, float* pool,
                      int T, int h, int w, int C, void* stream) {
     sn_clear_error();
@@ -607,6 +623,8 @@ int sn_dw5_gemm_gate(const void* g1, const float* ca_in, const uint32_t* w5, con
     return sn_check_launch();
 }
 
+#endif  // SN_EXPERIMENTAL
+
 int sn_grp5_blocks(int h, int w) { return ((h + 3) / 4) * ((w + 31) / 32); }
 
 int sn_grp5_gemm_gate(const void* g1, const float* ca_in, const void* wgrp, const void* wfrag, void* g2, float* pool,
@@ -615,8 +633,8 @@ int sn_grp5_gemm_gate(const void* g1, const float* ca_in, const void* wgrp, cons
     if (!g1 || !wgrp || !wfrag || !g2 || C != 80) return SN_EINVAL;
     dim3 grid((w + 31) / 32, (h + 3) / 4, T);
     const size_t lds = (size_t)(8 * 36 + 4 * 32) * (C * 2 + 16) + 4 * C * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)grp5_gemm_gate_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    sn_clear_error();
+    if (hipFuncSetAttribute((const void*)grp5_gemm_gate_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return SN_ELAUNCH;
     hipLaunchKernelGGL(grp5_gemm_gate_kernel<80>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)g1, ca_in,
                        (const uint4*)wgrp, (const uint4*)wfrag, (bf16_t*)g2, pool, h, w);
     return sn_check_launch();

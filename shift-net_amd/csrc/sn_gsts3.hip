@@ -21,7 +21,6 @@
 //     of the M-tiles, A fragments resident in registers), SimpleGate2, NHWC stores, channel sums.
 //   sn_nhwc_to_planar: layout change for A/B tests and for producers that still write NHWC.
 #include "sn_common.h"
-#include <stdlib.h>
 #include "../../include/shiftnet_hip.h"
 
 namespace {
@@ -43,8 +42,13 @@ template <int TH> struct K3mShape {
 template <int TH>
 __global__ __launch_bounds__(K3mShape<TH>::NTHR, TH == 8 ? 1 : 4)
 void dw5m_gemm_gate_kernel(const bf16_t* __restrict__ g1p, const float* __restrict__ ca_in, const uint32_t* __restrict__ ttab,
-                           const uint4* __restrict__ wfrag, bf16_t* g2, float* pool, int T, int h, int w, int wr, const int dbg,
-                           unsigned long long* prof) {
+                           const uint4* __restrict__ wfrag, bf16_t* g2, float* pool, int T, int h, int w, int wr, const int dbg_,
+                           unsigned long long* prof_) {
+#ifdef SN_EXPERIMENTAL
+    const int dbg = dbg_; unsigned long long* const prof = prof_;                 // ablation / phase-clock hooks (tools/prof_k3m.py)
+#else
+    constexpr int dbg = 0; constexpr unsigned long long* prof = nullptr;          // production: the hooks fold away
+#endif
     using SH = K3mShape<TH>;
     constexpr int C = K3M_C, TW = K3M_TW, RH = SH::RH, RX = K3M_RX, CHK = K3M_CHK, KS = 2, RP = SH::RPITCH;
     constexpr int NWV = SH::NWV, NTHR = SH::NTHR, NBUF = SH::NBUF, GIMG_BYTES = SH::GIMG_BYTES;
@@ -253,6 +257,7 @@ void dw5m_gemm_gate_kernel(const bf16_t* __restrict__ g1p, const float* __restri
     }
 }
 
+#ifdef SN_EXPERIMENTAL   // K12m: parity green, not faster than sn_ln_gemm_gate yet; off the production path
 // ------------------------------------------------------------------------------------------------------------
 // K12m: g1 = SimpleGate(RepConv2(body[0](norm(u)))) for C = 64 with the depthwise 3x3 on the matrix cores, g1 written
 // channel-planar.  Same chunk pipeline as sn_ln_gemm_gate (LayerNorm'd operands resident in registers, the 2C-channel
@@ -465,6 +470,8 @@ __global__ __launch_bounds__(512) void ln_gemm_gate_m_kernel(const UnitK3 U, con
     }
 }
 
+#endif  // SN_EXPERIMENTAL
+
 // NHWC [T][h][w][C] -> planar [T][h][C][wr] (pad columns zero).  64-pixel row segments through LDS.
 __global__ __launch_bounds__(256) void nhwc_to_planar_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ xp, int h, int w, int C, int wr) {
     __shared__ bf16_t tile[64][136];              // [px][channel], C <= 128; row pitch 272 B
@@ -491,29 +498,38 @@ __global__ __launch_bounds__(256) void nhwc_to_planar_kernel(const bf16_t* __res
 
 extern "C" {
 int sn_planar_pitch(int w);
+#ifdef SN_EXPERIMENTAL
 int sn_debug_get(void);
 void* sn_debug_buf_get(void);
+#endif
 }
+#ifdef SN_EXPERIMENTAL
+#define SN3_DBG_MASK sn_debug_get()
+#define SN3_DBG_BUF(bit) ((unsigned long long*)((sn_debug_get() & (bit)) ? sn_debug_buf_get() : nullptr))
+#else
+#define SN3_DBG_MASK 0
+#define SN3_DBG_BUF(bit) ((unsigned long long*)nullptr)
+#endif
 
 template <int TH>
 static int launch_k3m(const void* g1p, const float* ca_in, const void* ttab, const void* wfrag, void* g2, float* pool, int T, int h, int w,
                       void* stream) {
     using SH = K3mShape<TH>;
     const int ntiles = T * ((h + TH - 1) / TH) * ((w + K3M_TW - 1) / K3M_TW);
-    const int maxwg = 256 * (TH == 8 ? 1 : 2);              // persistent: one / two workgroups per CU (LDS-limited)
+    int dev = 0, ncu = 0;                                   // persistent: one / two workgroups per CU of THIS device (LDS-limited)
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1)
+        return SN_ELAUNCH;
+    const int maxwg = ncu * (TH == 8 ? 1 : 2);
     const int nwg = ntiles < maxwg ? ntiles : maxwg;
-    (void)hipFuncSetAttribute((const void*)dw5m_gemm_gate_kernel<TH>, hipFuncAttributeMaxDynamicSharedMemorySize, SH::LDS);
+    if (hipFuncSetAttribute((const void*)dw5m_gemm_gate_kernel<TH>, hipFuncAttributeMaxDynamicSharedMemorySize, SH::LDS) != hipSuccess)
+        return SN_ELAUNCH;
     sn_clear_error();
     hipLaunchKernelGGL(dw5m_gemm_gate_kernel<TH>, dim3(nwg), dim3(SH::NTHR), SH::LDS, (hipStream_t)stream, (const bf16_t*)g1p, ca_in,
-                       (const uint32_t*)ttab, (const uint4*)wfrag, (bf16_t*)g2, pool, T, h, w, sn_planar_pitch(w), sn_debug_get(),
-                       (unsigned long long*)((sn_debug_get() & 512) ? sn_debug_buf_get() : nullptr));
+                       (const uint32_t*)ttab, (const uint4*)wfrag, (bf16_t*)g2, pool, T, h, w, sn_planar_pitch(w), SN3_DBG_MASK, SN3_DBG_BUF(512));
     return sn_check_launch();
 }
 
 extern "C" {
-
-int sn_debug_get(void);
-void* sn_debug_buf_get(void);
 
 int sn_planar_pitch(int w) { return (w + 7) & ~7; }
 
@@ -525,6 +541,7 @@ int sn_nhwc_to_planar(const void* x, void* xp, int T, int h, int w, int C, void*
     return sn_check_launch();
 }
 
+#ifdef SN_EXPERIMENTAL
 int sn_lngatem_blocks(int h, int w) { return ((h + K12M_TH - 1) / K12M_TH) * ((w + K12M_TW - 1) / K12M_TW); }
 
 int sn_ln_gemm_gate_m(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, const void* ttab3,
@@ -537,39 +554,34 @@ int sn_ln_gemm_gate_m(const sn_unit_src* s, const void* hw, const void* wfrag, c
     hipStream_t st = (hipStream_t)stream;
     const int wr = sn_planar_pitch(s->w);
     if (s->mode) {
-        (void)hipFuncSetAttribute((const void*)ln_gemm_gate_m_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, K12M_LDS);
+        if (hipFuncSetAttribute((const void*)ln_gemm_gate_m_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, K12M_LDS) != hipSuccess) return SN_ELAUNCH;
         sn_clear_error();
         hipLaunchKernelGGL(ln_gemm_gate_m_kernel<true>, grid, dim3(512), K12M_LDS, st, u, (const bf16_t*)hw, (const uint4*)wfrag, bias,
-                           (const uint32_t*)ttab3, (bf16_t*)g1p, pool, wr, (unsigned long long*)((sn_debug_get() & 256) ? sn_debug_buf_get() : nullptr));
+                           (const uint32_t*)ttab3, (bf16_t*)g1p, pool, wr, SN3_DBG_BUF(256));
     } else {
-        (void)hipFuncSetAttribute((const void*)ln_gemm_gate_m_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, K12M_LDS);
+        if (hipFuncSetAttribute((const void*)ln_gemm_gate_m_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, K12M_LDS) != hipSuccess) return SN_ELAUNCH;
         sn_clear_error();
         hipLaunchKernelGGL(ln_gemm_gate_m_kernel<false>, grid, dim3(512), K12M_LDS, st, u, (const bf16_t*)hw, (const uint4*)wfrag, bias,
-                           (const uint32_t*)ttab3, (bf16_t*)g1p, pool, wr, (unsigned long long*)((sn_debug_get() & 256) ? sn_debug_buf_get() : nullptr));
+                           (const uint32_t*)ttab3, (bf16_t*)g1p, pool, wr, SN3_DBG_BUF(256));
     }
     return sn_check_launch();
 }
+#endif  // SN_EXPERIMENTAL
 
-// shape of sn_dw5m_gemm_gate: tile height 8 (one 1024-thread workgroup per CU, default: 381 us at level 1) or 4 (two
-// 512-thread workgroups per CU: 432 us, the extra halo rows and barriers cost more than the interleaving gains);
-// SN_K3M_TH overrides it for A/B measurements.  Read once: the pool layout (sn_dw5m_blocks) depends on it.
-static int k3m_th() {
-    static int th = 0;
-    if (!th) {
-        const char* e = getenv("SN_K3M_TH");
-        th = (e && atoi(e) == 4) ? 4 : 8;
-    }
-    return th;
-}
+// Tile height of sn_dw5m_gemm_gate: 8 = one 1024-thread workgroup per CU (381 us at level 1).  The experimental build can
+// also compile the 4-row shape (two 512-thread workgroups per CU: 432 us, more halo rows and barriers than the interleaving
+// wins back) with -DSN_K3M_TH=4; it is a compile-time choice, the library reads no environment and keeps no state.
+#ifndef SN_K3M_TH
+#define SN_K3M_TH 8
+#endif
 
-int sn_dw5m_blocks(int h, int w) { const int th = k3m_th(); return ((h + th - 1) / th) * ((w + K3M_TW - 1) / K3M_TW); }
+int sn_dw5m_blocks(int h, int w) { return ((h + SN_K3M_TH - 1) / SN_K3M_TH) * ((w + K3M_TW - 1) / K3M_TW); }
 
 int sn_dw5m_gemm_gate(const void* g1p, const float* ca_in, const void* ttab, const void* wfrag, void* g2, float* pool,
                       int T, int h, int w, int C, void* stream) {
     sn_clear_error();
     if (!g1p || !ttab || !wfrag || !g2 || C != 64 || T < 1 || h < 1 || w < 1) return SN_EINVAL;
-    return k3m_th() == 8 ? launch_k3m<8>(g1p, ca_in, ttab, wfrag, g2, pool, T, h, w, stream)
-                         : launch_k3m<4>(g1p, ca_in, ttab, wfrag, g2, pool, T, h, w, stream);
+    return launch_k3m<SN_K3M_TH>(g1p, ca_in, ttab, wfrag, g2, pool, T, h, w, stream);
 }
 
 }  // extern "C"

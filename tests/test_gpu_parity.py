@@ -214,15 +214,15 @@ def test_cab(name, pre, c, engines):
     check(f"cab_{name}_{pre}", to_cpu(out.t, c), O.cab(sd, pre, x), 8e-3)
 
 
-@pytest.mark.parametrize("gsts_v", [3, 2, 1, 0])
 @pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_denoise2", "gshift_deblur1", "gshift_denoise1"])
-def test_gsts_pieces(name, gsts_v, engines):
-    """shiftconv alone, then CAB2 (both directions), CAB1, a whole unit and a whole Encoder_shift_block.
+def test_gsts_pieces(name, engines):
+    """shiftconv alone, then CAB2 (both directions), CAB1, a whole unit and a whole Encoder_shift_block (production chain)."""
+    _gsts_pieces(engines(name), name, "")
 
-    gsts_v = 1: fused LN+1x1+dw3x3+gate and LDS-staged dw5x5+1x1+gate kernels; 0: the five-kernel chain."""
+
+def _gsts_pieces(eng_sd, name, tag):
     from shiftnet_amd import lib as L
-    eng, sd = engines(name)
-    eng.gsts_v = gsts_v
+    eng, sd = eng_sd
     V = O.VARIANTS[name]
     C, T, h, w = V.c1, 4, 20, 44
     x = bf(torch.from_numpy(synth.unit_noise((T, C, h, w), seed=81)))
@@ -238,19 +238,18 @@ def test_gsts_pieces(name, gsts_v, engines):
         hw_ref = torch.nn.functional.conv2d(O.spatial_shift(hw_ref.contiguous()), sd[pre + "conv1.weight"], padding=1, groups=C // 2)
         check(f"shiftconv_{name}_{mode}", to_cpu(hwb, C // 2), hw_ref, 8e-3)
         out = eng.naf(pre, xd, mode)
-        check(f"cab2_v{gsts_v}_{name}_{mode}", to_cpu(out.t, C), O.cab2(sd, pre, O.gsts_gather(x, rev, V.wrap), V), 8e-3)
+        check(f"cab2{tag}_{name}_{mode}", to_cpu(out.t, C), O.cab2(sd, pre, O.gsts_gather(x, rev, V.wrap), V), 8e-3)
     pre = blk + "encoder_level1.1."
     out = eng.naf(pre, xd, 0)
-    check(f"cab1_v{gsts_v}_{name}", to_cpu(out.t, C), O.cab1(sd, pre, x, V), 8e-3)
+    check(f"cab1{tag}_{name}", to_cpu(out.t, C), O.cab1(sd, pre, x, V), 8e-3)
     out = eng.gsts_unit(blk + "encoder_level1_1.", xd, True)
-    check(f"unit_rev_v{gsts_v}_{name}", to_cpu(out.t, C), O.gsts_unit(sd, blk + "encoder_level1_1.", x, True, V), 1.2e-2)
+    check(f"unit_rev{tag}_{name}", to_cpu(out.t, C), O.gsts_unit(sd, blk + "encoder_level1_1.", x, True, V), 1.2e-2)
     out = eng.shift_block(blk, xd)
-    check(f"shift_block_v{gsts_v}_{name}", to_cpu(out.t, C), O.shift_block(sd, blk, x, V), 4e-2)
+    check(f"shift_block{tag}_{name}", to_cpu(out.t, C), O.shift_block(sd, blk, x, V), 4e-2)
     # ragged sizes: partial tiles in both kernels' tilings
     x2 = bf(torch.from_numpy(synth.unit_noise((2, C, 13, 70), seed=82)))
     out = eng.gsts_unit(blk + "encoder_level1.", act(to_dev(x2), C), False)
-    check(f"unit_fwd_ragged_v{gsts_v}_{name}", to_cpu(out.t, C), O.gsts_unit(sd, blk + "encoder_level1.", x2, False, V), 1.2e-2)
-    eng.gsts_v = 2
+    check(f"unit_fwd_ragged{tag}_{name}", to_cpu(out.t, C), O.gsts_unit(sd, blk + "encoder_level1.", x2, False, V), 1.2e-2)
 
 
 def C_byref(s):

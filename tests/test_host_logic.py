@@ -26,6 +26,16 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(lib, s)
     assert lib.sn_abi_version() == 1
+    # the experimental header's symbols live ONLY in the -DSN_EXPERIMENTAL build; the production library must not export them
+    out_exp = mod.build(experimental=True)
+    exp_hdr = open(os.path.join(ROOT, "include", "shiftnet_hip_experimental.h")).read()
+    exp_decl = sorted(set(re.findall(r"^(?:int|void\*) (sn\d*_\w+)\(", exp_hdr, flags=re.M)))
+    assert exp_decl == sorted(L.EXPERIMENTAL_SYMBOLS)
+    libx = ctypes.CDLL(out_exp)
+    for s in exp_decl:
+        assert hasattr(libx, s) and not hasattr(lib, s), s
+    for s in declared:
+        assert hasattr(libx, s), s
     # argument validation is host side and must not need a GPU
     assert lib.sn_conv2d(None, None) == -22
     d = L.ConvDesc(); d.stride, d.mt, d.n_in, d.cs_in, d.h_out, d.w_out = 1, 1, 1, 16, 720, 1280

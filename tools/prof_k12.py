@@ -6,12 +6,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "shift-net_amd")):
     sys.path.insert(0, p)
+os.environ["SN_EXPERIMENTAL"] = "1"          # the phase clocks exist only in the -DSN_EXPERIMENTAL library
 import torch  # noqa: E402
 
 
 def main():
     from shiftnet_amd import lib as L
-    from shiftnet_amd.engine import Act, Engine, Plan
+    from shiftnet_amd.engine import Act, Plan
+    from shiftnet_amd.engine_experimental import ExperimentalEngine as Engine
     from shiftnet_amd.spec import VARIANTS
     from shiftnet_amd.weights import synth_state_dict
     dev = torch.device("cuda:0")

@@ -7,6 +7,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "shift-net_amd")):
     sys.path.insert(0, p)
+os.environ["SN_EXPERIMENTAL"] = "1"          # the phase clocks exist only in the -DSN_EXPERIMENTAL library
 import torch  # noqa: E402
 
 
