@@ -25,13 +25,27 @@ for p in (ROOT, os.path.join(ROOT, "shift-net_amd")):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PMC_FILE = "r01_v3_pmc_hbm_traffic_unit_L1.json"      # rocprofv3 --pmc passes of tools/bench_unit.py, summarised by tools/pmc_summary.py
+PMC_FILE = "r02_pmc_hbm_traffic_bench_window.json"    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very command (tools/make_profiles_r02.sh)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 VARIANT = "gshift_deblur2"
 H, W, ONE_LEN = 720, 1280, 16
 # elements per full-res pixel: stage0+stage1 per INPUT frame, stage2 per OUTPUT frame
 ELEMS = {"gshift_deblur2": (765.2 + 2180.0, 765.2), "gshift_deblur1": (2268.0 + 2866.5, 2268.0),
          "gshift_denoise2": (766.2 + 2194.0, 765.2), "gshift_denoise1": (2269.0 + 2962.5, 2268.0)}
+
+
+# BASELINE.json configs as bench presets (config 1 is the CPU case: it is the `cpu_baseline` leg and tests/test_gpu_fp32.py)
+CONFIGS = {
+    2: dict(variant="gshift_deblur2", height=720, width=1280, one_len=16, dtype="bf16", quadrants=False),
+    3: dict(variant="gshift_deblur1", height=720, width=1280, one_len=48, dtype="bf16", quadrants=False),
+    # config 4: davis_denoise sigma 30, 854x480 T=32: the CLI crops to 852x480 and runs 4 overlapping quadrants of 272x448
+    # (inference/test_denoise.py:153-173); upstream keeps this model in float32 (:83-85) -> --dtype fp32 is the reference
+    # arithmetic, bf16 the fast path
+    4: dict(variant="gshift_denoise1", height=480, width=852, one_len=32, dtype="bf16", quadrants=True),
+    # config 5's per-GPU window: 1920x1080, 96 restored frames over 8 GPUs = one_len 12 each (weak scaling with --gpus N)
+    5: dict(variant="gshift_deblur1", height=1080, width=1920, one_len=12, dtype="bf16", quadrants=False),
+}
+DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
 
 
 def algorithmic_bytes_window(variant, h, w, t_in, t_out, s=2):
@@ -90,7 +104,7 @@ def cpu_baseline_subprocess(timeout_s=240):
                 "sample": f"cpu leg exceeded {timeout_s} s and was stopped"}
 
 
-def cpu_baseline(budget_s=7.0):
+def cpu_baseline(budget_s=6.0):
     """The CPU oracle (a port of the reference forward, kind 'port') timed on this host's cores on a bounded sample."""
     from oracle import shiftnet_oracle as O
     from shiftnet_amd import synth
@@ -115,9 +129,12 @@ def cpu_baseline(budget_s=7.0):
     dt = run(5, hh, ww)
     per_pxf = dt / (5 * hh * ww)
     fps = ONE_LEN / ((ONE_LEN + 4) * H * W * per_pxf)
+    c1 = run(5, 256, 256)          # BASELINE config 1 in full: Shift-Net-s, fp32, one clip of T=5 256x256 (1 restored frame)
     return {"value": fps, "unit": "restored frames/s", "cores": cores, "kind": "port",
             "sample": f"oracle fp32 forward of {VARIANT} on T_in=5 {ww}x{hh} ({dt:.1f} s), cost/pixel/frame extrapolated "
-                      f"linearly to T_in=20 1280x720 (torch {torch.__version__}, {cores} threads)"}
+                      f"linearly to T_in=20 1280x720 (torch {torch.__version__}, {cores} threads)",
+            "config1_full": {"workload": "BASELINE config 1: Shift-Net-s fp32, 1 clip of T=5 256x256, past/future 2/2", "seconds": round(c1, 3),
+                             "restored_frames_per_s": round(1.0 / c1, 4), "input_frames_per_s": round(5.0 / c1, 3)}}
 
 
 def main():
@@ -132,7 +149,16 @@ def main():
     ap.add_argument("--one-len", type=int, default=ONE_LEN)
     ap.add_argument("--variant", default=VARIANT, choices=list(ELEMS),
                     help="default gshift_deblur2 = BASELINE config 2; the other variants are extra measurements")
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS), help="BASELINE.json config preset (default: 2)")
+    ap.add_argument("--dtype", default=None, choices=list(DTYPES), help="module dtype (fp32 runs the fp32 engine)")
+    ap.add_argument("--quadrants", action="store_true", help="denoise CLI tiling: 4 overlapping quadrants per step")
     args = ap.parse_args()
+    if args.config is not None:
+        c = CONFIGS[args.config]
+        args.variant, args.height, args.width, args.one_len = c["variant"], c["height"], c["width"], c["one_len"]
+        args.quadrants = c["quadrants"]
+        args.dtype = args.dtype or c["dtype"]
+    args.dtype = args.dtype or "bf16"
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline()))
         return
@@ -183,20 +209,32 @@ def main():
     from shiftnet_amd.weights import synth_state_dict
 
     h, w, L = args.height, args.width, args.one_len
+    dt = DTYPES[args.dtype]
     net = GShiftNet(future_frames=2, past_frames=2)
     net.load_state_dict(synth_state_dict(args.variant), strict=True)
-    net = net.to(torch.bfloat16).to(dev).eval()
+    net = net.to(dt).to(dev).eval()
     denoise = "denoise" in args.variant
-    sigma_map = torch.full((1, L + 4, 1, h, w), 30.0 / 255.0, dtype=torch.bfloat16, device=dev) if denoise else None
 
     # this rank's slice of one long synthetic clip: L owned frames (+ the clip edges on the first / last rank)
     blur, _ = synth.blurred_clip(L + 4, h, w, seed=100 + rank)
-    fr = (torch.from_numpy(blur).permute(0, 3, 1, 2).to(dev).to(torch.bfloat16) / 255).contiguous()
+    fr = (torch.from_numpy(blur).permute(0, 3, 1, 2).to(dev).to(dt) / 255).contiguous()
     own, first_edge, last_edge = fr[2:2 + L].contiguous(), fr[:2].contiguous(), fr[-2:].contiguous()
+    if args.quadrants:      # the denoise CLI's tiling (inference/test_denoise.py:153-173): 4 overlapping quadrants per window
+        pad_h, pad = 32 - (h // 2 % 16), 32 - (w // 2 % 16)
+        hh, ww = h // 2 + pad_h, w // 2 + pad
+        quads = [(0, hh, 0, ww), (0, hh, w // 2 - pad, w), (h // 2 - pad_h, h, 0, ww), (h // 2 - pad_h, h, w // 2 - pad, w)]
+        assert all(b - a == hh and d - c == ww for a, b, c, d in quads), (h, w, hh, ww)
+    else:
+        hh, ww, quads = h, w, [(0, h, 0, w)]
+    sigma_map = torch.full((1, L + 4, 1, hh, ww), 30.0 / 255.0, dtype=dt, device=dev) if denoise else None
 
     def step():
         win = assemble_window(own, first_edge, last_edge, rank, world)
-        return net(win.unsqueeze(0), sigma_map) if denoise else net(win.unsqueeze(0))
+        outs = []
+        for a, b, c, d in quads:
+            xq = win if len(quads) == 1 else win[:, :, a:b, c:d].contiguous()
+            outs.append(net(xq.unsqueeze(0), sigma_map) if denoise else net(xq.unsqueeze(0)))
+        return outs[0] if len(quads) == 1 else outs
 
     def barrier():
         if world > 1:
@@ -214,7 +252,8 @@ def main():
             out = step()
         barrier()
         elapsed = time.perf_counter() - t0
-    assert out.shape == (L, 3, h, w) and torch.isfinite(out.float()).all()
+    for o in (out if isinstance(out, list) else [out]):
+        assert o.shape == (L, 3, hh, ww) and torch.isfinite(o.float()).all()
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -252,35 +291,37 @@ def main():
         prof_copy = list(eng.prof)
         eng.prof = None
         dom = max(agg, key=lambda k: agg[k]["ms"])
-        # HBM traffic of the dominant kernel from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-        # passes, tools/bench_unit.py at the level-1 size), scaled by the pixels this bench's launches processed.
+        # HBM traffic of the dominant kernel from the committed PMC passes of THIS command (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE, separate passes, tools/make_profiles_r02.sh): per-launch average over the kernel's launches in the window,
+        # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950.
         traffic, traffic_note = None, "no PMC entry for this kernel under profiles/"
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))["kernels"]
-            sym = {"sn_dw5_gemm_gate": "dw5_gemm_gate_kernel", "sn_dw5m_gemm_gate": "dw5m_gemm_gate_kernel", "sn_ln_gemm_gate<cab2>": "ln_gemm_gate_kernel<64, true>",
+            sym = {"sn_dw5m_gemm_gate": "dw5m_gemm_gate_kernel", "sn_ln_gemm_gate<cab2>": "ln_gemm_gate_kernel<64, true>",
                    "sn_ln_gemm_gate<cab1>": "ln_gemm_gate_kernel<64, false>", "sn_scale_gemm_res": "scale_gemm_res_kernel<64>",
-                   "sn_gsts_shiftconv": "shiftconv_kernel<32>"}.get(dom)
+                   "sn_gsts_shiftconv": "shiftconv_kernel<32>", "sn_conv2d<mt1,8x32>": "conv3_fast_kernel<1, 16, 8>",
+                   "sn_conv2d<mt2,8x32>": "conv3_fast_kernel<2, 24, 8>"}.get(dom)
             ent = next((v for k, v in pmc.items() if sym and sym in k), None)
-            if ent and args.variant == VARIANT:
-                l1_px = 20 * 360 * 640
-                px = [m[1] * m[2] * m[3] for f, _, m, _, _ in prof_copy if m and m[0] == "naf" and dom.startswith(f)
-                      and ("<cab" not in dom or (m[5] != 0) == dom.endswith("<cab2>"))]
-                scale = sum(px) / (len(px) * l1_px)
-                traffic = round((ent["FETCH_SIZE_KB_per_launch"] + ent["WRITE_SIZE_KB_per_launch"]) * 1024 * scale / 1e9, 4)
-                traffic_note = ("GB per launch (average over this kernel's launches): raw FETCH_SIZE+WRITE_SIZE of the committed PMC run "
-                                "at the level-1 size, scaled by pixels; FETCH_SIZE may under-report wide reads on gfx950 (MI355X_MICROARCH.md)")
+            if ent and (args.variant, h, w, L, args.dtype) == (VARIANT, H, W, ONE_LEN, "bf16"):
+                traffic = round((2 * ent["FETCH_SIZE_KB_per_launch"] + ent["WRITE_SIZE_KB_per_launch"]) * 1024 / 1e9, 4)
+                traffic_note = ("GB per launch, average over this kernel's launches in the window: 2 x FETCH_SIZE + WRITE_SIZE of the "
+                                f"committed PMC passes of this command (profiles/{PMC_FILE})")
         except Exception as e:                                      # noqa: BLE001
             traffic_note = f"PMC file unreadable: {e}"
         ach = agg[dom]["bytes"] / (agg[dom]["ms"] * 1e-3) / 1e9
         kernels = {k: {"ms_total": round(v["ms"], 3), "launches": v["n"],
                        "gbps_algorithmic": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)} for k, v in agg.items()}
-        win_bytes = algorithmic_bytes_window(args.variant, h, w, L + 4, L)
+        sbytes = 4 if dt == torch.float32 else 2
+        win_bytes = len(quads) * algorithmic_bytes_window(args.variant, hh, ww, L + 4, L, s=sbytes)
         result = {
-            "metric": f"restored frames/sec at {w}x{h} T={L} bf16", "value": round(fps, 3), "unit": "frames/s",
+            "metric": f"restored frames/sec at {w}x{h} T={L} {'fp32' if dt == torch.float32 else 'bf16'}", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if dt == torch.float32 else "bf16", "data": "synthetic",
             "config": {"workload": f"{'Shift-Net-s' if args.variant.endswith('2') else 'Shift-Net+'} ({args.variant}), {w}x{h}, one_len={L} (T_in={L + 4}), "
-                                   "one window per GPU, synthetic checkpoint", "parallelism": f"clip-parallel x{world}"},
+                                   + ("as the denoise CLI's 4 quadrants of %dx%d, " % (ww, hh) if args.quadrants else "")
+                                   + (f"module dtype {args.dtype}, " if args.dtype != "bf16" else "")
+                                   + "one window per GPU, synthetic checkpoint", "parallelism": f"clip-parallel x{world}",
+                       "baseline_config": args.config if args.config is not None else (2 if (args.variant, h, w, L) == (VARIANT, H, W, ONE_LEN) else None)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_gb_per_launch": round(agg[dom]["bytes"] / agg[dom]["n"] / 1e9, 4),
@@ -292,7 +333,7 @@ def main():
                                    "frac": round(win_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "kernels": kernels,
         }
-        if world == 1 and args.variant == VARIANT:
+        if world == 1 and args.variant == VARIANT and args.dtype == "bf16":
             # parity sample next to the throughput: the same module on a small clip vs the CPU oracle (checker only)
             from oracle import shiftnet_oracle as O
             sd = synth_state_dict(VARIANT)
