@@ -431,142 +431,160 @@ __global__ __launch_bounds__(256) void dw5_gemm_gate_kernel(const bf16_t* __rest
 // K3g ("+" variants, RepConv with groups = C/8): grouped 5x5 (+3x3 +identity folded) as a block-diagonal MFMA GEMM
 // (one M-tile = two groups of 8 output channels, K = 25 taps x their 16 input channels, half of each A fragment is zero),
 // then the 1x1 C -> 2C, SimpleGate2 and the channel sums.  Tile 32 x 4 pixels, g1 region (+2 ring, all C channels) in LDS.
+//
+// Second generation.  The first one (one workgroup per tile, every wave walking ALL M-tiles of its 32 pixels) re-read
+// every weight fragment from L1/L2 for every 32 pixels: 125 KB of A operands per wave-tile against 5 KB of activations,
+// ~60 clk per pixel and CU on the vector-memory path alone (1120 us at the level-1 size of config 2 vs 381 us for the
+// depthwise kernel).  Here the WEIGHTS STAY IN REGISTERS: a persistent workgroup of 10 waves, wave (m, nh) owns M-tile m of
+// the grouped conv (13 fragments) and gate pair m of the 1x1 (6 fragments) for the four N-tiles of half nh of every tile it
+// walks, so the only operand traffic inside the tile loop is LDS reads of activations:
+//   stage (HBM -> registers one tile AHEAD -> LDS, optional CALayer2 scale) | grouped MFMAs -> r tile in LDS | 1x1 MFMAs,
+//   gate -> output tile in LDS (over the dead g1 region) | coalesced 16-byte NHWC stores + channel sums.
 template <int C>
-__global__ __launch_bounds__(256) void grp5_gemm_gate_kernel(const bf16_t* __restrict__ g1, const float* __restrict__ ca_in,
-                                                           const uint4* __restrict__ wgrp, const uint4* __restrict__ wfrag,
-                                                           bf16_t* g2, float* pool, int h, int w) {
+__global__ __launch_bounds__(640) void grp5p_gemm_gate_kernel(const bf16_t* __restrict__ g1, const float* __restrict__ ca_in,
+                                                            const uint4* __restrict__ wgrp, const uint4* __restrict__ wfrag,
+                                                            bf16_t* g2, float* pool, int T, int h, int w) {
     constexpr int TY = 4, TXW = 32, RH = TY + 4, RW = TXW + 4, PS = C * 2 + 16, MTG = C / 16, KSG = 13;
-    constexpr int MT = C / 8, KS = (C + 31) / 32, NPC = C / 8, NT = 2;
+    constexpr int KS = (C + 31) / 32, NPC = C / 8, NTL = (TY * TXW) / 16, NTWV = NTL / 2, NTHR = 64 * 2 * MTG;
+    constexpr int NITEM = RH * RW * NPC, NIT = (NITEM + NTHR - 1) / NTHR;
+    static_assert(C == 80 && NTHR == 640, "wave roles are laid out for C = 80 (5 group pairs x 2 pixel halves)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* lds_g = smem;                                  // [RH*RW][PS]
-    char* lds_r = smem + RH * RW * PS;                   // [TY*TXW][PS]
-    float* red = (float*)(lds_r + TY * TXW * PS);        // [4][C]
+    char* lds_g = smem;                                  // [RH*RW][PS] staged g1 region; reused as the [TY*TXW][PS] output tile
+    char* lds_r = smem + RH * RW * PS;                   // [TY*TXW][PS] RepConv output
+    float* red = (float*)(lds_r + TY * TXW * PS);        // [2][C]
     const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
-    const int t = blockIdx.z, y0 = blockIdx.y * TY, x0 = blockIdx.x * TXW;
-    const bf16_t* gt = g1 + (size_t)t * h * w * C;
+    const int m = wv % MTG, nh = wv / MTG;
+    const int tiles_x = (w + TXW - 1) / TXW, tiles_y = (h + TY - 1) / TY, tpf = tiles_x * tiles_y, ntiles = T * tpf;
 
-    {   // stage the region: all loads first (branch-free), then optional CALayer2 scale, mask and LDS write
-        constexpr int NIT = (RH * RW * NPC + 255) / 256;
-        uint4 v[NIT];
-        int lo[NIT];
+    // resident weights: the 13 grouped-conv fragments of M-tile m (52 VGPRs).  The 6 fragments of gate pair m (rows 2m, 2m+1 of
+    // the gate-paired order) are re-fetched once per tile, early enough to land during the grouped MFMAs: keeping them too
+    // pushes the kernel over the 168 registers that 10 waves per workgroup allow (scratch spills).
+    bf16x8_t A1[KSG];
+#pragma unroll
+    for (int s = 0; s < KSG; ++s) A1[s] = as_frag(wgrp[(m * KSG + s) * 64 + lane]);
+    // this wave's N-tiles: nt = NTWV*nh + n -> tile row nt >> 1, x block nt & 1
+    int pbase[NTWV];
+#pragma unroll
+    for (int n = 0; n < NTWV; ++n) {
+        const int nt = NTWV * nh + n, row = nt >> 1, xb = nt & 1;
+        pbase[n] = (row * RW + xb * 16 + p) * PS + (g & 1) * 16 + m * 32;
+    }
+    // staging plan (the same region items for every tile): item idx -> (region pixel, 16-byte piece), recomputed where needed
+    // (divisions by constants) instead of kept live
+    uint4 stg[NIT];
+    bool sin[NIT];
+    auto item = [&](int k, int& pix, int& pc) {
+        int idx = tid + k * NTHR;
+        asm volatile("" : "+v"(idx));                      // opaque: keeps LICM from hoisting (and then spilling) the results
+        pix = idx / NPC; pc = idx - pix * NPC;
+        return idx < NITEM;
+    };
+    auto issue_loads = [&](int tile) {                   // branch-free (clamped) loads; masks are applied at the LDS write
+        const int t = tile / tpf, rem = tile - t * tpf, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const bf16_t* gt = g1 + (size_t)t * h * w * C;
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
-            const int idx = tid + k * 256, pix = idx / NPC, pc = idx - pix * NPC;
-            const int ry = pix / RW, rx = pix - ry * RW, gy = y0 - 2 + ry, gx = x0 - 2 + rx;
-            const bool live = idx < RH * RW * NPC, in = live && gy >= 0 && gy < h && gx >= 0 && gx < w;
-            lo[k] = live ? (in ? pix * PS + pc * 16 : -(pix * PS + pc * 16) - 1) : 0x7fffffff;
-            v[k] = *(const uint4*)(gt + (in ? ((size_t)gy * w + gx) * C + pc * 8 : 0));
+            int pix, pc;
+            const bool live = item(k, pix, pc);
+            const int ry = pix / RW, rx = pix - ry * RW, gy = ty * TY - 2 + ry, gx = tx * TXW - 2 + rx;
+            sin[k] = live && gy >= 0 && gy < h && gx >= 0 && gx < w;
+            stg[k] = *(const uint4*)(gt + (sin[k] ? (gy * w + gx) * C + pc * 8 : 0));
         }
+    };
+
+    // persistent, XCD-aware walk (workgroup b runs on XCD b % 8): each XCD takes a contiguous eighth of the tile list
+    const int nxcd = (gridDim.x % 8 == 0) ? 8 : 1, wpx = gridDim.x / nxcd, seg = (ntiles + nxcd - 1) / nxcd;
+    const int seg0 = (blockIdx.x % nxcd) * seg, seg1 = seg0 + seg < ntiles ? seg0 + seg : ntiles;
+    int tile = seg0 + blockIdx.x / nxcd;
+    if (tile < seg1) issue_loads(tile);
+    for (; tile < seg1; tile += wpx) {
+        const int t = tile / tpf, rem = tile - t * tpf, tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
+        const int y0 = tyi * TY, x0 = txi * TXW;
+        // ---- registers -> LDS (optional CALayer2 scale of the denoise variants), then prefetch the next tile ----
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
-            if (lo[k] == 0x7fffffff) continue;
-            const bool in = lo[k] >= 0;
-            const int off = in ? lo[k] : -(lo[k] + 1);
-            uint4 q = in ? v[k] : make_uint4(0, 0, 0, 0);
-            if (ca_in && in) {
-                const int pc = (off % PS) >> 4;
+            int pix, pc;
+            if (!item(k, pix, pc)) continue;
+            uint4 q = sin[k] ? stg[k] : make_uint4(0, 0, 0, 0);
+            if (ca_in && sin[k]) {
                 float f[8];
                 unpack8(q, f);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] *= ca_in[(size_t)t * C + pc * 8 + j];
                 q = pack8(f);
             }
-            *(uint4*)(lds_g + off) = q;
+            *(uint4*)(lds_g + pix * PS + pc * 16) = q;
         }
-    }
-    __syncthreads();
-
-    // ---- grouped 5x5: k-step s covers taps 2s, 2s+1; lane group g -> tap 2s + (g>>1), input channels 16*mt + (g&1)*8 ..
-    {
-        f32x4_t acc[MTG][NT];
-#pragma unroll
-        for (int m = 0; m < MTG; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        int pbase[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int nt = wv * NT + n, row = nt >> 1, xb = nt & 1;
-            pbase[n] = (row * RW + xb * 16 + p) * PS + (g & 1) * 16;
+        __syncthreads();
+        {
+            const int ntile = tile + wpx < seg1 ? tile + wpx : tile;      // past the end: re-read this tile (harmless)
+            issue_loads(ntile);
         }
-#pragma unroll 1
-        for (int s = 0; s < KSG; ++s) {
-            int tap = 2 * s + (g >> 1);
-            tap = tap < 25 ? tap : 0;                     // the 26th slot has zero weights: any valid address will do
-            const int dy = tap / 5, dx = tap - dy * 5;
-            const int toff = (dy * RW + dx) * PS;
-#pragma unroll
-            for (int m = 0; m < MTG; ++m) {
-                const bf16x8_t a = as_frag(wgrp[(m * KSG + s) * 64 + lane]);
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[m][n] = mfma16(a, as_frag(*(const uint4*)(lds_g + pbase[n] + toff + m * 32)), acc[m][n]);
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < MTG; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                uint2 o; o.x = pack_bf2(acc[m][n][0], acc[m][n][1]); o.y = pack_bf2(acc[m][n][2], acc[m][n][3]);
-                *(uint2*)(lds_r + ((wv * NT + n) * 16 + p) * PS + (m * 16 + g * 4) * 2) = o;
-            }
-    }
-    __syncthreads();
-
-    // ---- 1x1 C -> 2C (gate-paired rows), SimpleGate2, stores, channel sums ----
-    float ps[MT / 2][4];
-#pragma unroll
-    for (int mp = 0; mp < MT / 2; ++mp)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) ps[mp][rr] = 0.f;
-#pragma unroll 1
-    for (int n = 0; n < NT; ++n) {
-        const int tp = (wv * NT + n) * 16 + p;
-        bf16x8_t Bf[KS];
+        bf16x8_t A2[2][KS];                                // gate-pair fragments: in flight while the grouped MFMAs run
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const int kk0 = s * 32 + g * 8;
-            Bf[s] = as_frag(kk0 < C ? *(const uint4*)(lds_r + tp * PS + kk0 * 2) : make_uint4(0, 0, 0, 0));
+            A2[0][s] = as_frag(wfrag[((2 * m) * KS + s) * 64 + lane]);
+            A2[1][s] = as_frag(wfrag[((2 * m + 1) * KS + s) * 64 + lane]);
         }
-        uint32_t o[MT];
+        // ---- grouped 5x5: k-step s covers taps 2s, 2s+1; lane group g -> tap 2s + (g>>1), input channels 16m + (g&1)*8 .. ----
+        {
+            f32x4_t acc[NTWV];
 #pragma unroll
-        for (int mp = 0; mp < MT / 2; ++mp) {
+            for (int n = 0; n < NTWV; ++n) acc[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KSG; ++s) {
+                int tap = 2 * s + (g >> 1);
+                tap = tap < 25 ? tap : 0;                  // the 26th slot has zero weights: any valid address will do
+                const int dy = tap / 5, dx = tap - dy * 5;
+                const int toff = (dy * RW + dx) * PS;
+#pragma unroll
+                for (int n = 0; n < NTWV; ++n) acc[n] = mfma16(A1[s], as_frag(*(const uint4*)(lds_g + pbase[n] + toff)), acc[n]);
+            }
+#pragma unroll
+            for (int n = 0; n < NTWV; ++n) {
+                uint2 o; o.x = pack_bf2(acc[n][0], acc[n][1]); o.y = pack_bf2(acc[n][2], acc[n][3]);
+                *(uint2*)(lds_r + ((NTWV * nh + n) * 16 + p) * PS + (m * 16 + g * 4) * 2) = o;
+            }
+        }
+        __syncthreads();                                   // r complete; every wave is done reading the g1 region
+        // ---- 1x1 C -> 2C, gate pair m: channels 2*MT*g + 4m + rr of the gate-paired order (MT = C/8), SimpleGate2 ----
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < NTWV; ++n) {
+            const int tp = (NTWV * nh + n) * 16 + p;
             f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                a0 = mfma16(as_frag(wfrag[((2 * mp) * KS + s) * 64 + lane]), Bf[s], a0);
-                a1 = mfma16(as_frag(wfrag[((2 * mp + 1) * KS + s) * 64 + lane]), Bf[s], a1);
+                const int kk0 = s * 32 + g * 8;
+                const bf16x8_t Bf = as_frag(kk0 < C ? *(const uint4*)(lds_r + tp * PS + kk0 * 2) : make_uint4(0, 0, 0, 0));
+                a0 = mfma16(A2[0][s], Bf, a0);
+                a1 = mfma16(A2[1][s], Bf, a1);
             }
             float v[4];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) v[rr] = a0[rr] * sigmoidf_(a1[rr]);
-            o[2 * mp] = pack_bf2(v[0], v[1]); o[2 * mp + 1] = pack_bf2(v[2], v[3]);
             const int oyv = y0 + (tp >> 5), oxv = x0 + (tp & 31);
             if (oyv < h && oxv < w) {
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) ps[mp][rr] += v[rr];
+                for (int rr = 0; rr < 4; ++rr) ps[rr] += v[rr];
             }
+            uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+            *(uint2*)(lds_g + tp * PS + (g * (C / 4) + 4 * m) * 2) = o;      // output tile over the dead g1 region
         }
-        const int oy = y0 + (tp >> 5), ox = x0 + (tp & 31);
-        if (oy < h && ox < w) {
-            bf16_t* dst = g2 + (((size_t)t * h + oy) * w + ox) * C + g * 2 * MT;       // 4*(MT/2) consecutive channels
-#pragma unroll
-            for (int m = 0; m + 3 < MT; m += 4) *(uint4*)(dst + m * 2) = make_uint4(o[m], o[m + 1], o[m + 2], o[m + 3]);
-            if (MT & 2) *(uint2*)(dst + (MT & ~3) * 2) = make_uint2(o[MT - 2], o[MT - 1]);
-        }
-    }
-#pragma unroll
-    for (int mp = 0; mp < MT / 2; ++mp)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            float sm = ps[mp][rr];
-            sm = row_sum16(sm);
-            if (p == 0) red[wv * C + g * 2 * MT + mp * 4 + rr] = sm;
+            const float sm = row_sum16(ps[rr]);
+            if (p == 0) red[nh * C + g * (C / 4) + 4 * m + rr] = sm;
         }
-    __syncthreads();
-    if (pool && tid < C) {
-        const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
-        pool[((size_t)t * nblk + blk) * C + tid] = red[tid] + red[C + tid] + red[2 * C + tid] + red[3 * C + tid];
+        __syncthreads();                                   // output tile and red complete
+        // ---- coalesced NHWC stores: 16-byte pieces, consecutive lanes = consecutive addresses of a pixel's C channels ----
+        for (int it = tid; it < TY * TXW * NPC; it += NTHR) {
+            const int px = it / NPC, pc = it - px * NPC;
+            const int oy = y0 + (px >> 5), ox = x0 + (px & 31);
+            if (oy < h && ox < w) *(uint4*)(g2 + (((size_t)t * h + oy) * w + ox) * C + pc * 8) = *(const uint4*)(lds_g + px * PS + pc * 16);
+        }
+        if (pool && tid < C) pool[((size_t)t * tpf + rem) * C + tid] = red[tid] + red[C + tid];
+        __syncthreads();                                   // the output tile (g1 region) and red are rewritten by the next tile
     }
 }
 
@@ -630,13 +648,18 @@ int sn_grp5_blocks(int h, int w) { return ((h + 3) / 4) * ((w + 31) / 32); }
 int sn_grp5_gemm_gate(const void* g1, const float* ca_in, const void* wgrp, const void* wfrag, void* g2, float* pool,
                       int T, int h, int w, int C, void* stream) {
     sn_clear_error();
-    if (!g1 || !wgrp || !wfrag || !g2 || C != 80) return SN_EINVAL;
-    dim3 grid((w + 31) / 32, (h + 3) / 4, T);
-    const size_t lds = (size_t)(8 * 36 + 4 * 32) * (C * 2 + 16) + 4 * C * sizeof(float);
-    if (hipFuncSetAttribute((const void*)grp5_gemm_gate_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (!g1 || !wgrp || !wfrag || !g2 || C != 80 || T < 1 || h < 1 || w < 1) return SN_EINVAL;
+    const size_t lds = (size_t)(8 * 36 + 4 * 32) * (C * 2 + 16) + 2 * C * sizeof(float);        // 73856 B
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1)
         return SN_ELAUNCH;
-    hipLaunchKernelGGL(grp5_gemm_gate_kernel<80>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)g1, ca_in,
-                       (const uint4*)wgrp, (const uint4*)wfrag, (bf16_t*)g2, pool, h, w);
+    if (hipFuncSetAttribute((const void*)grp5p_gemm_gate_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return SN_ELAUNCH;
+    const int ntiles = T * ((h + 3) / 4) * ((w + 31) / 32);
+    const int maxwg = ncu, nwg = ntiles < maxwg ? ntiles : maxwg;      // persistent: one 10-wave workgroup per CU (166 VGPRs)
+    sn_clear_error();
+    hipLaunchKernelGGL(grp5p_gemm_gate_kernel<80>, dim3(nwg), dim3(640), lds, (hipStream_t)stream, (const bf16_t*)g1, ca_in,
+                       (const uint4*)wgrp, (const uint4*)wfrag, (bf16_t*)g2, pool, T, h, w);
     return sn_check_launch();
 }
 
