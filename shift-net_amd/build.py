@@ -31,6 +31,8 @@ def build(force: bool = False, verbose: bool = False, experimental: bool = False
            "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
     if experimental:
         cmd.insert(1, "-DSN_EXPERIMENTAL")
+    for f in os.environ.get("SN_HIPCC_FLAGS", "").split():      # A/B builds of compile-time shapes, e.g. SN_HIPCC_FLAGS=-DSN_GRP5_NH=2
+        cmd.insert(1, f)
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -440,35 +440,30 @@ __global__ __launch_bounds__(256) void dw5_gemm_gate_kernel(const bf16_t* __rest
 // walks, so the only operand traffic inside the tile loop is LDS reads of activations:
 //   stage (HBM -> registers one tile AHEAD -> LDS, optional CALayer2 scale) | grouped MFMAs -> r tile in LDS | 1x1 MFMAs,
 //   gate -> output tile in LDS (over the dead g1 region) | coalesced 16-byte NHWC stores + channel sums.
-template <int C>
-__global__ __launch_bounds__(640) void grp5p_gemm_gate_kernel(const bf16_t* __restrict__ g1, const float* __restrict__ ca_in,
+// NH = pixel halves per tile = waves per M-tile: NH = 1 -> 5 waves (320 threads) per workgroup and TWO independent workgroups per
+// CU (one computes while the other waits for its loads); NH = 2 -> one 10-wave workgroup per CU.
+template <int C, int NH>
+__global__ __launch_bounds__(64 * NH * (C / 16), 3) void grp5p_gemm_gate_kernel(const bf16_t* __restrict__ g1, const float* __restrict__ ca_in,
                                                             const uint4* __restrict__ wgrp, const uint4* __restrict__ wfrag,
                                                             bf16_t* g2, float* pool, int T, int h, int w) {
     constexpr int TY = 4, TXW = 32, RH = TY + 4, RW = TXW + 4, PS = C * 2 + 16, MTG = C / 16, KSG = 13;
-    constexpr int KS = (C + 31) / 32, NPC = C / 8, NTL = (TY * TXW) / 16, NTWV = NTL / 2, NTHR = 64 * 2 * MTG;
+    constexpr int KS = (C + 31) / 32, NPC = C / 8, NTL = (TY * TXW) / 16, NTWV = NTL / NH, NTHR = 64 * NH * MTG;
     constexpr int NITEM = RH * RW * NPC, NIT = (NITEM + NTHR - 1) / NTHR;
-    static_assert(C == 80 && NTHR == 640, "wave roles are laid out for C = 80 (5 group pairs x 2 pixel halves)");
+    static_assert(C == 80 && (NH == 1 || NH == 2), "wave roles are laid out for C = 80 (5 group pairs x NH pixel halves)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds_g = smem;                                  // [RH*RW][PS] staged g1 region; reused as the [TY*TXW][PS] output tile
     char* lds_r = smem + RH * RW * PS;                   // [TY*TXW][PS] RepConv output
-    float* red = (float*)(lds_r + TY * TXW * PS);        // [2][C]
+    float* red = (float*)(lds_r + TY * TXW * PS);        // [NH][C]
     const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
     const int m = wv % MTG, nh = wv / MTG;
     const int tiles_x = (w + TXW - 1) / TXW, tiles_y = (h + TY - 1) / TY, tpf = tiles_x * tiles_y, ntiles = T * tpf;
 
     // resident weights: the 13 grouped-conv fragments of M-tile m (52 VGPRs).  The 6 fragments of gate pair m (rows 2m, 2m+1 of
-    // the gate-paired order) are re-fetched once per tile, early enough to land during the grouped MFMAs: keeping them too
-    // pushes the kernel over the 168 registers that 10 waves per workgroup allow (scratch spills).
+    // the gate-paired order) are re-fetched once per tile right before the barrier that precedes their use: keeping them
+    // resident too pushes the kernel over the 168 registers that 10 waves per CU allow (scratch spills).
     bf16x8_t A1[KSG];
 #pragma unroll
     for (int s = 0; s < KSG; ++s) A1[s] = as_frag(wgrp[(m * KSG + s) * 64 + lane]);
-    // this wave's N-tiles: nt = NTWV*nh + n -> tile row nt >> 1, x block nt & 1
-    int pbase[NTWV];
-#pragma unroll
-    for (int n = 0; n < NTWV; ++n) {
-        const int nt = NTWV * nh + n, row = nt >> 1, xb = nt & 1;
-        pbase[n] = (row * RW + xb * 16 + p) * PS + (g & 1) * 16 + m * 32;
-    }
     // staging plan (the same region items for every tile): item idx -> (region pixel, 16-byte piece), recomputed where needed
     // (divisions by constants) instead of kept live
     uint4 stg[NIT];
@@ -520,17 +515,19 @@ __global__ __launch_bounds__(640) void grp5p_gemm_gate_kernel(const bf16_t* __re
             const int ntile = tile + wpx < seg1 ? tile + wpx : tile;      // past the end: re-read this tile (harmless)
             issue_loads(ntile);
         }
-        bf16x8_t A2[2][KS];                                // gate-pair fragments: in flight while the grouped MFMAs run
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            A2[0][s] = as_frag(wfrag[((2 * m) * KS + s) * 64 + lane]);
-            A2[1][s] = as_frag(wfrag[((2 * m + 1) * KS + s) * 64 + lane]);
-        }
         // ---- grouped 5x5: k-step s covers taps 2s, 2s+1; lane group g -> tap 2s + (g>>1), input channels 16m + (g&1)*8 .. ----
-        {
-            f32x4_t acc[NTWV];
+        // (four N-tiles at a time: 16 accumulator registers live next to the 52 of the resident fragments)
+#pragma unroll 1
+        for (int n0 = 0; n0 < NTWV; n0 += 4) {
+            f32x4_t acc[4];
 #pragma unroll
-            for (int n = 0; n < NTWV; ++n) acc[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int n = 0; n < 4; ++n) acc[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            int pb[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int nt = NTWV * nh + n0 + n, row = nt >> 1, xb = nt & 1;
+                pb[n] = (row * RW + xb * 16 + p) * PS + (g & 1) * 16 + m * 32;
+            }
 #pragma unroll
             for (int s = 0; s < KSG; ++s) {
                 int tap = 2 * s + (g >> 1);
@@ -538,18 +535,24 @@ __global__ __launch_bounds__(640) void grp5p_gemm_gate_kernel(const bf16_t* __re
                 const int dy = tap / 5, dx = tap - dy * 5;
                 const int toff = (dy * RW + dx) * PS;
 #pragma unroll
-                for (int n = 0; n < NTWV; ++n) acc[n] = mfma16(A1[s], as_frag(*(const uint4*)(lds_g + pbase[n] + toff)), acc[n]);
+                for (int n = 0; n < 4; ++n) acc[n] = mfma16(A1[s], as_frag(*(const uint4*)(lds_g + pb[n] + toff)), acc[n]);
             }
 #pragma unroll
-            for (int n = 0; n < NTWV; ++n) {
+            for (int n = 0; n < 4; ++n) {
                 uint2 o; o.x = pack_bf2(acc[n][0], acc[n][1]); o.y = pack_bf2(acc[n][2], acc[n][3]);
-                *(uint2*)(lds_r + ((NTWV * nh + n) * 16 + p) * PS + (m * 16 + g * 4) * 2) = o;
+                *(uint2*)(lds_r + ((NTWV * nh + n0 + n) * 16 + p) * PS + (m * 16 + g * 4) * 2) = o;
             }
+        }
+        bf16x8_t A2[2][KS];                                // gate-pair fragments (L1/L2 hits): land while the barrier collects the waves
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            A2[0][s] = as_frag(wfrag[((2 * m) * KS + s) * 64 + lane]);
+            A2[1][s] = as_frag(wfrag[((2 * m + 1) * KS + s) * 64 + lane]);
         }
         __syncthreads();                                   // r complete; every wave is done reading the g1 region
         // ---- 1x1 C -> 2C, gate pair m: channels 2*MT*g + 4m + rr of the gate-paired order (MT = C/8), SimpleGate2 ----
         float ps[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 2
         for (int n = 0; n < NTWV; ++n) {
             const int tp = (NTWV * nh + n) * 16 + p;
             f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(640) void grp5p_gemm_gate_kernel(const bf16_t* __re
             const int oy = y0 + (px >> 5), ox = x0 + (px & 31);
             if (oy < h && ox < w) *(uint4*)(g2 + (((size_t)t * h + oy) * w + ox) * C + pc * 8) = *(const uint4*)(lds_g + px * PS + pc * 16);
         }
-        if (pool && tid < C) pool[((size_t)t * tpf + rem) * C + tid] = red[tid] + red[C + tid];
+        if (pool && tid < C) pool[((size_t)t * tpf + rem) * C + tid] = NH == 2 ? red[tid] + red[C + tid] : red[tid];
         __syncthreads();                                   // the output tile (g1 region) and red are rewritten by the next tile
     }
 }
@@ -653,12 +656,16 @@ int sn_grp5_gemm_gate(const void* g1, const float* ca_in, const void* wgrp, cons
     int dev = 0, ncu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1)
         return SN_ELAUNCH;
-    if (hipFuncSetAttribute((const void*)grp5p_gemm_gate_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+#ifndef SN_GRP5_NH
+#define SN_GRP5_NH 1
+#endif
+    constexpr int NH = SN_GRP5_NH;
+    if (hipFuncSetAttribute((const void*)grp5p_gemm_gate_kernel<80, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return SN_ELAUNCH;
     const int ntiles = T * ((h + 3) / 4) * ((w + 31) / 32);
-    const int maxwg = ncu, nwg = ntiles < maxwg ? ntiles : maxwg;      // persistent: one 10-wave workgroup per CU (166 VGPRs)
+    const int maxwg = (NH == 1 ? 2 : 1) * ncu, nwg = ntiles < maxwg ? ntiles : maxwg;            // persistent, all workgroups resident
     sn_clear_error();
-    hipLaunchKernelGGL(grp5p_gemm_gate_kernel<80>, dim3(nwg), dim3(640), lds, (hipStream_t)stream, (const bf16_t*)g1, ca_in,
+    hipLaunchKernelGGL((grp5p_gemm_gate_kernel<80, NH>), nwg, dim3(64 * NH * 5), lds, (hipStream_t)stream, (const bf16_t*)g1, ca_in,
                        (const uint4*)wgrp, (const uint4*)wfrag, (bf16_t*)g2, pool, T, h, w);
     return sn_check_launch();
 }
