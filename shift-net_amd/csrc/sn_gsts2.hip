@@ -459,8 +459,8 @@ __global__ __launch_bounds__(64 * NH * (C / 16), 3) void grp5p_gemm_gate_kernel(
     const int tiles_x = (w + TXW - 1) / TXW, tiles_y = (h + TY - 1) / TY, tpf = tiles_x * tiles_y, ntiles = T * tpf;
 
     // resident weights: the 13 grouped-conv fragments of M-tile m (52 VGPRs).  The 6 fragments of gate pair m (rows 2m, 2m+1 of
-    // the gate-paired order) are re-fetched once per tile right before the barrier that precedes their use: keeping them
-    // resident too pushes the kernel over the 168 registers that 10 waves per CU allow (scratch spills).
+    // the gate-paired order) are re-fetched once per tile: keeping them resident too pushes the kernel over the 168 registers
+    // that 10 waves per CU allow (scratch spills).
     bf16x8_t A1[KSG];
 #pragma unroll
     for (int s = 0; s < KSG; ++s) A1[s] = as_frag(wgrp[(m * KSG + s) * 64 + lane]);
@@ -511,6 +511,14 @@ __global__ __launch_bounds__(64 * NH * (C / 16), 3) void grp5p_gemm_gate_kernel(
             *(uint4*)(lds_g + pix * PS + pc * 16) = q;
         }
         __syncthreads();
+        // gate-pair fragments of this tile (L1/L2 hits) FIRST, then the next tile's staging loads: vmcnt retires in order, so
+        // waiting for the fragments before phase 2 must not also wait for the HBM loads issued behind them
+        bf16x8_t A2[2][KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            A2[0][s] = as_frag(wfrag[((2 * m) * KS + s) * 64 + lane]);
+            A2[1][s] = as_frag(wfrag[((2 * m + 1) * KS + s) * 64 + lane]);
+        }
         {
             const int ntile = tile + wpx < seg1 ? tile + wpx : tile;      // past the end: re-read this tile (harmless)
             issue_loads(ntile);
@@ -528,26 +536,35 @@ __global__ __launch_bounds__(64 * NH * (C / 16), 3) void grp5p_gemm_gate_kernel(
                 const int nt = NTWV * nh + n0 + n, row = nt >> 1, xb = nt & 1;
                 pb[n] = (row * RW + xb * 16 + p) * PS + (g & 1) * 16 + m * 32;
             }
-#pragma unroll
-            for (int s = 0; s < KSG; ++s) {
+            // B fragments one k-step AHEAD (explicit double buffer): left to itself hipcc waits for every ds_read right before
+            // the MFMA that consumes it (s_waitcnt lgkmcnt(0) x 52: the LDS latency, ~100 cycles, exposed per MFMA)
+            auto toff_of = [&](int s) {
                 int tap = 2 * s + (g >> 1);
                 tap = tap < 25 ? tap : 0;                  // the 26th slot has zero weights: any valid address will do
                 const int dy = tap / 5, dx = tap - dy * 5;
-                const int toff = (dy * RW + dx) * PS;
+                return (dy * RW + dx) * PS;
+            };
+            uint4 Bq[2][4];
+            {
+                const int t0 = toff_of(0);
 #pragma unroll
-                for (int n = 0; n < 4; ++n) acc[n] = mfma16(A1[s], as_frag(*(const uint4*)(lds_g + pb[n] + toff)), acc[n]);
+                for (int n = 0; n < 4; ++n) Bq[0][n] = *(const uint4*)(lds_g + pb[n] + t0);
+            }
+#pragma unroll
+            for (int s = 0; s < KSG; ++s) {
+                if (s + 1 < KSG) {
+                    const int t1 = toff_of(s + 1);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) Bq[(s + 1) & 1][n] = *(const uint4*)(lds_g + pb[n] + t1);
+                }
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[n] = mfma16(A1[s], as_frag(Bq[s & 1][n]), acc[n]);
             }
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 uint2 o; o.x = pack_bf2(acc[n][0], acc[n][1]); o.y = pack_bf2(acc[n][2], acc[n][3]);
                 *(uint2*)(lds_r + ((NTWV * nh + n0 + n) * 16 + p) * PS + (m * 16 + g * 4) * 2) = o;
             }
-        }
-        bf16x8_t A2[2][KS];                                // gate-pair fragments (L1/L2 hits): land while the barrier collects the waves
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            A2[0][s] = as_frag(wfrag[((2 * m) * KS + s) * 64 + lane]);
-            A2[1][s] = as_frag(wfrag[((2 * m + 1) * KS + s) * 64 + lane]);
         }
         __syncthreads();                                   // r complete; every wave is done reading the g1 region
         // ---- 1x1 C -> 2C, gate pair m: channels 2*MT*g + 4m + rr of the gate-paired order (MT = C/8), SimpleGate2 ----
@@ -657,7 +674,7 @@ int sn_grp5_gemm_gate(const void* g1, const float* ca_in, const void* wgrp, cons
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1)
         return SN_ELAUNCH;
 #ifndef SN_GRP5_NH
-#define SN_GRP5_NH 1
+#define SN_GRP5_NH 2       /* measured on config 3: NH = 2 (one 10-wave workgroup per CU) 123.6 ms, NH = 1 (two 5-wave workgroups) 180.1 ms */
 #endif
     constexpr int NH = SN_GRP5_NH;
     if (hipFuncSetAttribute((const void*)grp5p_gemm_gate_kernel<80, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
