@@ -445,7 +445,16 @@ __global__ __launch_bounds__(256) void dw5_gemm_gate_kernel(const bf16_t* __rest
 template <int C, int NH>
 __global__ __launch_bounds__(64 * NH * (C / 16), 3) void grp5p_gemm_gate_kernel(const bf16_t* __restrict__ g1, const float* __restrict__ ca_in,
                                                             const uint4* __restrict__ wgrp, const uint4* __restrict__ wfrag,
-                                                            bf16_t* g2, float* pool, int T, int h, int w) {
+                                                            bf16_t* g2, float* pool, int T, int h, int w, unsigned long long* prof_) {
+#ifdef SN_EXPERIMENTAL
+    unsigned long long* const prof = prof_;                 // in-kernel phase clocks (tools/prof_k3g.py)
+#else
+    constexpr unsigned long long* prof = nullptr;
+#endif
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+    auto tick = [&](int slot) {
+        if (prof) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tacc[slot] += now - tlast; tlast = now; }
+    };
     constexpr int TY = 4, TXW = 32, RH = TY + 4, RW = TXW + 4, PS = C * 2 + 16, MTG = C / 16, KSG = 13;
     constexpr int KS = (C + 31) / 32, NPC = C / 8, NTL = (TY * TXW) / 16, NTWV = NTL / NH, NTHR = 64 * NH * MTG;
     constexpr int NITEM = RH * RW * NPC, NIT = (NITEM + NTHR - 1) / NTHR;
@@ -495,6 +504,7 @@ __global__ __launch_bounds__(64 * NH * (C / 16), 3) void grp5p_gemm_gate_kernel(
     for (; tile < seg1; tile += wpx) {
         const int t = tile / tpf, rem = tile - t * tpf, tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
         const int y0 = tyi * TY, x0 = txi * TXW;
+        tick(7);
         // ---- registers -> LDS (optional CALayer2 scale of the denoise variants), then prefetch the next tile ----
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
@@ -510,7 +520,9 @@ __global__ __launch_bounds__(64 * NH * (C / 16), 3) void grp5p_gemm_gate_kernel(
             }
             *(uint4*)(lds_g + pix * PS + pc * 16) = q;
         }
+        tick(0);
         __syncthreads();
+        tick(1);
         // gate-pair fragments of this tile (L1/L2 hits) FIRST, then the next tile's staging loads: vmcnt retires in order, so
         // waiting for the fragments before phase 2 must not also wait for the HBM loads issued behind them
         bf16x8_t A2[2][KS];
@@ -566,7 +578,9 @@ __global__ __launch_bounds__(64 * NH * (C / 16), 3) void grp5p_gemm_gate_kernel(
                 *(uint2*)(lds_r + ((NTWV * nh + n0 + n) * 16 + p) * PS + (m * 16 + g * 4) * 2) = o;
             }
         }
+        tick(2);
         __syncthreads();                                   // r complete; every wave is done reading the g1 region
+        tick(3);
         // ---- 1x1 C -> 2C, gate pair m: channels 2*MT*g + 4m + rr of the gate-paired order (MT = C/8), SimpleGate2 ----
         float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
@@ -596,7 +610,9 @@ __global__ __launch_bounds__(64 * NH * (C / 16), 3) void grp5p_gemm_gate_kernel(
             const float sm = row_sum16(ps[rr]);
             if (p == 0) red[nh * C + g * (C / 4) + 4 * m + rr] = sm;
         }
+        tick(4);
         __syncthreads();                                   // output tile and red complete
+        tick(5);
         // ---- coalesced NHWC stores: 16-byte pieces, consecutive lanes = consecutive addresses of a pixel's C channels ----
         for (int it = tid; it < TY * TXW * NPC; it += NTHR) {
             const int px = it / NPC, pc = it - px * NPC;
@@ -604,7 +620,12 @@ __global__ __launch_bounds__(64 * NH * (C / 16), 3) void grp5p_gemm_gate_kernel(
             if (oy < h && ox < w) *(uint4*)(g2 + (((size_t)t * h + oy) * w + ox) * C + pc * 8) = *(const uint4*)(lds_g + px * PS + pc * 16);
         }
         if (pool && tid < C) pool[((size_t)t * tpf + rem) * C + tid] = NH == 2 ? red[tid] + red[C + tid] : red[tid];
+        tick(6);
         __syncthreads();                                   // the output tile (g1 region) and red are rewritten by the next tile
+    }
+    if (prof && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) prof[((size_t)blockIdx.x * 16 + wv) * 8 + k] = tacc[k];
     }
 }
 
@@ -683,7 +704,7 @@ int sn_grp5_gemm_gate(const void* g1, const float* ca_in, const void* wgrp, cons
     const int maxwg = (NH == 1 ? 2 : 1) * ncu, nwg = ntiles < maxwg ? ntiles : maxwg;            // persistent, all workgroups resident
     sn_clear_error();
     hipLaunchKernelGGL((grp5p_gemm_gate_kernel<80, NH>), nwg, dim3(64 * NH * 5), lds, (hipStream_t)stream, (const bf16_t*)g1, ca_in,
-                       (const uint4*)wgrp, (const uint4*)wfrag, (bf16_t*)g2, pool, T, h, w);
+                       (const uint4*)wgrp, (const uint4*)wfrag, (bf16_t*)g2, pool, T, h, w, SN_DBG_BUF(1024));
     return sn_check_launch();
 }
 
