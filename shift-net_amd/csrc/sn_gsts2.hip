@@ -562,6 +562,7 @@ __global__ __launch_bounds__(64 * NH * (C / 16), 3) void grp5p_gemm_gate_kernel(
 #pragma unroll
                 for (int n = 0; n < 4; ++n) Bq[0][n] = *(const uint4*)(lds_g + pb[n] + t0);
             }
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);          // prologue reads of step 0 (see the loop)
 #pragma unroll
             for (int s = 0; s < KSG; ++s) {
                 if (s + 1 < KSG) {
@@ -571,6 +572,10 @@ __global__ __launch_bounds__(64 * NH * (C / 16), 3) void grp5p_gemm_gate_kernel(
                 }
 #pragma unroll
                 for (int n = 0; n < 4; ++n) acc[n] = mfma16(A1[s], as_frag(Bq[s & 1][n]), acc[n]);
+                // pin the issue order: the 4 ds_reads of step s+1, THEN the 4 MFMAs of step s (the scheduler otherwise sinks each
+                // read next to its consumer and the wave waits out one LDS latency per MFMA)
+                if (s + 1 < KSG) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             }
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
@@ -583,27 +588,40 @@ __global__ __launch_bounds__(64 * NH * (C / 16), 3) void grp5p_gemm_gate_kernel(
         tick(3);
         // ---- 1x1 C -> 2C, gate pair m: channels 2*MT*g + 4m + rr of the gate-paired order (MT = C/8), SimpleGate2 ----
         float ps[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-        for (int n = 0; n < NTWV; ++n) {
-            const int tp = (NTWV * nh + n) * 16 + p;
-            f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int n0 = 0; n0 < NTWV; n0 += 2) {             // two N-tiles at a time: all six B reads first, then the twelve MFMAs
+            uint4 Bf[2][KS];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int kk0 = s * 32 + g * 8;
-                const bf16x8_t Bf = as_frag(kk0 < C ? *(const uint4*)(lds_r + tp * PS + kk0 * 2) : make_uint4(0, 0, 0, 0));
-                a0 = mfma16(A2[0][s], Bf, a0);
-                a1 = mfma16(A2[1][s], Bf, a1);
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const int kk0 = s * 32 + g * 8, tpj = (NTWV * nh + n0 + j) * 16 + p;
+                    Bf[j][s] = kk0 < C ? *(const uint4*)(lds_r + tpj * PS + kk0 * 2) : make_uint4(0, 0, 0, 0);
+                }
+            f32x4_t a0[2], a1[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { a0[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; a1[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    a0[j] = mfma16(A2[0][s], as_frag(Bf[j][s]), a0[j]);
+                    a1[j] = mfma16(A2[1][s], as_frag(Bf[j][s]), a1[j]);
+                }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int tp = (NTWV * nh + n0 + j) * 16 + p;
+                float v[4];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) v[rr] = a0[j][rr] * sigmoidf_(a1[j][rr]);
+                const int oyv = y0 + (tp >> 5), oxv = x0 + (tp & 31);
+                if (oyv < h && oxv < w) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) ps[rr] += v[rr];
+                }
+                uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+                *(uint2*)(lds_g + tp * PS + (g * (C / 4) + 4 * m) * 2) = o;      // output tile over the dead g1 region
             }
-            float v[4];
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) v[rr] = a0[rr] * sigmoidf_(a1[rr]);
-            const int oyv = y0 + (tp >> 5), oxv = x0 + (tp & 31);
-            if (oyv < h && oxv < w) {
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) ps[rr] += v[rr];
-            }
-            uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-            *(uint2*)(lds_g + tp * PS + (g * (C / 4) + 4 * m) * 2) = o;      // output tile over the dead g1 region
         }
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
