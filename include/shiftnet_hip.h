@@ -131,7 +131,8 @@ int sn_gsts_shiftconv(const sn_unit_src* s, const int8_t* offs, const uint32_t* 
  * affine folded into the 1x1 weights), the 1x1 conv to 2C on MFMA, depthwise 3x3 + identity and the gate, with the 2C-channel
  * intermediate kept in LDS (gshift_deblur1.py:19-28,190-198,225-233).  wfrag / bias: prep.pack_ln_gemm (gate-paired rows).
  * hw may be NULL for mode 0.
- * wdw: [9][2C] u32, the bf16 weight of position j in half (j & 1) of its word, other half zero (v_dot2c operand).
+ * wdw: [9][C] u32: word k of a tap row holds the fp16 weights of positions (2k, 2k+1) of a's storage order (v_pk_fma_f16
+ * operand, prep.pk_f16_words of the [9][2C] table with the identity folded into the centre tap).
  * g1_blocked = 0: g1 natural NHWC [T][h][w][C] (sn_grp5_gemm_gate); 1 (C = 64 only): channel-blocked [T][4][h][w][16] (experimental K3');
  * g1_blocked = 2 (C = 64 only): channel-planar [T][h][C][sn_planar_pitch(w)], zeros in the pad columns (sn_dw5m_gemm_gate).
  * pool: NULL or [T][sn_lngate_blocks][C]. */

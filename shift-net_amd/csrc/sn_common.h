@@ -36,6 +36,12 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
     bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
     return __builtin_bit_cast(uint32_t, h);
 }
+// fp32 pair -> packed fp16, round to nearest even (two v_cvt_f16_f32 + v_pack_b32_f16); lo goes to bits 0..15
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
+    const h2_t h = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, h);
+}
 __device__ __forceinline__ bf16_t f_to_bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
 __device__ __forceinline__ void unpack8(const uint4 q, float* v) {

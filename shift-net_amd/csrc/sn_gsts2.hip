@@ -143,9 +143,9 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
             const int rp = (wv + NWV * n) * 16 + p;
             if (rp < NPX && (wv + NWV * n) < NTILES) {
                 uint4 o = make_uint4(0, 0, 0, 0);
-                if (inimg[n]) {
-                    o.x = pack_bf2(acc0[n][0], acc0[n][1]); o.y = pack_bf2(acc0[n][2], acc0[n][3]);
-                    o.z = pack_bf2(acc1[n][0], acc1[n][1]); o.w = pack_bf2(acc1[n][2], acc1[n][3]);
+                if (inimg[n]) {       // `a` lives in LDS as fp16 (round to nearest): operand of the packed-fp16 stencil below
+                    o.x = pack_h2(acc0[n][0], acc0[n][1]); o.y = pack_h2(acc0[n][2], acc0[n][3]);
+                    o.z = pack_h2(acc1[n][0], acc1[n][1]); o.w = pack_h2(acc1[n][2], acc1[n][3]);
                 }
                 *(uint4*)(lds_a + rp * PSA + g * 16) = o;
             }
@@ -177,14 +177,19 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
 #pragma unroll
             for (int gi = 0; gi < 2; ++gi) {
                 const int gs = gp * 2 + gi;
-                uint32_t wt[9][8];            // weight of position j as bf16 in half (j & 1) of its word, other half zero
+                // Depthwise 3x3 (+identity) as PACKED fp16 FMAs: a dword of the chunk image holds positions (2k, 2k+1) of one pixel,
+                // the weight word the two matching fp16 taps, so one v_pk_fma_f16 (full-rate VALU) does two MACs -- the former
+                // one-hot v_dot2c_f32_bf16 did one MAC in 4.8 cycles and this loop was 35 % of the kernel (VALU-bound).
+                // |a| is O(10) after the LayerNorm'd 1x1, nine fp16 products accumulate with 2^-11 relative steps: tighter than the
+                // bf16 rounding of the old operands (the folded identity tap 1 + w is exact to 2^-11 instead of 2^-8).
+                h2_t wt[9][4];                // fp16 weights of positions (2k, 2k+1), k = 0..3, per tap (wave-uniform: scalar loads)
 #pragma unroll
                 for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) wt[tp][j] = wdw[tp * (2 * C) + gs * 4 * MT + q * 8 + j];
-                float o[8];
+                    for (int k = 0; k < 4; ++k) wt[tp][k] = __builtin_bit_cast(h2_t, wdw[tp * C + gs * 2 * MT + q * 4 + k]);
+                h2_t o2[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = 0.f;
+                for (int k = 0; k < 4; ++k) o2[k] = (h2_t){(_Float16)0.f, (_Float16)0.f};
                 if (!(dbg & 32)) {
 #pragma unroll
                     for (int ty = 0; ty < 3; ++ty)
@@ -193,9 +198,12 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
                             const uint4 v = *(const uint4*)(lds_a + ((oy + ty) * RW + ox + tx) * PSA + gs * 16);
                             const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) o[j] = dot2bf(d[j >> 1], wt[ty * 3 + tx][j], o[j]);
+                            for (int k = 0; k < 4; ++k) o2[k] = __builtin_elementwise_fma(__builtin_bit_cast(h2_t, d[k]), wt[ty * 3 + tx][k], o2[k]);
                         }
                 }
+                float o[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { o[2 * k] = (float)o2[k][0]; o[2 * k + 1] = (float)o2[k][1]; }
                 const float r0 = o[0] * o[4], r1 = o[1] * o[5], r2 = o[2] * o[6], r3 = o[3] * o[7];
                 ow[2 * gi] = pack_bf2(r0, r1); ow[2 * gi + 1] = pack_bf2(r2, r3);
                 if (pool) {                   // denoise CALayer2 on g1: per-wave channel sums (4 channels of slot gs)

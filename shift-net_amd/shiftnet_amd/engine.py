@@ -92,7 +92,8 @@ class Plan:
         u["w_ln"], u["b_ln"] = self._dev(g["wfrag"]), self._dev(g["bias"])
         w3 = prep.pack_dw3_gate(sd[f"{pre}body.{i}.conv_2.weight"], c); i += 1
         u["w_dw3"] = self._dev(w3)
-        u["w_dw3_d2"] = self._dev(prep.dot2_words(w3))
+        u["w_dw3_d2"] = self._dev(prep.dot2_words(w3))          # experimental chains (v_dot2c operands)
+        u["w_dw3_h2"] = self._dev(prep.pk_f16_words(w3))        # K12: packed-fp16 stencil, [9][C] words = positions (2k, 2k+1)
         if c == 64:
             u["w_toep3"] = self._dev(prep.pack_toeplitz_dw3_chunks(sd[f"{pre}body.{i - 1}.conv_2.weight"], c))   # K12m band records
         i += 1
@@ -360,7 +361,7 @@ class Engine:
             g1 = self._new(T, h, w, c)
         pool1 = torch.empty((T, lib.sn_lngate_blocks(h, w), c), dtype=torch.float32, device=self.dev) if V.denoise else None
         self._call("sn_ln_gemm_gate", "sn_ln_gemm_gate", C.byref(src), hw_ptr, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(),
-                   u["w_dw3_d2"].data_ptr(), g1.data_ptr(), pool1.data_ptr() if pool1 is not None else None, 2 if mstencil else 0, st)
+                   u["w_dw3_h2"].data_ptr(), g1.data_ptr(), pool1.data_ptr() if pool1 is not None else None, 2 if mstencil else 0, st)
         ca1_ptr = self.ca_mlp(pre + "ca1", pool1, h * w).data_ptr() if V.denoise else None      # denoise: CALayer2 on g1
         g2 = self._new(T, h, w, c)
         if mstencil:

@@ -50,7 +50,7 @@ class ExperimentalEngine(Engine):
             if V.denoise:
                 pool1 = torch.empty((T, lib.sn_lngate_blocks(h, w), c), dtype=torch.float32, device=self.dev)
             self._call("sn_ln_gemm_gate", "sn_ln_gemm_gate", C.byref(src), hw_ptr, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(),
-                       u["w_dw3_d2"].data_ptr(), g1.data_ptr(), pool1.data_ptr() if pool1 is not None else None, blocked, st)
+                       u["w_dw3_h2"].data_ptr(), g1.data_ptr(), pool1.data_ptr() if pool1 is not None else None, blocked, st)
         else:
             a = self._new(T, h, w, 2 * c)
             self._call("sn_ln_gemm", "sn_ln_gemm", C.byref(src), hw_ptr, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(), a.data_ptr(), st)

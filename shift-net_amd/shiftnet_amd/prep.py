@@ -178,6 +178,13 @@ def dot2_words(w: torch.Tensor) -> torch.Tensor:
     return (bits << shift).to(torch.int32).contiguous()
 
 
+def pk_f16_words(w: torch.Tensor) -> torch.Tensor:
+    """fp32 [..., N] (N even) -> int32 [..., N/2] words for v_pk_fma_f16: fp16(w[..., 2k]) in the low half, fp16(w[..., 2k+1]) in the
+    high half of word k (round to nearest)."""
+    h = w.to(torch.float16).contiguous().view(torch.int16).to(torch.int32) & 0xFFFF
+    return (h[..., 0::2] | (h[..., 1::2] << 16)).to(torch.int32).contiguous()
+
+
 def chunk_block_perm(c: int = 64) -> np.ndarray:
     """position -> channel of the chunk-blocked g1 / r layout used between sn_ln_gemm_gate and sn_dw5_gemm_gate (C = 64):
     position pos = q*16 + gs*4 + r (block q written by chunk q of K12)  <->  channel gs*16 + q*4 + r."""
