@@ -217,6 +217,11 @@ int sn_ingest_u8(const uint8_t* src, void* dst, int dst_dtype, int T, int H, int
  * squared error of the UNROUNDED value vs gt (skimage PSNR, data_range 255, :142). */
 int sn_egress_blocks(void);
 int sn_egress_u8(const void* out, int out_dtype, const uint8_t* gt, uint8_t* img, float* sse, int T, int H, int W, void* stream);
+/* The CLIs' own SSIM (inference/test_deblur.py:25-49: Gaussian statistics, sd 1.5, over the (C,H,W) volume of clamp(out,0,1) and
+ * gt / 255, scipy 'reflect' boundaries on all three axes): scratch:[T][15][H][W] f32 workspace, partial:[T][sn_ssim_blocks()]
+ * f32 sums of the SSIM map; SSIM of frame t = sum(partial[t]) / (3 H W). */
+int sn_ssim_blocks(void);
+int sn_ssim_u8(const void* out, int out_dtype, const uint8_t* gt, float* scratch, float* partial, int T, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@ Same flags, directory layout, window arithmetic, metric definitions and log line
   --dtype {fp16,bf16,fp32}  dtype of the module (upstream: fp16 except the "+" denoiser, which stays float32): fp16 / bf16
                       modules run the bf16-storage MFMA kernels, fp32 modules the fp32 kernels (engine32.py)
   --host_io           convert uint8 <-> float on the host exactly like upstream (default: on the device, csrc/sn_io.hip:
-                      same values bit for bit, 3 instead of 12 bytes per pixel over PCIe, PSNR sums reduced on the GPU)
+                      same values bit for bit, 3 instead of 12 bytes per pixel over PCIe, PSNR and SSIM reduced on the GPU)
 Image I/O uses PIL (imageio / cv2 / skimage are not in this image); PSNR / SSIM restate the upstream formulas.
 """
 from __future__ import annotations
@@ -25,7 +25,7 @@ import torch
 from . import synth
 from .arch import CLASSES
 from .clip_parallel import window_ranges
-from .io_edges import egress_u8, ingest_u8
+from .io_edges import egress_u8, ingest_u8, ssim_u8
 from .weights import synth_state_dict
 
 DTYPES = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}
@@ -186,15 +186,18 @@ class Inference:
                 torch.cuda.synchronize()
                 t2 = time.time()
                 psnr = ssim = float("nan")
-                img_u8 = psnrs = None
-                if dev_io:      # clamp * 255, rounding and the PSNR sums on the device; SSIM (Gaussian statistics) stays on the host
-                    img_u8, psnrs = egress_u8(output, torch.from_numpy(np.stack(gtf)).to("cuda"), want_image=a.save_image)
+                img_u8 = psnrs = ssims = None
+                if dev_io:      # clamp * 255, rounding, the PSNR sums and the SSIM statistics all on the device: no float frame goes back
+                    gt_dev = torch.from_numpy(np.stack(gtf)).to("cuda")
+                    img_u8, psnrs = egress_u8(output, gt_dev, want_image=a.save_image)
+                    ssims = ssim_u8(output, gt_dev)
                     img_u8 = img_u8.cpu().numpy() if img_u8 is not None else None
-                    output = output.float()
                 for e in range(n_out):
-                    img = output[e].clamp(0, 1.0).permute(1, 2, 0).cpu().numpy() * 255
-                    psnr = psnrs[e] if psnrs is not None else psnr_255(img, gtf[e])
-                    ssim = ssim_calculate(img, gtf[e])
+                    if dev_io:
+                        psnr, ssim = psnrs[e], ssims[e]
+                    else:
+                        img = output[e].clamp(0, 1.0).permute(1, 2, 0).cpu().numpy() * 255
+                        psnr, ssim = psnr_255(img, gtf[e]), ssim_calculate(img, gtf[e])
                     vp.append(psnr); vs.append(ssim)
                     if a.save_image:
                         os.makedirs(os.path.join(self.result_path, v), exist_ok=True)

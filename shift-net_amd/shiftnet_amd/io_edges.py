@@ -53,3 +53,19 @@ def egress_u8(out: torch.Tensor, gt_u8: Optional[torch.Tensor] = None, want_imag
         tot = sse.double().cpu().sum(1)             # T x 64 partial sums: summed in float64 on the host
         psnr = [float("inf") if s == 0 else 10.0 * math.log10(255.0 ** 2 / (s / (3 * H * W))) for s in tot.tolist()]
     return img, psnr
+
+
+def ssim_u8(out: torch.Tensor, gt_u8: torch.Tensor) -> List[float]:
+    """The CLIs' SSIM (test_deblur.py:25-49) per frame, on the device.  out: [T,3,H,W] module dtype, gt_u8: [T,H,W,3] uint8."""
+    assert out.is_cuda and out.dim() == 4 and out.shape[1] == 3 and out.dtype in _CODE
+    out = out.contiguous()
+    T, _, H, W = out.shape
+    assert gt_u8.dtype == torch.uint8 and tuple(gt_u8.shape) == (T, H, W, 3) and gt_u8.device == out.device
+    gt_u8 = gt_u8.contiguous()
+    lib = L.load()
+    scratch = torch.empty((T, 15, H, W), dtype=torch.float32, device=out.device)
+    part = torch.empty((T, lib.sn_ssim_blocks()), dtype=torch.float32, device=out.device)
+    with torch.cuda.device(out.device):
+        L.check(lib.sn_ssim_u8(out.data_ptr(), _CODE[out.dtype], gt_u8.data_ptr(), scratch.data_ptr(), part.data_ptr(), T, H, W,
+                               torch.cuda.current_stream(out.device).cuda_stream), "sn_ssim_u8")
+    return (part.double().cpu().sum(1) / (3.0 * H * W)).tolist()

@@ -23,7 +23,7 @@ SYMBOLS = [          # include/shiftnet_hip.h, production ABI
     "sn_abi_version", "sn_selftest_mfma", "sn_ingest", "sn_conv2d", "sn_conv_pool_blocks", "sn_ca_mlp",
     "sn_scale_residual", "sn_cab_ca", "sn_cab_ca_scratch_floats", "sn_planar_pitch", "sn_nhwc_to_planar", "sn_dw5m_blocks",
     "sn_dw5m_gemm_gate", "sn_gsts_gather", "sn_temporal_roll", "sn_gsts_shiftconv", "sn_scale_gemm_res",
-    "sn_ingest_u8", "sn_egress_blocks", "sn_egress_u8",
+    "sn_ingest_u8", "sn_egress_blocks", "sn_egress_u8", "sn_ssim_blocks", "sn_ssim_u8",
     "sn32_conv2d", "sn32_gsts_gather", "sn32_layernorm", "sn32_gate", "sn32_chan_sum", "sn32_scale_residual", "sn32_ingest",
     "sn_ln_gemm_gate", "sn_lngate_blocks", "sn_grp5_gemm_gate", "sn_grp5_blocks",
 ]
@@ -110,6 +110,8 @@ def load() -> C.CDLL:
     lib.sn_ingest_u8.argtypes = [vp, vp, ci, ci, ci, ci, vp]
     lib.sn_egress_blocks.argtypes = []
     lib.sn_egress_u8.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci, vp]
+    lib.sn_ssim_blocks.argtypes = []
+    lib.sn_ssim_u8.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci, vp]
     ll = C.c_longlong
     lib.sn32_conv2d.argtypes = [C.POINTER(Conv32Desc), vp]
     lib.sn32_gsts_gather.argtypes = [C.POINTER(UnitSrc), vp, vp, vp]

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from shiftnet_amd import cli, synth
-from shiftnet_amd.io_edges import egress_u8, ingest_u8
+from shiftnet_amd.io_edges import egress_u8, ingest_u8, ssim_u8
 
 pytestmark = pytest.mark.gpu
 
@@ -30,3 +30,17 @@ def test_egress_u8_matches_host_metrics(dt):
         host = out[e].float().clamp(0, 1.0).permute(1, 2, 0).numpy() * 255       # test_deblur.py:140-141
         assert abs(psnr[e] - cli.psnr_255(host, sharp[e])) < 1e-3
         assert np.array_equal(img[e].cpu().numpy(), np.rint(host).astype(np.uint8))
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.float32])
+@pytest.mark.parametrize("hw", [(40, 56), (9, 300)])
+def test_device_ssim_matches_the_cli_formula(dt, hw):
+    """sn_ssim_u8 vs cli.ssim_calculate (scipy gaussian_filter over the (C,H,W) volume, reflect boundaries on all three axes)."""
+    T, (H, W) = 2, hw
+    _, sharp = synth.blurred_clip(T, H, W, seed=33)
+    g = torch.Generator().manual_seed(6)
+    out = (torch.from_numpy(sharp).permute(0, 3, 1, 2).float() / 255 + 0.08 * torch.randn(T, 3, H, W, generator=g)).to(dt)
+    got = ssim_u8(out.cuda(), torch.from_numpy(sharp).cuda())
+    for e in range(T):
+        host = out[e].float().clamp(0, 1.0).permute(1, 2, 0).numpy() * 255
+        assert abs(got[e] - cli.ssim_calculate(host, sharp[e])) < 2e-5, (e, got[e])

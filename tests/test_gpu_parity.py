@@ -388,6 +388,45 @@ def test_full_size_properties():
     assert (y1.float() - x[0, 2:18].float()).abs().max().item() < 1.0
 
 
+FULL_SIZE = {
+    # BASELINE config 3: Shift-Net+ deblur, 1280x720, one_len 48 -> T_in 52 (three levels, 56 GSTS units)
+    "config3": ("gshift_deblur1", 52, 720, 1280),
+    # BASELINE config 4: Shift-Net+ denoise sigma 30, 852x480 T=32 -> T_in 36, ONE of the CLI's 4 quadrants of 272x448
+    # (inference/test_denoise.py:153-173; the four differ only in their crop)
+    "config4_quadrant": ("gshift_denoise1", 36, 272, 448),
+}
+
+
+@pytest.mark.parametrize("cfg", list(FULL_SIZE))
+def test_full_size_parity_against_fp32_engine(cfg):
+    """Full-size parity for the "+" configs, where the CPU oracle would take hours: the bf16 module against the SAME module in
+    float32 on the fp32 engine, which tests/test_gpu_fp32.py pins to the oracle / reference fixtures at 1e-4 on small sizes and
+    which shares no kernel with the bf16 path.  Contract bound: PSNR >= 48 dB; plus determinism and finiteness.
+    This is where production tile counts, three levels and ragged level-3 maps (90x160, 34x56) meet the "+" kernels."""
+    import importlib
+    name, T, H, W = FULL_SIZE[cfg]
+    mod = importlib.import_module(f"basicsr.models.archs.{name}")
+    V = O.VARIANTS[name]
+    blur, _ = synth.blurred_clip(T, H, W, seed=23)
+    x = torch.from_numpy(blur).permute(0, 3, 1, 2).unsqueeze(0).cuda().float() / 255
+    nm = torch.full((1, T, 1, H, W), 30.0 / 255.0, device="cuda") if V.denoise else None
+    net = mod.GShiftNet(future_frames=2, past_frames=2)
+    net.load_state_dict(synth_state_dict(name), strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        ref = net(x, nm) if V.denoise else net(x)                        # float32 module -> fp32 engine
+        net = net.to(torch.bfloat16)
+        xb, nb = x.bfloat16(), (nm.bfloat16() if V.denoise else None)
+        y1 = net(xb, nb) if V.denoise else net(xb)
+        y2 = net(xb, nb) if V.denoise else net(xb)
+    torch.cuda.synchronize()
+    assert ref.dtype == torch.float32 and y1.dtype == torch.bfloat16 and y1.shape == ref.shape == (T - 4, 3, H, W)
+    assert torch.isfinite(y1.float()).all() and torch.equal(y1, y2)
+    p = _psnr(y1.float(), ref)
+    REPORT.append({"name": f"full_size_{cfg}", "psnr_bf16_vs_fp32_engine": p, "max_abs": (y1.float() - ref).abs().max().item()})
+    assert p >= 48.0, (cfg, p)
+
+
 def test_cli_synthetic_runs(tmp_path):
     """The drop-in CLIs end to end on a synthetic clip with the synthetic checkpoint (deblur-small and denoise-small)."""
     from shiftnet_amd import cli
