@@ -65,7 +65,12 @@ def kernel_alg_bytes(fn, meta):
     if meta and meta[0] == "conv":
         _, T, ho, wo, cin, cs_out, k, stride, in_mode, out_mode = meta
         pin = T * ho * wo * stride * stride / (4 if in_mode == 1 else 1)
+        if out_mode == 9:                           # sums-only launch (pass A of the fused CAB): reads x, writes nothing
+            return 2 * pin * cin
         return 2 * (pin * cin + T * ho * wo * cs_out)
+    if meta and meta[0] == "cab":                   # sn_cab_fused: read x, write out
+        _, T, h, w, cs = meta
+        return 2 * 2 * T * h * w * cs
     if meta and meta[0] == "ew":
         _, T, h, w, cs = meta
         return 2 * 3 * T * h * w * cs
@@ -277,7 +282,9 @@ def main():
             key = fn
             if fn == "sn_conv2d":                       # one GPU kernel per (M-tiles, tile shape): key by template instance
                 mt = -(-max(meta[5], 1) // 16) if meta[9] != 1 else -(-meta[5] * 4 // 16)
-                key = f"sn_conv2d<mt{mt},{'8x32' if meta[7] == 1 else '4x16'}>"
+                key = f"sn_conv2d<mt{mt},{'8x32' if meta[7] == 1 else '4x16'}>" + ("[sums]" if meta[9] == 9 else "")
+            elif fn == "sn_cab_fused":
+                key = f"sn_cab_fused<cs{meta[4]}>"
             elif fn in ("sn_ln_gemm_gate", "sn_ln_gemm_gate_m"):
                 key = f"{fn}<{'cab2' if meta[5] else 'cab1'}>"
             a = agg.setdefault(key, {"ms": 0.0, "n": 0, "bytes": 0.0})

@@ -24,6 +24,7 @@ struct ConvK {
     const float* bias; int act; float prelu;
     const bf16_t* res; bf16_t* out; int cs_out, out_mode, c_out, nchw_dtype;
     const void* sc; float* pool; const float* oscale; int oscale_stride; const bf16_t* res2;
+    bf16_t* brow; bf16_t* bcol;      // conv3_fast only: first/last row and column of the result, [T][2][w][cs_out] / [T][2][h][cs_out]
     int rh, rw, ps;
     unsigned m_nblk8, m_rw, m_csb, m_cv, m_k;   // ceil(2^24/d) multipliers: integer division by runtime constants without v_div
 };
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(256) void conv3_fast_kernel(const ConvK P) {
     // offset (a frame has < 2^31 elements), instead of a 64-bit multiply chain per N-tile.
     const bool full = (oy0 + TH <= P.hout) && (ox0 + TW <= P.wout);           // workgroup-uniform: no bounds masks at all
     const size_t tbase = (((size_t)t * P.hout + oy0) * P.wout + ox0) * P.cs_out;
-    bf16_t* const outb = P.out + tbase;
+    bf16_t* const outb = P.out ? P.out + tbase : nullptr;
     const bf16_t* const resb = P.res ? P.res + tbase : nullptr;
     const bf16_t* const res2b = P.res2 ? P.res2 + tbase : nullptr;
     const int c0 = g * 4 * MT;                                      // this lane's 4*MT consecutive channels of its pixel
@@ -457,6 +458,24 @@ __global__ __launch_bounds__(256) void conv3_fast_kernel(const ConvK P) {
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) psum[m][r] += v[m][r];
+            if (P.brow) {       // pass A of the fused CAB: `mid` is never stored, only its border lines (sn_cab_ca needs their sums)
+                const int nn = wv * NTW + n, row = nn / XB, xb = nn - row * XB;
+                const int oy = oy0 + row, ox = ox0 + xb * 16 + p;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    if (c0 + m * 4 >= P.cs_out) continue;
+                    uint2 o; o.x = pack_bf2(v[m][0], v[m][1]); o.y = pack_bf2(v[m][2], v[m][3]);
+                    if (oy == 0 || oy == P.hout - 1)
+                        *(uint2*)(P.brow + (((size_t)t * 2 + (oy == 0 ? 0 : 1)) * P.wout + ox) * P.cs_out + c0 + m * 4) = o;
+                    if (oy == 0 && P.hout == 1)
+                        *(uint2*)(P.brow + (((size_t)t * 2 + 1) * P.wout + ox) * P.cs_out + c0 + m * 4) = o;
+                    if (ox == 0 || ox == P.wout - 1)
+                        *(uint2*)(P.bcol + (((size_t)t * 2 + (ox == 0 ? 0 : 1)) * P.hout + oy) * P.cs_out + c0 + m * 4) = o;
+                    if (ox == 0 && P.wout == 1)
+                        *(uint2*)(P.bcol + (((size_t)t * 2 + 1) * P.hout + oy) * P.cs_out + c0 + m * 4) = o;
+                }
+            }
+            if (!P.out) continue;                                   // wave-uniform: sums-only launch
             if constexpr (MT == 2 || MT == 4) {
 #pragma unroll
                 for (int m = 0; m < MT; m += 2)
@@ -489,6 +508,185 @@ __global__ __launch_bounds__(256) void conv3_fast_kernel(const ConvK P) {
             P.pool[((size_t)t * nblk + blk) * (16 * MT) + tid] = sm;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Fused CAB, pass B:  out = x + ca * conv2(PReLU(conv1(x)))  [+ res2]   (gshift_deblur1.py:141-156) with `mid` in LDS.
+// The CALayer scale `ca` is known beforehand from pass A (conv3_fast_kernel with P.out == NULL: sums and border lines of mid,
+// closed form in sn_cab_ca), so a CAB costs three tensor passes -- read x (pass A), read x + write out (pass B) -- instead of
+// five (conv1: read x, write mid; conv2: read mid, read x, write out).  The dense convs are memory-bound (PMC: 3.8-5.1 TB/s,
+// MFMA pipe 11-14 % busy), so recomputing conv1 on the tile's 1-pixel ring (340 instead of 256 pixels) is paid in idle issue slots.
+//   stage x on (TH+4) x (TW+4) -> conv1 + PReLU on (TH+2) x (TW+2), ZERO outside the image (conv2's padding), bf16 into LDS ->
+//   conv2 on TH x TW from that image -> x ca, + x (from the staged tile), [+ res2] -> store.
+template <int MT, int CS>
+__global__ __launch_bounds__(256) void cab_fused_kernel(const ConvK P, const uint4* __restrict__ w2frag) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TH = 8, TW = 32, XH = TH + 4, XW = TW + 4, MH = TH + 2, MW = TW + 2, NPB = CS / 8;
+    constexpr int PS = 16 * sn_lds_slots(NPB);
+    constexpr int KTOT = 9 * CS, KS = (KTOT + 31) / 32;
+    constexpr int NTW = (TH * TW) / 64, XB = TW / 16;
+    constexpr int ROWP = XW * NPB, NITEM = XH * ROWP, NIT = (NITEM + 255) / 256;
+    constexpr int NMID = MH * MW, NMT = (NMID + 15) / 16, NMW = (NMT + 3) / 4;        // 340 mid pixels = 22 N-tiles, <= 6 per wave
+    char* xs = smem;                                     // [XH*XW][PS] staged x
+    char* ms = smem + XH * XW * PS;                      // [MH*MW][PS] mid = PReLU(conv1(x)), zero outside the image
+    const int tid = threadIdx.x & 255, lane = tid & 63, wv = wave_id();
+    const int g = lane >> 4, p = lane & 15;
+    const int t = blockIdx.z, oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+    const int c0 = g * 4 * MT;
+
+    {   // ---- stage x: rows oy0-2 .. oy0+TH+1, columns ox0-2 .. ox0+TW+1; a region row is one contiguous run in memory ----
+        const int iy0 = oy0 - 2, ix0 = ox0 - 2;
+        const bf16_t* inb = P.in0 + (size_t)t * P.hin * P.win * CS;
+        uint4 v[NIT];
+        bool in[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int idx = tid + k * 256, idc = idx < NITEM ? idx : NITEM - 1;
+            const int r = idc / ROWP, i = idc - r * ROWP, px = i / NPB;
+            const int gy = iy0 + r, gx = ix0 + px;
+            in[k] = gy >= 0 && gy < P.hin && gx >= 0 && gx < P.win;
+            v[k] = *(const uint4*)(inb + (in[k] ? ((ptrdiff_t)gy * P.win + ix0) * CS + i * 8 : 0));      // branch-free, clamped
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int idx = tid + k * 256;
+            const int r = idx / ROWP, i = idx - r * ROWP, px = i / NPB, blk = i - px * NPB;
+            if (idx < NITEM) *(uint4*)(xs + (r * XW + px) * PS + blk * 16) = in[k] ? v[k] : make_uint4(0, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+
+    auto toff_of = [&](int s, int rw) {                 // LDS byte offset of lane group g's 8 channels at k-step s in an image of row width rw
+        int toff = 0;
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            const int kk0 = (s * 4 + gg) * 8;
+            const int tap = kk0 / CS, cc0 = kk0 - tap * CS, dy = tap / 3, dx = tap - dy * 3;
+            const int o = kk0 < KTOT ? (dy * rw + dx) * PS + cc0 * 2 : 0;
+            toff = g == gg ? o : toff;
+        }
+        return toff;
+    };
+
+    // ---- conv1 + PReLU on the (TH+2) x (TW+2) ring-extended tile -> ms ----
+    const float slope = P.prelu;
+    const int act = (slope >= 0.f && slope <= 1.f) ? 1 : 2;
+#pragma unroll 1
+    for (int j0 = 0; j0 < NMW; j0 += 3) {               // three N-tiles at a time share every weight fragment
+        f32x4_t acc[MT][3];
+        int qb[3], qpix[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int nt = wv + 4 * (j0 + j);
+            int q = nt * 16 + p;
+            qpix[j] = (nt < NMT && q < NMID) ? q : -1;
+            q = q < NMID ? q : NMID - 1;
+            const int ry = q / MW, rx = q - ry * MW;
+            qb[j] = (ry * XW + rx) * PS;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll(MT >= 3 ? 2 : KS)        // wide CABs: partial unroll, otherwise every weight fragment of the k-walk is hoisted (235+ VGPRs)
+        for (int s = 0; s < KS; ++s) {
+            const int toff = toff_of(s, XW);
+            bf16x8_t a[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[m] = as_frag(P.wfrag[(m * KS + s) * 64 + lane]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const bf16x8_t b = as_frag(*(const uint4*)(xs + qb[j] + toff));
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m][j] = mfma16(a[m], b, acc[m][j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (qpix[j] < 0) continue;
+            const int ry = qpix[j] / MW, rx = qpix[j] - ry * MW;
+            const int gy = oy0 - 1 + ry, gx = ox0 - 1 + rx;
+            const bool inimg = gy >= 0 && gy < P.hout && gx >= 0 && gx < P.wout;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if (c0 + m * 4 >= CS) continue;
+                float v[4] = {acc[m][j][0], acc[m][j][1], acc[m][j][2], acc[m][j][3]};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = act == 1 ? fmaxf(v[r], slope * v[r]) : fmaf(slope, fminf(v[r], 0.f), fmaxf(v[r], 0.f));
+                    v[r] = inimg ? v[r] : 0.f;            // conv2 zero-pads mid OUTSIDE the image, it does not see conv1 of padding
+                }
+                uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+                *(uint2*)(ms + qpix[j] * PS + (c0 + m * 4) * 2) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- conv2 on TH x TW from ms ----
+    f32x4_t acc[MT][NTW];
+    int pixbase[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        const int nn = wv * NTW + n, row = nn / XB, xb = nn - row * XB;
+        pixbase[n] = (row * MW + xb * 16 + p) * PS;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll(MT >= 3 ? 2 : KS)
+    for (int s = 0; s < KS; ++s) {
+        const int toff = toff_of(s, MW);
+        bf16x8_t a[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = as_frag(w2frag[(m * KS + s) * 64 + lane]);
+        bf16x8_t b[NTW];
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) b[n] = as_frag(*(const uint4*)(ms + pixbase[n] + toff));
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) acc[m][n] = mfma16(a[m], b[n], acc[m][n]);
+    }
+
+    // ---- epilogue: x ca, + x (staged tile), [+ res2], store ----
+    const size_t tbase = (((size_t)t * P.hout + oy0) * P.wout + ox0) * P.cs_out;
+    bf16_t* const outb = P.out + tbase;
+    const bf16_t* const res2b = P.res2 ? P.res2 + tbase : nullptr;
+    float4 osc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) osc[m] = *(const float4*)(P.oscale + (size_t)t * P.oscale_stride + c0 + m * 4);
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        const int nn = wv * NTW + n, row = nn / XB, xb = nn - row * XB;
+        const int col = xb * 16 + p;
+        if (oy0 + row >= P.hout || ox0 + col >= P.wout) continue;
+        const int loff = (row * P.wout + col) * P.cs_out + c0;
+        const char* xres = xs + ((row + 2) * XW + col + 2) * PS + c0 * 2;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (c0 + m * 4 >= P.cs_out) continue;
+            float v[4] = {acc[m][n][0] * osc[m].x, acc[m][n][1] * osc[m].y, acc[m][n][2] * osc[m].z, acc[m][n][3] * osc[m].w};
+            const uint2 rr = *(const uint2*)(xres + m * 8);
+            v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
+            if (res2b) {
+                const uint2 r2 = *(const uint2*)(res2b + loff + m * 4);
+                v[0] += bf_lo(r2.x); v[1] += bf_hi(r2.x); v[2] += bf_lo(r2.y); v[3] += bf_hi(r2.y);
+            }
+            uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+            *(uint2*)(outb + loff + m * 4) = o;
+        }
+    }
+}
+
+template <int MT, int CS>
+int launch_cab_fused(const ConvK& K, const uint4* w2, int T, hipStream_t st) {
+    constexpr int NPB = CS / 8, PS = 16 * sn_lds_slots(NPB);
+    dim3 grid((K.wout + 31) / 32, (K.hout + 7) / 8, T);
+    const size_t lds = (size_t)(12 * 36 + 10 * 34) * PS;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)cab_fused_kernel<MT, CS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return SN_ELAUNCH;
+    }
+    hipLaunchKernelGGL((cab_fused_kernel<MT, CS>), grid, dim3(256), lds, st, K, w2);
+    return sn_check_launch();
 }
 
 template <int MT, int CS>
@@ -583,10 +781,10 @@ __global__ __launch_bounds__(1024) void ca_mlp_kernel(const float* partial, int 
 // workgroup per frame was a 40 us latency chain, 101 times per window -- then one workgroup per frame finishes.
 #define SN_CABCA_NS 16
 __global__ __launch_bounds__(256) void cab_ca_part_kernel(const float* partial, int nblk, int cpad, const bf16_t* mid, int cs,
-                                                        int h, int w, float* scratch) {
+                                                        int h, int w, float* scratch, const bf16_t* brow, const bf16_t* bcol) {
     __shared__ float acc[256];
     const int t = blockIdx.y, sidx = blockIdx.x, tid = threadIdx.x;
-    const bf16_t* mt = mid + (size_t)t * h * w * cs;
+    const bf16_t* mt = mid ? mid + (size_t)t * h * w * cs : nullptr;
     float* out = scratch + ((size_t)t * SN_CABCA_NS + sidx) * 5 * 128;
     {
         const int nsplit = 256 / cpad, ch = tid % cpad, part = tid / cpad;
@@ -610,8 +808,13 @@ __global__ __launch_bounds__(256) void cab_ca_part_kernel(const float* partial, 
         float sm = 0.f;
         if (seg < nseg)
             for (int i = sidx * nseg + seg; i < len; i += SN_CABCA_NS * nseg) {
-                const int y = line == 0 ? 0 : (line == 1 ? h - 1 : i), x = line == 2 ? 0 : (line == 3 ? w - 1 : i);
-                sm += bf_to_f(mt[((size_t)y * w + x) * cs + ch]);
+                if (brow) {           // fused CAB: mid exists only as its border lines ([T][2][w][cs] rows, [T][2][h][cs] columns)
+                    const bf16_t* ln = line < 2 ? brow + ((size_t)blockIdx.y * 2 + line) * w * cs : bcol + ((size_t)blockIdx.y * 2 + (line - 2)) * h * cs;
+                    sm += bf_to_f(ln[(size_t)i * cs + ch]);
+                } else {
+                    const int y = line == 0 ? 0 : (line == 1 ? h - 1 : i), x = line == 2 ? 0 : (line == 3 ? w - 1 : i);
+                    sm += bf_to_f(mt[((size_t)y * w + x) * cs + ch]);
+                }
             }
         acc[tid] = sm;
         __syncthreads();
@@ -625,13 +828,13 @@ __global__ __launch_bounds__(256) void cab_ca_part_kernel(const float* partial, 
 }
 
 __global__ __launch_bounds__(1024) void cab_ca_kernel(const float* scratch, int cpad, const bf16_t* mid, int cs, int c, int cr,
-                                                     int h, int w, const float* w2, const float* wa, const float* wb, float* ca) {
+                                                     int h, int w, const float* w2, const float* wa, const float* wb, float* ca, const bf16_t* brow) {
     __shared__ float acc[1024];
     __shared__ float S[9][128];      // 0 total, 1 row0, 2 row h-1, 3 col0, 4 col w-1, 5..8 corners (0,0) (0,w-1) (h-1,0) (h-1,w-1)
     __shared__ float mean[128];
     __shared__ float hid[128];
     const int t = blockIdx.x, tid = threadIdx.x;
-    const bf16_t* mt = mid + (size_t)t * h * w * cs;
+    const bf16_t* mt = mid ? mid + (size_t)t * h * w * cs : nullptr;
     if (tid < 5 * 128) {
         const int k = tid >> 7, ch = tid & 127;
         float m = 0.f;
@@ -642,10 +845,16 @@ __global__ __launch_bounds__(1024) void cab_ca_kernel(const float* scratch, int 
         S[k][ch] = m;
     }
     if (tid < cs) {
-        S[5][tid] = bf_to_f(mt[tid]);
-        S[6][tid] = bf_to_f(mt[((size_t)(w - 1)) * cs + tid]);
-        S[7][tid] = bf_to_f(mt[((size_t)(h - 1) * w) * cs + tid]);
-        S[8][tid] = bf_to_f(mt[((size_t)(h - 1) * w + w - 1) * cs + tid]);
+        if (brow) {
+            const bf16_t* r0 = brow + (size_t)t * 2 * w * cs, *r1 = r0 + (size_t)w * cs;
+            S[5][tid] = bf_to_f(r0[tid]); S[6][tid] = bf_to_f(r0[(size_t)(w - 1) * cs + tid]);
+            S[7][tid] = bf_to_f(r1[tid]); S[8][tid] = bf_to_f(r1[(size_t)(w - 1) * cs + tid]);
+        } else {
+            S[5][tid] = bf_to_f(mt[tid]);
+            S[6][tid] = bf_to_f(mt[((size_t)(w - 1)) * cs + tid]);
+            S[7][tid] = bf_to_f(mt[((size_t)(h - 1) * w) * cs + tid]);
+            S[8][tid] = bf_to_f(mt[((size_t)(h - 1) * w + w - 1) * cs + tid]);
+        }
     }
     __syncthreads();
     {   // pooled res[co] = (1/hw) sum_ci sum_tap w2[ci][tap][co] * S_tap[ci]; thread = (slice of ci, co), then a tree over slices
@@ -751,7 +960,9 @@ int sn_conv_pool_blocks(const sn_conv_desc* d) {
 
 int sn_conv2d(const sn_conv_desc* d, void* stream) {
     sn_clear_error();
-    if (!d || d->n_in < 1 || d->n_in > 3 || (d->cs_in & 7) || (d->cs_out & 7) || !d->wfrag || !d->out) return SN_EINVAL;
+    if (!d || d->n_in < 1 || d->n_in > 3 || (d->cs_in & 7) || (d->cs_out & 7) || !d->wfrag) return SN_EINVAL;
+    if (!d->out && !(d->border_rows && d->border_cols && d->pool)) return SN_EINVAL;      // sums-only launch: pass A of the fused CAB
+    if ((d->border_rows == nullptr) != (d->border_cols == nullptr)) return SN_EINVAL;
     if (d->k < 1 || d->k > 5 || (d->stride != 1 && d->stride != 2) || d->mt < 1 || d->mt > 6 || d->ks < 1) return SN_EINVAL;
     if (d->in_mode == 1 && ((d->h_in | d->w_in) & 1)) return SN_EINVAL;
     if (d->out_mode == 2 && (!d->sc || d->c_out > 4 * d->mt)) return SN_EINVAL;
@@ -766,6 +977,7 @@ int sn_conv2d(const sn_conv_desc* d, void* stream) {
     K.wfrag = (const uint4*)d->wfrag; K.ks = d->ks; K.bias = d->bias; K.act = d->act; K.prelu = d->prelu;
     K.res = (const bf16_t*)d->res; K.out = (bf16_t*)d->out; K.cs_out = d->cs_out; K.out_mode = d->out_mode;
     K.c_out = d->c_out; K.nchw_dtype = d->nchw_dtype; K.sc = d->sc; K.pool = d->pool; K.oscale = d->oscale; K.oscale_stride = d->oscale_stride; K.res2 = (const bf16_t*)d->res2;
+    K.brow = (bf16_t*)d->border_rows; K.bcol = (bf16_t*)d->border_cols;
     const int blocks = K.cv >> 3;
     K.ps = d->stride == 1 ? 16 * sn_lds_slots(blocks) : ((blocks & 1) ? K.cv * 2 : K.cv * 2 + 16);     // stride 2: odd slot count (pixels 2 apart)
     K.rh = K.rw = 0;
@@ -784,9 +996,30 @@ int sn_conv2d(const sn_conv_desc* d, void* stream) {
             default: break;                       // any other width: the generic kernel below
         }
     }
+    if (d->border_rows || !d->out) return SN_EINVAL;          // only the specialised 3x3 kernel knows sums-only / border-line launches
     if (th == 16) return launch_conv<16, 32>(K, d->mt, d->T, (hipStream_t)stream);
     if (th == 8) return launch_conv<8, 32>(K, d->mt, d->T, (hipStream_t)stream);
     return launch_conv<4, 16>(K, d->mt, d->T, (hipStream_t)stream);
+}
+
+int sn_cab_fused(const sn_conv_desc* d, const void* wfrag2, void* stream) {
+    sn_clear_error();
+    if (!d || !wfrag2 || !d->wfrag || !d->out || !d->in[0] || !d->oscale || d->n_in != 1 || d->k != 3 || d->stride != 1 || d->pad != 1 ||
+        d->in_mode != 0 || d->out_mode != 0 || d->cs_in != d->cs_out || d->h_in != d->h_out || d->w_in != d->w_out || d->bias || d->act != 1 ||
+        d->ks != (9 * d->cs_in + 31) / 32 || d->oscale_stride < 16 * d->mt || d->res || d->pool) return SN_EINVAL;
+    ConvK K{};
+    K.in0 = (const bf16_t*)d->in[0]; K.n_in = 1; K.cs = d->cs_in; K.cv = d->cs_in;
+    K.hin = d->h_in; K.win = d->w_in; K.hout = d->h_out; K.wout = d->w_out; K.k = 3; K.stride = 1; K.pad = 1;
+    K.wfrag = (const uint4*)d->wfrag; K.ks = d->ks; K.prelu = d->prelu; K.act = 1;
+    K.out = (bf16_t*)d->out; K.cs_out = d->cs_out; K.oscale = d->oscale; K.oscale_stride = d->oscale_stride; K.res2 = (const bf16_t*)d->res2;
+    hipStream_t st = (hipStream_t)stream;
+    switch (d->mt * 1000 + d->cs_in) {
+        case 1016: return launch_cab_fused<1, 16>(K, (const uint4*)wfrag2, d->T, st);
+        case 2024: return launch_cab_fused<2, 24>(K, (const uint4*)wfrag2, d->T, st);
+        case 3040: return launch_cab_fused<3, 40>(K, (const uint4*)wfrag2, d->T, st);
+        case 3048: return launch_cab_fused<3, 48>(K, (const uint4*)wfrag2, d->T, st);
+        default: return SN_EINVAL;              // wider CABs (64, 80 channels) stay on the two-conv path (LDS: > 120 KB per workgroup)
+    }
 }
 
 int sn_ca_mlp(const float* partial, int nblk, int cpad, int c, int cr, float inv_hw,
@@ -800,14 +1033,16 @@ int sn_ca_mlp(const float* partial, int nblk, int cpad, int c, int cr, float inv
 int sn_cab_ca_scratch_floats(int T) { return T * SN_CABCA_NS * 5 * 128; }
 
 int sn_cab_ca(const float* partial, int nblk, int cpad, const void* mid, int cs, int c, int cr, int h, int w,
-              const float* w2, const float* wa, const float* wb, float* scratch, float* ca, int T, void* stream) {
+              const float* w2, const float* wa, const float* wb, float* scratch, float* ca, int T, void* stream,
+              const void* border_rows, const void* border_cols) {
     sn_clear_error();
-    if (!partial || !mid || !w2 || !wa || !wb || !ca || !scratch || cpad < 16 || cpad > 128 || cs > 128 || (cs & 7) || c > cs ||
+    if (!partial || !w2 || !wa || !wb || !ca || !scratch || cpad < 16 || cpad > 128 || cs > 128 || (cs & 7) || c > cs ||
         c > cpad || cr < 1 || cr > 128 || nblk < 1 || h < 2 || w < 2) return SN_EINVAL;
+    if ((border_rows == nullptr) != (border_cols == nullptr) || (!mid && !border_rows)) return SN_EINVAL;
     hipLaunchKernelGGL(cab_ca_part_kernel, dim3(SN_CABCA_NS, T), dim3(256), 0, (hipStream_t)stream, partial, nblk, cpad,
-                       (const bf16_t*)mid, cs, h, w, scratch);
+                       (const bf16_t*)mid, cs, h, w, scratch, (const bf16_t*)border_rows, (const bf16_t*)border_cols);
     hipLaunchKernelGGL(cab_ca_kernel, dim3(T), dim3(1024), 0, (hipStream_t)stream, (const float*)scratch, cpad, (const bf16_t*)mid, cs,
-                       c, cr, h, w, w2, wa, wb, ca);
+                       c, cr, h, w, w2, wa, wb, ca, (const bf16_t*)border_rows);
     return sn_check_launch();
 }
 

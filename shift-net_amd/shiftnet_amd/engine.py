@@ -194,7 +194,7 @@ class Engine:
         self.V = plan.V
         self.lib = L.load()
         self.dev = plan.device
-        self.cab_v = int(os.environ.get("SN_CAB_V", "1"))     # 1: CALayer scale + residual in the second conv's epilogue
+        self.cab_v = int(os.environ.get("SN_CAB_V", "2"))     # 2: fused CAB (mid in LDS); 1: two convs, CALayer in conv2's epilogue; 0: + scale pass
         self.prof: Optional[list] = None      # bench.py attaches a list to collect (fn, label, meta, ev0, ev1)
         self._meta: Tuple = ()
         self.split = None                     # temporal_split.TemporalSplit: this engine holds a frame range of a longer window
@@ -224,7 +224,8 @@ class Engine:
 
     def conv(self, name: str, ins: Sequence[Act], *, stride: int = 1, pad: Optional[int] = None, prelu: Optional[float] = None,
              res: Optional[Act] = None, out_mode: int = 0, pool: bool = False, in_mode: int = 0, oscale: Optional[torch.Tensor] = None,
-             nchw_out: Optional[torch.Tensor] = None, nchw_sc: Optional[torch.Tensor] = None, res2: Optional[Act] = None):
+             nchw_out: Optional[torch.Tensor] = None, nchw_sc: Optional[torch.Tensor] = None, res2: Optional[Act] = None,
+             sums_only: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
         p = self.P.convs[name]
         k, cout = int(p["k"]), int(p["cout"])
         T, hs, ws, cs_in = ins[0].dims
@@ -248,6 +249,10 @@ class Engine:
             assert nchw_out is not None and nchw_sc is not None
             d.out, d.sc, d.cs_out = nchw_out.data_ptr(), nchw_sc.data_ptr(), 8
             d.c_out, d.nchw_dtype = cout, _dtype_code(nchw_out.dtype)
+        elif sums_only is not None:     # pass A of the fused CAB: channel sums + border lines, the result itself is not stored
+            assert out_mode == 0 and pool
+            d.out, d.cs_out, d.c_out = None, prep.ceil8(cout), cout
+            d.border_rows, d.border_cols = sums_only[0].data_ptr(), sums_only[1].data_ptr()
         else:
             c_log = cout // 4 if out_mode == 1 else cout
             cs_out = prep.ceil8(c_log)
@@ -267,7 +272,7 @@ class Engine:
             nblk = self.lib.sn_conv_pool_blocks(C.byref(d))
             pool_buf = torch.empty((T, nblk, 16 * d.mt), dtype=torch.float32, device=self.dev)
             d.pool = pool_buf.data_ptr()
-        self._meta = ("conv", T, h_out, w_out, len(ins) * cs_in, int(d.cs_out), k, stride, in_mode, out_mode)
+        self._meta = ("conv", T, h_out, w_out, len(ins) * cs_in, int(d.cs_out), k, stride, in_mode, 9 if sums_only is not None else out_mode)
         self._call("sn_conv2d", f"sn_conv2d[{name}]", C.byref(d), self._stream())
         if pool:
             return out_act, pool_buf, h_out * w_out
@@ -294,21 +299,58 @@ class Engine:
     def cab(self, pre: str, x: Act, extra: Optional[Act] = None) -> Act:
         """CAB: 3x3 -> PReLU -> 3x3 -> CALayer -> +x (gshift_deblur1.py:141-156).
 
-        cab_v 1: the CALayer scale is known BEFORE the second conv (its pooled input is linear in `mid`, sn_cab_ca), so
-        the second conv applies scale and residual in its epilogue: 5 tensor passes instead of 7, no pass over `res`."""
+        The CALayer scale is known BEFORE the second conv (its pooled input is linear in `mid`, sn_cab_ca), so scale and residual
+        are applied in conv2's epilogue.  cab_v 2 (default, storage widths 16..48): FUSED -- pass A = conv1 + PReLU as a sums-only
+        launch (channel sums + the border lines of mid; mid itself never reaches HBM), pass B = sn_cab_fused recomputes conv1 on the
+        tile's ring, keeps mid in LDS and runs conv2 with the scale / residual epilogue: 3 tensor passes instead of 5.
+        cab_v 1: two sn_conv2d launches with mid in HBM (wide CABs always); cab_v 0: plus a separate scale pass (A/B only)."""
         if self.cab_v >= 1:
-            mid, pool, _ = self.conv(pre + "body.0", [x], prelu=self.P.scalar(pre + "body.1.weight"), pool=True)
             p = self.P.cas[pre + "CA"]
-            T, h, w, cs = mid.dims
+            c1, c2 = self.P.convs[pre + "body.0"], self.P.convs[pre + "body.2"]
+            T, h, w, cs = x.dims
+            slope = self.P.scalar(pre + "body.1.weight")
+            fused = self.cab_v >= 2 and cs in (16, 24, 40, 48) and c1["bias"] is None and c2["bias"] is None and h >= 2 and w >= 2
+            scratch = torch.empty((self.lib.sn_cab_ca_scratch_floats(T),), dtype=torch.float32, device=self.dev)
+            if fused:
+                brow = torch.empty((T, 2, w, cs), dtype=torch.bfloat16, device=self.dev)
+                bcol = torch.empty((T, 2, h, cs), dtype=torch.bfloat16, device=self.dev)
+                _, pool, _ = self.conv(pre + "body.0", [x], prelu=slope, pool=True, sums_only=(brow, bcol))
+                _, nblk, cpad = pool.shape
+                ca = torch.empty((T, cpad), dtype=torch.float32, device=self.dev)
+                self._call("sn_cab_ca", f"sn_cab_ca[{pre}]", pool.data_ptr(), nblk, cpad, None, cs, p["c"], p["cr"], h, w,
+                           p["w2"].data_ptr(), p["wa"].data_ptr(), p["wb"].data_ptr(), scratch.data_ptr(), ca.data_ptr(), T, self._stream(),
+                           brow.data_ptr(), bcol.data_ptr())
+                return self.cab_fused(pre, x, slope, ca, extra)
+            mid, pool, _ = self.conv(pre + "body.0", [x], prelu=slope, pool=True)
             _, nblk, cpad = pool.shape
             ca = torch.empty((T, cpad), dtype=torch.float32, device=self.dev)
-            scratch = torch.empty((self.lib.sn_cab_ca_scratch_floats(T),), dtype=torch.float32, device=self.dev)
             self._call("sn_cab_ca", f"sn_cab_ca[{pre}]", pool.data_ptr(), nblk, cpad, mid.t.data_ptr(), cs, p["c"], p["cr"], h, w,
-                       p["w2"].data_ptr(), p["wa"].data_ptr(), p["wb"].data_ptr(), scratch.data_ptr(), ca.data_ptr(), T, self._stream())
+                       p["w2"].data_ptr(), p["wa"].data_ptr(), p["wb"].data_ptr(), scratch.data_ptr(), ca.data_ptr(), T, self._stream(), None, None)
             return self.conv(pre + "body.2", [mid], res=x, oscale=ca, res2=extra)
         r = self.conv(pre + "body.0", [x], prelu=self.P.scalar(pre + "body.1.weight"))
         r, pool, npix = self.conv(pre + "body.2", [r], pool=True)
         return self.scale_residual(r, x, self.ca_mlp(pre + "CA", pool, npix), extra)
+
+    def cab_fused(self, pre: str, x: Act, slope: float, ca: torch.Tensor, extra: Optional[Act]) -> Act:
+        """Pass B of the fused CAB (sn_cab_fused)."""
+        c1, c2 = self.P.convs[pre + "body.0"], self.P.convs[pre + "body.2"]
+        T, h, w, cs = x.dims
+        assert c1["mt"] == c2["mt"] and c1["ks"] == c2["ks"] and c1["cs_in"] == cs
+        o = self._new(T, h, w, cs)
+        d = L.ConvDesc()
+        d.inp[0] = x.t.data_ptr()
+        d.n_in, d.cs_in, d.T, d.h_in, d.w_in, d.in_mode = 1, cs, T, h, w, 0
+        d.k, d.stride, d.pad, d.h_out, d.w_out = 3, 1, 1, h, w
+        d.wfrag, d.mt, d.ks = c1["wfrag"].data_ptr(), int(c1["mt"]), int(c1["ks"])
+        d.act, d.prelu = 1, slope
+        d.out, d.cs_out, d.c_out, d.out_mode = o.data_ptr(), cs, int(c2["cout"]), 0
+        d.oscale, d.oscale_stride = ca.data_ptr(), ca.shape[1]
+        if extra is not None:
+            assert extra.dims == x.dims
+            d.res2 = extra.t.data_ptr()
+        self._meta = ("cab", T, h, w, cs)
+        self._call("sn_cab_fused", f"sn_cab_fused[{pre}]", C.byref(d), c2["wfrag"].data_ptr(), self._stream())
+        return Act(o, x.c)
 
     def _wrap_flag(self, mode: int, circular: bool) -> int:
         """sn_unit_src.wrap: 0 keep the boundary frame, 1 circular, 2 neighbour frame in the halo slot (temporal split)."""

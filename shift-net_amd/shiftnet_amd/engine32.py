@@ -116,7 +116,8 @@ class Engine32(Engine):
 
     def conv(self, name: str, ins: Sequence[Act], *, stride: int = 1, pad: Optional[int] = None, prelu: Optional[float] = None,
              res: Optional[Act] = None, out_mode: int = 0, pool: bool = False, in_mode: int = 0, oscale: Optional[torch.Tensor] = None,
-             nchw_out: Optional[torch.Tensor] = None, nchw_sc: Optional[torch.Tensor] = None, res2: Optional[Act] = None):
+             nchw_out: Optional[torch.Tensor] = None, nchw_sc: Optional[torch.Tensor] = None, res2: Optional[Act] = None,
+             sums_only=None):
         p = self.P.convs[name]
         key = p["key"]
         k = int(self.P.sd[key + "weight"].shape[-1])

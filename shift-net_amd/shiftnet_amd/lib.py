@@ -21,7 +21,7 @@ if EXPERIMENTAL:
 
 SYMBOLS = [          # include/shiftnet_hip.h, production ABI
     "sn_abi_version", "sn_selftest_mfma", "sn_ingest", "sn_conv2d", "sn_conv_pool_blocks", "sn_ca_mlp",
-    "sn_scale_residual", "sn_cab_ca", "sn_cab_ca_scratch_floats", "sn_planar_pitch", "sn_nhwc_to_planar", "sn_dw5m_blocks",
+    "sn_scale_residual", "sn_cab_ca", "sn_cab_ca_scratch_floats", "sn_cab_fused", "sn_planar_pitch", "sn_nhwc_to_planar", "sn_dw5m_blocks",
     "sn_dw5m_gemm_gate", "sn_gsts_gather", "sn_temporal_roll", "sn_gsts_shiftconv", "sn_scale_gemm_res",
     "sn_ingest_u8", "sn_egress_blocks", "sn_egress_u8", "sn_ssim_blocks", "sn_ssim_u8",
     "sn32_conv2d", "sn32_gsts_gather", "sn32_layernorm", "sn32_gate", "sn32_chan_sum", "sn32_scale_residual", "sn32_ingest",
@@ -42,6 +42,7 @@ class ConvDesc(C.Structure):
         ("act", C.c_int), ("prelu", C.c_float), ("res", C.c_void_p), ("out", C.c_void_p),
         ("cs_out", C.c_int), ("out_mode", C.c_int), ("c_out", C.c_int), ("nchw_dtype", C.c_int),
         ("sc", C.c_void_p), ("pool", C.c_void_p), ("oscale", C.c_void_p), ("oscale_stride", C.c_int), ("res2", C.c_void_p),
+        ("border_rows", C.c_void_p), ("border_cols", C.c_void_p),
     ]
 
 
@@ -96,7 +97,8 @@ def load() -> C.CDLL:
     lib.sn_nhwc_to_planar.argtypes = [vp, vp, ci, ci, ci, ci, vp]
     lib.sn_dw5m_blocks.argtypes = [ci, ci]
     lib.sn_dw5m_gemm_gate.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
-    lib.sn_cab_ca.argtypes = [vp, ci, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp]
+    lib.sn_cab_ca.argtypes = [vp, ci, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp]
+    lib.sn_cab_fused.argtypes = [C.POINTER(ConvDesc), vp, vp]
     lib.sn_cab_ca_scratch_floats.argtypes = [ci]
     lib.sn_scale_residual.argtypes = [vp, vp, vp, ci, vp, ci, ci, ci, vp]
     lib.sn_gsts_gather.argtypes = [C.POINTER(UnitSrc), vp, vp, vp]
