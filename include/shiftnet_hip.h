@@ -78,7 +78,7 @@ typedef struct sn_conv_desc {
                             follows the last TFR_UNet of a stage (gshift_deblur1.py:769,779) rides on that UNet's last conv */
     void* border_rows;   /* NULL, or (3x3 stride-1 single-input NHWC convs only) [T][2][w_out][cs_out]: the result's first and last row; */
     void* border_cols;   /* [T][2][h_out][cs_out]: its first and last column.  With both given `out` may be NULL: a sums-only launch
-                            (pool + border lines) = pass A of the fused CAB, whose conv1 result never reaches HBM */
+                            (pool + border lines) = pass A of the (experimental) fused CAB, whose conv1 result never reaches HBM */
 } sn_conv_desc;
 int sn_conv2d(const sn_conv_desc* d, void* stream);   /* d is a HOST pointer, read during the call */
 /* number of workgroups per frame sn_conv2d launches for this descriptor (= rows of `pool` per frame); host only */
@@ -101,12 +101,6 @@ int sn_cab_ca_scratch_floats(int T);
 int sn_cab_ca(const float* partial, int nblk, int cpad, const void* mid, int cs, int c, int cr, int h, int w,
               const float* w2, const float* wa, const float* wb, float* scratch, float* ca, int T, void* stream,
               const void* border_rows, const void* border_cols);   /* the border lines of mid instead of mid itself (mid may then be NULL) */
-
-/* Fused CAB, pass B (gshift_deblur1.py:141-156): out = x + ca * conv2(PReLU(conv1(x))) [+ res2] with mid kept in LDS.  d describes
- * conv1 (in[0] = x, wfrag = conv1 fragments, act = 1 / prelu, bias NULL, oscale = ca from sn_cab_ca, res2 optional, out); wfrag2 =
- * conv2 fragments (same mt / ks).  Storage widths 16, 24, 40, 48; wider CABs run as two sn_conv2d calls.  Three tensor passes per
- * CAB (pass A reads x, pass B reads x and writes out) instead of five. */
-int sn_cab_fused(const sn_conv_desc* d, const void* wfrag2, void* stream);
 
 /* CAB tail "res = self.CA(res); res += x" (gshift_deblur1.py:155-157): out = res * ca[t][c] + x. */
 int sn_scale_residual(const void* res, const void* x, const float* ca, int cpad, void* out,

@@ -57,6 +57,13 @@ int sn_ln_gemm_gate_m(const sn_unit_src* s, const void* hw, const void* wfrag, c
                       void* g1p, float* pool, void* stream);
 
 
+/* ---- fused CAB (mid in LDS): parity green, slower than two sn_conv2d launches on MI355X (note in csrc/sn_conv.hip) ---- */
+/* Fused CAB, pass B (gshift_deblur1.py:141-156): out = x + ca * conv2(PReLU(conv1(x))) [+ res2] with mid kept in LDS.  d describes
+ * conv1 (in[0] = x, wfrag = conv1 fragments, act = 1 / prelu, bias NULL, oscale = ca from sn_cab_ca, res2 optional, out); wfrag2 =
+ * conv2 fragments (same mt / ks).  Storage widths 16, 24, 40, 48; wider CABs run as two sn_conv2d calls.  Three tensor passes per
+ * CAB (pass A reads x, pass B reads x and writes out) instead of five. */
+int sn_cab_fused(const sn_conv_desc* d, const void* wfrag2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -510,6 +510,7 @@ __global__ __launch_bounds__(256) void conv3_fast_kernel(const ConvK P) {
     }
 }
 
+#ifdef SN_EXPERIMENTAL   // fused CAB: parity green, measured SLOWER than two conv launches (see the note at sn_cab_fused); not on the product path
 // ------------------------------------------------------------------------------------------------------------
 // Fused CAB, pass B:  out = x + ca * conv2(PReLU(conv1(x)))  [+ res2]   (gshift_deblur1.py:141-156) with `mid` in LDS.
 // The CALayer scale `ca` is known beforehand from pass A (conv3_fast_kernel with P.out == NULL: sums and border lines of mid,
@@ -688,6 +689,8 @@ int launch_cab_fused(const ConvK& K, const uint4* w2, int T, hipStream_t st) {
     hipLaunchKernelGGL((cab_fused_kernel<MT, CS>), grid, dim3(256), lds, st, K, w2);
     return sn_check_launch();
 }
+
+#endif  // SN_EXPERIMENTAL
 
 template <int MT, int CS>
 int launch_conv3_fast(const ConvK& K, int T, hipStream_t st) {
@@ -1002,6 +1005,12 @@ int sn_conv2d(const sn_conv_desc* d, void* stream) {
     return launch_conv<4, 16>(K, d->mt, d->T, (hipStream_t)stream);
 }
 
+#ifdef SN_EXPERIMENTAL
+// Measured on MI355X (round 2): config 2 130.7 ms per window with the fused CABs vs 124.7 ms with two sn_conv2d launches per CAB,
+// config 3 816 vs 710 ms.  The dense convs are LATENCY-bound, not bandwidth-bound (67 % of wave cycles parked on loads at 3.8-5.1
+// TB/s): one workgroup = load -> compute -> store with 4-8 workgroups per CU covering each other.  The fused pass B lengthens that
+// chain (stage, conv1 on 340 pixels, barrier, conv2, store) at a third of the occupancy, and pass A (sums only) saves just 15 % of a
+// conv: three passes instead of five do not pay until the kernel is persistent with the next tile's loads in flight.
 int sn_cab_fused(const sn_conv_desc* d, const void* wfrag2, void* stream) {
     sn_clear_error();
     if (!d || !wfrag2 || !d->wfrag || !d->out || !d->in[0] || !d->oscale || d->n_in != 1 || d->k != 3 || d->stride != 1 || d->pad != 1 ||
@@ -1021,6 +1030,8 @@ int sn_cab_fused(const sn_conv_desc* d, const void* wfrag2, void* stream) {
         default: return SN_EINVAL;              // wider CABs (64, 80 channels) stay on the two-conv path (LDS: > 120 KB per workgroup)
     }
 }
+
+#endif  // SN_EXPERIMENTAL
 
 int sn_ca_mlp(const float* partial, int nblk, int cpad, int c, int cr, float inv_hw,
               const float* wa, const float* wb, float* ca, int T, void* stream) {

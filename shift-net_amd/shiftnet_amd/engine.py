@@ -194,7 +194,11 @@ class Engine:
         self.V = plan.V
         self.lib = L.load()
         self.dev = plan.device
-        self.cab_v = int(os.environ.get("SN_CAB_V", "2"))     # 2: fused CAB (mid in LDS); 1: two convs, CALayer in conv2's epilogue; 0: + scale pass
+        # 1: two convs, CALayer scale + residual in conv2's epilogue (product path); 0: + a separate scale pass; 2: fused CAB with mid
+        # in LDS -- experimental library only, measured slower (csrc/sn_conv.hip: sn_cab_fused)
+        self.cab_v = int(os.environ.get("SN_CAB_V", "1"))
+        if self.cab_v >= 2 and not L.EXPERIMENTAL:
+            raise L.ShiftNetLibError("SN_CAB_V=2 (fused CAB) needs the experimental library: SN_EXPERIMENTAL=1")
         self.prof: Optional[list] = None      # bench.py attaches a list to collect (fn, label, meta, ev0, ev1)
         self._meta: Tuple = ()
         self.split = None                     # temporal_split.TemporalSplit: this engine holds a frame range of a longer window
@@ -300,10 +304,11 @@ class Engine:
         """CAB: 3x3 -> PReLU -> 3x3 -> CALayer -> +x (gshift_deblur1.py:141-156).
 
         The CALayer scale is known BEFORE the second conv (its pooled input is linear in `mid`, sn_cab_ca), so scale and residual
-        are applied in conv2's epilogue.  cab_v 2 (default, storage widths 16..48): FUSED -- pass A = conv1 + PReLU as a sums-only
-        launch (channel sums + the border lines of mid; mid itself never reaches HBM), pass B = sn_cab_fused recomputes conv1 on the
-        tile's ring, keeps mid in LDS and runs conv2 with the scale / residual epilogue: 3 tensor passes instead of 5.
-        cab_v 1: two sn_conv2d launches with mid in HBM (wide CABs always); cab_v 0: plus a separate scale pass (A/B only)."""
+        are applied in conv2's epilogue.  cab_v 1 (product path): two sn_conv2d launches, 5 tensor passes.  cab_v 2 (experimental
+        library, storage widths 16..48): FUSED -- pass A = conv1 + PReLU as a sums-only launch (channel sums + the border lines of
+        mid; mid itself never reaches HBM), pass B = sn_cab_fused recomputes conv1 on the tile's ring, keeps mid in LDS and runs conv2
+        with the scale / residual epilogue: 3 tensor passes, parity green, but measured slower (latency-bound).
+        cab_v 0: two convs plus a separate scale pass (A/B only)."""
         if self.cab_v >= 1:
             p = self.P.cas[pre + "CA"]
             c1, c2 = self.P.convs[pre + "body.0"], self.P.convs[pre + "body.2"]

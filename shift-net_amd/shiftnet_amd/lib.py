@@ -21,7 +21,7 @@ if EXPERIMENTAL:
 
 SYMBOLS = [          # include/shiftnet_hip.h, production ABI
     "sn_abi_version", "sn_selftest_mfma", "sn_ingest", "sn_conv2d", "sn_conv_pool_blocks", "sn_ca_mlp",
-    "sn_scale_residual", "sn_cab_ca", "sn_cab_ca_scratch_floats", "sn_cab_fused", "sn_planar_pitch", "sn_nhwc_to_planar", "sn_dw5m_blocks",
+    "sn_scale_residual", "sn_cab_ca", "sn_cab_ca_scratch_floats", "sn_planar_pitch", "sn_nhwc_to_planar", "sn_dw5m_blocks",
     "sn_dw5m_gemm_gate", "sn_gsts_gather", "sn_temporal_roll", "sn_gsts_shiftconv", "sn_scale_gemm_res",
     "sn_ingest_u8", "sn_egress_blocks", "sn_egress_u8", "sn_ssim_blocks", "sn_ssim_u8",
     "sn32_conv2d", "sn32_gsts_gather", "sn32_layernorm", "sn32_gate", "sn32_chan_sum", "sn32_scale_residual", "sn32_ingest",
@@ -29,7 +29,7 @@ SYMBOLS = [          # include/shiftnet_hip.h, production ABI
 ]
 EXPERIMENTAL_SYMBOLS = [     # include/shiftnet_hip_experimental.h, only in libshiftnet_hip_exp.so
     "sn_ln_gemm", "sn_dw_gate", "sn_dwgate_blocks", "sn_dw_gemm_gate", "sn_dwgemm_blocks", "sn_dw5_gemm_gate", "sn_dw5_blocks",
-    "sn_debug_set", "sn_debug_get", "sn_debug_buf_set", "sn_debug_buf_get", "sn_lngatem_blocks", "sn_ln_gemm_gate_m",
+    "sn_debug_set", "sn_debug_get", "sn_debug_buf_set", "sn_debug_buf_get", "sn_lngatem_blocks", "sn_ln_gemm_gate_m", "sn_cab_fused",
 ]
 
 
@@ -98,7 +98,6 @@ def load() -> C.CDLL:
     lib.sn_dw5m_blocks.argtypes = [ci, ci]
     lib.sn_dw5m_gemm_gate.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.sn_cab_ca.argtypes = [vp, ci, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp]
-    lib.sn_cab_fused.argtypes = [C.POINTER(ConvDesc), vp, vp]
     lib.sn_cab_ca_scratch_floats.argtypes = [ci]
     lib.sn_scale_residual.argtypes = [vp, vp, vp, ci, vp, ci, ci, ci, vp]
     lib.sn_gsts_gather.argtypes = [C.POINTER(UnitSrc), vp, vp, vp]
@@ -125,6 +124,7 @@ def load() -> C.CDLL:
     for s in SYMBOLS:
         getattr(lib, s).restype = ci
     if EXPERIMENTAL:
+        lib.sn_cab_fused.argtypes = [C.POINTER(ConvDesc), vp, vp]
         lib.sn_lngatem_blocks.argtypes = [ci, ci]
         lib.sn_ln_gemm_gate_m.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp, vp, vp]
         lib.sn_ln_gemm.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp]

@@ -30,6 +30,19 @@ for name in ("gshift_deblur2", "gshift_denoise2", "gshift_deblur1"):
         eng.gsts_v = v
         TP._gsts_pieces((eng, sd), name, "_v%%d" %% v)
         print("ok", name, v, flush=True)
+# fused CAB (sn_cab_fused): every storage width it supports, ragged and sub-tile maps, second residual
+cache = {}
+def engines(name):
+    if name not in cache:
+        sd = synth_state_dict(name)
+        cache[name] = (ExperimentalEngine(Plan(VARIANTS[name], sd, TP.DEV)), sd)
+    return cache[name]
+for name, pre, c in (("gshift_deblur2", "stage1.concat.", 14), ("gshift_deblur2", "orb1.encoder_level2.1.", 18),
+                     ("gshift_deblur1", "stage1.concat.", 24), ("gshift_deblur1", "orb1.encoder_level2.0.", 36),
+                     ("gshift_deblur1", "orb1.encoder_level3.0.", 48)):
+    for hw in ((20, 44), (13, 70), (2, 3)):
+        TP.test_cab.__wrapped__(name, pre, c, hw, engines) if hasattr(TP.test_cab, "__wrapped__") else TP.test_cab(name, pre, c, hw, engines)
+    print("okcab", name, c, flush=True)
 """
 
 
@@ -40,4 +53,4 @@ def test_experimental_chains_match_the_oracle():
     code = CHILD % (ROOT, os.path.join(ROOT, "shift-net_amd"), os.path.join(ROOT, "tests"))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SN_EXPERIMENTAL="1"), capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert r.stdout.count("ok ") == 9
+    assert r.stdout.count("ok ") == 9 and r.stdout.count("okcab ") == 5
