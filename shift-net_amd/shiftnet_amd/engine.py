@@ -202,6 +202,11 @@ class Engine:
         self.prof: Optional[list] = None      # bench.py attaches a list to collect (fn, label, meta, ev0, ev1)
         self._meta: Tuple = ()
         self.split = None                     # temporal_split.TemporalSplit: this engine holds a frame range of a longer window
+        # hipGraph replay of the whole forward (~1400 launches per window): the first call with a given input signature runs eagerly,
+        # the second one is captured, later ones replay -- the Python / ctypes / allocator work per launch (which starves the GPU on
+        # the ~10 us squeeze-excite kernels and at the small pyramid levels) disappears.  SN_GRAPH=0 keeps everything eager.
+        self.use_graph = os.environ.get("SN_GRAPH", "1") != "0"
+        self._graphs: Dict[Tuple, object] = {}
 
     # ---- low level wrappers --------------------------------------------------------------------------------
     def _stream(self) -> int:
@@ -520,7 +525,38 @@ class Engine:
     def forward(self, x: torch.Tensor, noise_map: Optional[torch.Tensor], past: int, future: int) -> torch.Tensor:
         """GShiftNet.forward; x:[T,C,H,W] (already x[0]) on this engine's device, any of fp32/fp16/bf16."""
         with torch.cuda.device(self.dev):      # launches, events and allocations all belong to the engine's device
+            if not self.use_graph or self.split is not None or self.prof is not None or torch.cuda.is_current_stream_capturing():
+                return self._forward(x, noise_map, past, future)
+            return self._forward_graphed(x, noise_map, past, future)
+
+    def _forward_graphed(self, x, noise_map, past, future):
+        key = (tuple(x.shape), x.dtype, None if noise_map is None else (tuple(noise_map.shape), noise_map.dtype), past, future)
+        ent = self._graphs.get(key)
+        if ent is None:                         # first sight of this signature: eager (also the warm-up the capture needs)
+            self._graphs[key] = "seen"
             return self._forward(x, noise_map, past, future)
+        if ent == "eager":
+            return self._forward(x, noise_map, past, future)
+        if ent == "seen":
+            try:
+                sx = x.clone()
+                sn = noise_map.clone() if noise_map is not None else None
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    so = self._forward(sx, sn, past, future)
+                ent = self._graphs[key] = (g, sx, sn, so)
+            except Exception as e:                                  # noqa: BLE001  (capture unsupported here: stay eager, say so once)
+                import warnings
+                warnings.warn(f"shiftnet_amd: hipGraph capture failed ({type(e).__name__}: {e}); running eagerly")
+                self._graphs[key] = "eager"
+                torch.cuda.synchronize(self.dev)
+                return self._forward(x, noise_map, past, future)
+        g, sx, sn, so = ent
+        sx.copy_(x)
+        if sn is not None:
+            sn.copy_(noise_map)
+        g.replay()
+        return so.clone()                       # the graph owns `so`: hand out a copy, like the fresh tensor upstream returns
 
     def _forward(self, x: torch.Tensor, noise_map: Optional[torch.Tensor], past: int, future: int) -> torch.Tensor:
         V = self.V
