@@ -444,6 +444,41 @@ def test_full_size_parity_against_fp32_engine(cfg):
     assert p >= 48.0, (cfg, p)
 
 
+def test_hipgraph_replay_is_bit_identical_to_eager():
+    """SN_GRAPH=1 path: second call captures the whole forward into a hipGraph, later calls replay it; results must be bit
+    identical to the eager run and must follow the INPUT (the graph reads a static buffer the new input is copied into)."""
+    import time
+    from basicsr.models.archs.gshift_deblur2 import GShiftNet
+    net = GShiftNet(future_frames=2, past_frames=2)
+    net.load_state_dict(synth_state_dict("gshift_deblur2"), strict=True)
+    net = net.to(torch.bfloat16).cuda().eval()
+    blur, _ = synth.blurred_clip(8, 64, 96, seed=29)
+    xa = O.frames_to_tensor(list(blur)).bfloat16().cuda()
+    xb = torch.roll(xa, 2, dims=1).contiguous()
+    eng = net.prepare()
+    with torch.no_grad():
+        ea, eb = net(xa), net(xb)                         # eager references
+        eng.use_graph = True
+        try:
+            outs = [net(xa), net(xa), net(xb), net(xa)]  # eager (first sight), capture, replay with another input, replay
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                net(xa)
+            torch.cuda.synchronize()
+            t_graph = (time.perf_counter() - t0) / 5
+        finally:
+            eng.use_graph = False
+        t0 = time.perf_counter()
+        for _ in range(5):
+            net(xa)
+        torch.cuda.synchronize()
+        t_eager = (time.perf_counter() - t0) / 5
+    assert any(isinstance(v, tuple) for v in eng._graphs.values()), "no graph was captured"
+    assert torch.equal(outs[0], ea) and torch.equal(outs[1], ea) and torch.equal(outs[2], eb) and torch.equal(outs[3], ea)
+    REPORT.append({"name": "hipgraph_small_clip", "ms_eager": 1e3 * t_eager, "ms_graph": 1e3 * t_graph})
+
+
 def test_cli_synthetic_runs(tmp_path):
     """The drop-in CLIs end to end on a synthetic clip with the synthetic checkpoint (deblur-small and denoise-small)."""
     from shiftnet_amd import cli
