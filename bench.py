@@ -171,7 +171,7 @@ def main():
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        if torch.cuda.device_count() < args.gpus:
+        if torch.cuda.device_count() < args.gpus and os.environ.get("SN_BENCH_SHARED_DEVICE_TEST") != "1":
             sys.exit(f"bench.py: --gpus {args.gpus} needs {args.gpus} HIP devices on this node, {torch.cuda.device_count()} visible: "
                      "refusing to report a multi-GPU number from fewer GPUs")
         # self-launch: one rank per GPU under torch.distributed.run (what the driver does explicitly for N > 1)
@@ -189,12 +189,20 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
                  "(or run plain `python bench.py --gpus N`, which launches the ranks itself)")
     ndev = torch.cuda.device_count()
-    if ndev < world or local >= ndev:
+    # Rank-flow self test (tests/test_gpu_multirank.py on the one-GPU box): every rank on device 0, gloo transport.  The line it prints
+    # is marked "shared_device_test" and is NOT a multi-GPU measurement; without this variable fewer devices than ranks is fatal.
+    shared = os.environ.get("SN_BENCH_SHARED_DEVICE_TEST") == "1"
+    if shared:
+        local = 0
+    if ndev < (1 if shared else world) or local >= ndev:
         sys.exit(f"bench.py: --gpus {args.gpus} needs {world} HIP devices on this node, {ndev} visible: refusing to report a "
                  f"{world}-GPU number from fewer GPUs")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 and shared:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -204,7 +212,7 @@ def main():
         allv = [torch.empty_like(me) for _ in range(world)]
         dist.all_gather(allv, me)
         ids = {tuple(v.tolist()) for v in allv}
-        if len(ids) != world or dist.get_world_size() != args.gpus:
+        if (len(ids) != world and not shared) or dist.get_world_size() != args.gpus:
             sys.exit(f"bench.py: {world} ranks share {len(ids)} device(s): not a {world}-GPU run")
 
     import importlib
@@ -233,8 +241,9 @@ def main():
         hh, ww, quads = h, w, [(0, h, 0, w)]
     sigma_map = torch.full((1, L + 4, 1, hh, ww), 30.0 / 255.0, dtype=dt, device=dev) if denoise else None
 
-    def step():
-        win = assemble_window(own, first_edge, last_edge, rank, world)
+    def step(local_only=False):
+        # local_only: rank 0's extra per-kernel profiling step must not enter a collective the other ranks are not in
+        win = fr if local_only else assemble_window(own, first_edge, last_edge, rank, world)
         outs = []
         for a, b, c, d in quads:
             xq = win if len(quads) == 1 else win[:, :, a:b, c:d].contiguous()
@@ -273,7 +282,7 @@ def main():
         eng = net.prepare()
         eng.prof = []
         with torch.no_grad():
-            step()
+            step(local_only=True)
         torch.cuda.synchronize()
         agg = {}
         unit_ms = 0.0
@@ -340,6 +349,8 @@ def main():
                                    "frac": round(win_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "kernels": kernels,
         }
+        if world > 1 and os.environ.get("SN_BENCH_SHARED_DEVICE_TEST") == "1":
+            result["shared_device_test"] = True        # all ranks on one GPU: a rank-flow test, not a measurement
         if world == 1 and args.variant == VARIANT and args.dtype == "bf16":
             # parity sample next to the throughput: the same module on a small clip vs the CPU oracle (checker only)
             from oracle import shiftnet_oracle as O

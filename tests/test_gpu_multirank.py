@@ -59,3 +59,22 @@ def test_rccl_halo_allgather_and_config5_window(rccl_world1):
     assert torch.equal(y1, y2)                                # deterministic: no atomics anywhere in the path
     # "+" keeps the boundary frames un-rolled (gshift_deblur1.py:513,517): the restored frames stay near the input
     assert (y1.float() - win[2:-2].float()).abs().max().item() < 1.0
+
+
+def test_bench_two_rank_flow_on_one_device():
+    """`bench.py --gpus 2` end to end with both ranks on the box's single GPU (gloo transport, SN_BENCH_SHARED_DEVICE_TEST=1): the
+    self-launch through torch.distributed.run, the halo all-gather in every step, the MAX-over-ranks timing, rank 0's local
+    profiling step (no collective the other rank is not in) and the final barrier must all complete; the line is marked as a
+    shared-device test, never as a 2-GPU measurement."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["SN_BENCH_SHARED_DEVICE_TEST"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--height", "144",
+                        "--width", "256", "--one-len", "4", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["shared_device_test"] is True and d["value"] > 0 and d["config"]["parallelism"] == "clip-parallel x2"
