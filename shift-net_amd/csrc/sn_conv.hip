@@ -273,10 +273,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK P) {
 //   * a region row is ONE contiguous run of (TW+2)*CS*2 bytes in memory: lane i of the staging loop loads the i-th 16-byte
 //     piece of its row, so consecutive lanes read consecutive addresses and the only per-item math is idx -> (row, piece);
 //   * tiles whose ring lies inside the image (all but the frame border) take a path without bounds masks.
-// (launch bounds: resident waves per SIMD the register allocator must leave room for; without them the unrolled k-walk hoists every
-// weight fragment to the top of the tile loop)
+// One workgroup per tile, deliberately: a PERSISTENT variant with the next tile's region prefetched into registers (round 2, like the
+// round-1 attempt on the generic kernel) measured slower -- 16-channel convs 16.5 -> 20.4 ms, 24-channel 15.7 -> 18.2 ms per window of
+// config 2: the prefetch and the loop-carried state take the kernel from 32-48 to 107-155 VGPRs, and at 3.8-5.1 TB/s this kernel
+// hides its load latency through occupancy (6-8 resident workgroups per CU), not through software pipelining.
 template <int MT, int CS, int TH>
-__global__ __launch_bounds__(256, CS <= 16 ? 4 : (CS <= 48 ? 3 : 2)) void conv3_fast_kernel(const ConvK P) {
+__global__ __launch_bounds__(256) void conv3_fast_kernel(const ConvK P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TW = 32, RH = TH + 2, RW = TW + 2, NPB = CS / 8;
     // LDS bytes per pixel = k slots of 16 B with k the smallest value >= CS/8 that is 2 mod 4.  ds_read_b128 is serviced in the lane
@@ -290,44 +292,45 @@ __global__ __launch_bounds__(256, CS <= 16 ? 4 : (CS <= 48 ? 3 : 2)) void conv3_
     constexpr int TILE_BYTES = RH * RW * PS;
     const int tid = threadIdx.x & 255, lane = tid & 63, wv = wave_id();     // (& 255: lets the compiler fold the idx < NITEM guards)
     const int g = lane >> 4, p = lane & 15;
+    const int t = blockIdx.z, oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
     float* red = (float*)(smem + TILE_BYTES);
-    // PERSISTENT: gridDim.x workgroups walk the (frame, tile row, tile column) list; the region of the NEXT tile is loaded into
-    // registers while this tile's MFMAs and epilogue run.  The kernel was latency-bound as one workgroup per tile (67 % of wave cycles
-    // parked on loads at 3.8 TB/s for the 24-channel convs): load -> compute -> store chains covering each other only through
-    // occupancy.  XCD-aware walk (workgroup b runs on XCD b % 8): each XCD takes a contiguous eighth, halo rows meet in one L2.
-    const int tiles_x = (P.wout + TW - 1) / TW, tiles_y = (P.hout + TH - 1) / TH, tpf = tiles_x * tiles_y, ntiles = P.cv /* T */ * tpf;
-    const int nxcd = (gridDim.x % 8 == 0) ? 8 : 1, wpx = gridDim.x / nxcd, seg = (ntiles + nxcd - 1) / nxcd;
-    const int seg0 = (blockIdx.x % nxcd) * seg, seg1 = seg0 + seg < ntiles ? seg0 + seg : ntiles;
-    uint4 stg[NIT];
-    bool sin[NIT];
-    auto issue_loads = [&](int tile) {                   // branch-free, clamped; masks are applied at the LDS write
-        const int tt = tile / tpf, rem = tile - tt * tpf, ty = rem / tiles_x, tx = rem - ty * tiles_x;
-        const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
-        const bf16_t* inb = P.in0 + (size_t)tt * P.hin * P.win * CS;
+
+    {
+        const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+        const bf16_t* inb = P.in0 + (size_t)t * P.hin * P.win * CS;
+        const bool interior = iy0 >= 0 && iy0 + RH <= P.hin && ix0 >= 0 && ix0 + RW <= P.win;    // workgroup-uniform
+        uint4 v[NIT];
+        if (interior) {
+            const bf16_t* base = inb + ((size_t)iy0 * P.win + ix0) * CS;
 #pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int idx = tid + k * 256, idc = idx < NITEM ? idx : NITEM - 1;
-            const int r = idc / ROWP, i = idc - r * ROWP, px = i / NPB;
-            const int gy = iy0 + r, gx = ix0 + px;
-            sin[k] = gy >= 0 && gy < P.hin && gx >= 0 && gx < P.win;
-            stg[k] = *(const uint4*)(inb + (sin[k] ? (gy * P.win + ix0) * CS + i * 8 : 0));
+            for (int k = 0; k < NIT; ++k) {
+                const int idx = tid + k * 256, idc = idx < NITEM ? idx : NITEM - 1;
+                const int r = idc / ROWP, i = idc - r * ROWP;
+                v[k] = *(const uint4*)(base + (size_t)r * P.win * CS + i * 8);
+            }
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int idx = tid + k * 256;
+                const int r = idx / ROWP, i = idx - r * ROWP, px = i / NPB, blk = i - px * NPB;
+                if (idx < NITEM) *(uint4*)(smem + (r * RW + px) * PS + blk * 16) = v[k];
+            }
+        } else {
+            bool in[NIT];
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int idx = tid + k * 256, idc = idx < NITEM ? idx : NITEM - 1;
+                const int r = idc / ROWP, i = idc - r * ROWP, px = i / NPB;
+                const int gy = iy0 + r, gx = ix0 + px;
+                in[k] = gy >= 0 && gy < P.hin && gx >= 0 && gx < P.win;
+                v[k] = *(const uint4*)(inb + (in[k] ? ((size_t)gy * P.win + ix0) * CS + i * 8 : 0));   // branch-free, clamped
+            }
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int idx = tid + k * 256;
+                const int r = idx / ROWP, i = idx - r * ROWP, px = i / NPB, blk = i - px * NPB;
+                if (idx < NITEM) *(uint4*)(smem + (r * RW + px) * PS + blk * 16) = in[k] ? v[k] : make_uint4(0, 0, 0, 0);
+            }
         }
-    };
-    int tile = seg0 + blockIdx.x / nxcd;
-    if (tile < seg1) issue_loads(tile);
-    for (; tile < seg1; tile += wpx) {
-    const int t = tile / tpf, trem = tile - t * tpf, tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
-    const int oy0 = tyi * TH, ox0 = txi * TW;
-    // Weight fragments: loop-invariant, so the compiler would hoist ALL of them out of the tile loop.  That is what we want for the
-    // 16-channel convs (5 fragments = 20 VGPRs resident), not for the wider ones (14 .. 115 fragments = 56 .. 460 VGPRs: spills):
-    // there the pointer is made opaque once per tile and the fragments stream from L1/L2 as before.
-    const uint4* wfrag = P.wfrag;
-    if constexpr (MT * KS > 8) asm volatile("" : "+s"(wfrag));
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-        const int idx = tid + k * 256;
-        const int r = idx / ROWP, i = idx - r * ROWP, px = i / NPB, blk = i - px * NPB;
-        if (idx < NITEM) *(uint4*)(smem + (r * RW + px) * PS + blk * 16) = sin[k] ? stg[k] : make_uint4(0, 0, 0, 0);
     }
 
     // Output / residual addressing: ONE 64-bit wave-uniform base per tensor (scalar registers) plus a 32-bit per-lane element
@@ -355,9 +358,6 @@ __global__ __launch_bounds__(256, CS <= 16 ? 4 : (CS <= 48 ? 3 : 2)) void conv3_
         for (int n = 0; n < NTW; ++n) rres[n] = *(const uint2*)(rb + ((resb && valid[n] && c0 < P.cs_out) ? loff[n] : 0));
     }
     __syncthreads();
-    if constexpr (CS <= 24)       // (wider instances run one tile per workgroup: 7-14 staging registers per thread on top of 48-80
-                                  //  accumulators spill, and their k-walk is long enough to be covered by 2-3 resident workgroups)
-        issue_loads(tile + wpx < seg1 ? tile + wpx : tile);      // next tile's region: in flight during the MFMAs and the epilogue
 
     f32x4_t acc[MT][NTW];
 #pragma unroll
@@ -370,9 +370,8 @@ __global__ __launch_bounds__(256, CS <= 16 ? 4 : (CS <= 48 ? 3 : 2)) void conv3_
         const int nn = wv * NTW + n, row = nn / XB, xb = nn - row * XB;
         pixbase[n] = (row * RW + xb * 16 + p) * PS;
     }
-    // K walk: lane group g reads k-slots [(4s+g)*8, +8) = 8 channels starting at cc0 of tap (dy,dx); compile-time per (s, g) when
-    // fully unrolled (narrow convs); the wide ones unroll by two, otherwise every weight fragment of the walk is hoisted to the top
-#pragma unroll(MT >= 3 ? 2 : KS)
+    // K walk: lane group g reads k-slots [(4s+g)*8, +8) = 8 channels starting at cc0 of tap (dy,dx); compile-time per (s, g)
+#pragma unroll
     for (int s = 0; s < KS; ++s) {
         int toff = 0;
 #pragma unroll
@@ -384,7 +383,7 @@ __global__ __launch_bounds__(256, CS <= 16 ? 4 : (CS <= 48 ? 3 : 2)) void conv3_
         }
         bf16x8_t a[MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a[m] = as_frag(wfrag[(m * KS + s) * 64 + lane]);
+        for (int m = 0; m < MT; ++m) a[m] = as_frag(P.wfrag[(m * KS + s) * 64 + lane]);
         bf16x8_t b[NTW];
 #pragma unroll
         for (int n = 0; n < NTW; ++n) b[n] = as_frag(*(const uint4*)(smem + pixbase[n] + toff));
@@ -509,12 +508,10 @@ __global__ __launch_bounds__(256, CS <= 16 ? 4 : (CS <= 48 ? 3 : 2)) void conv3_
         __syncthreads();
         if (tid < 16 * MT) {
             const float sm = red[tid] + red[16 * MT + tid] + red[2 * 16 * MT + tid] + red[3 * 16 * MT + tid];
-            P.pool[((size_t)t * tpf + trem) * (16 * MT) + tid] = sm;
+            const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
+            P.pool[((size_t)t * nblk + blk) * (16 * MT) + tid] = sm;
         }
     }
-    if constexpr (CS > 24) break;                          // one tile per workgroup: lets the staging registers die after the LDS write
-    __syncthreads();                                       // the LDS tile (and red) are rewritten by the next tile
-    }   // tile loop
 }
 
 #ifdef SN_EXPERIMENTAL   // fused CAB: parity green, measured SLOWER than two conv launches (see the note at sn_cab_fused); not on the product path
@@ -702,23 +699,13 @@ int launch_cab_fused(const ConvK& K, const uint4* w2, int T, hipStream_t st) {
 template <int MT, int CS>
 int launch_conv3_fast(const ConvK& K, int T, hipStream_t st) {
     constexpr int TH = 8, TW = 32, NPB = CS / 8, PS = 16 * sn_lds_slots(NPB);
+    dim3 grid((K.wout + TW - 1) / TW, (K.hout + TH - 1) / TH, T);
     const size_t lds = (size_t)(TH + 2) * (TW + 2) * PS + 4 * 16 * MT * sizeof(float);
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)conv3_fast_kernel<MT, CS, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return SN_ELAUNCH;
     }
-    int dev = 0, ncu = 0, per_cu = 0;                      // persistent grid: every workgroup resident, a multiple of 8 for the XCD walk
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1 ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv3_fast_kernel<MT, CS, TH>, 256, lds) != hipSuccess || per_cu < 1)
-        return SN_ELAUNCH;
-    if (per_cu > 8) per_cu = 8;
-    const int ntiles = T * ((K.wout + TW - 1) / TW) * ((K.hout + TH - 1) / TH);
-    int nwg = CS <= 24 ? ncu * per_cu : ntiles;            // persistent with prefetch (narrow) / one tile per workgroup (wide)
-    if (ntiles < nwg) nwg = ntiles;
-    ConvK P = K;
-    P.cv = T;                                              // (cv is a compile-time constant in this kernel: the field carries the frame count)
-    sn_clear_error();
-    hipLaunchKernelGGL((conv3_fast_kernel<MT, CS, TH>), dim3(nwg), dim3(256), lds, st, P);
+    hipLaunchKernelGGL((conv3_fast_kernel<MT, CS, TH>), grid, dim3(256), lds, st, K);
     return sn_check_launch();
 }
 
