@@ -415,7 +415,11 @@ class Engine:
         pool1 = torch.empty((T, lib.sn_lngate_blocks(h, w), c), dtype=torch.float32, device=self.dev) if V.denoise else None
         self._call("sn_ln_gemm_gate", "sn_ln_gemm_gate", C.byref(src), hw_ptr, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(),
                    u["w_dw3_h2"].data_ptr(), g1.data_ptr(), pool1.data_ptr() if pool1 is not None else None, 2 if mstencil else 0, st)
-        ca1_ptr = self.ca_mlp(pre + "ca1", pool1, h * w).data_ptr() if V.denoise else None      # denoise: CALayer2 on g1
+        # denoise: CALayer2 on g1.  `ca1` must stay referenced until the K3 launch below: a temporary would go back to the caching
+        # allocator at once and g2 / pool2, which K3 WRITES, could be carved out of the block K3 still READS its scale from
+        # (intermittent wrong frames at the small pyramid levels; found by the full-size determinism check of config 4).
+        ca1 = self.ca_mlp(pre + "ca1", pool1, h * w) if V.denoise else None
+        ca1_ptr = ca1.data_ptr() if ca1 is not None else None
         g2 = self._new(T, h, w, c)
         if mstencil:
             pool2 = torch.empty((T, lib.sn_dw5m_blocks(h, w), c), dtype=torch.float32, device=self.dev)

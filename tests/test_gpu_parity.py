@@ -435,10 +435,11 @@ def test_full_size_parity_against_fp32_engine(cfg):
         net = net.to(torch.bfloat16)
         xb, nb = x.bfloat16(), (nm.bfloat16() if V.denoise else None)
         y1 = net(xb, nb) if V.denoise else net(xb)
-        y2 = net(xb, nb) if V.denoise else net(xb)
+        again = [net(xb, nb) if V.denoise else net(xb) for _ in range(2)]
     torch.cuda.synchronize()
     assert ref.dtype == torch.float32 and y1.dtype == torch.bfloat16 and y1.shape == ref.shape == (T - 4, 3, H, W)
-    assert torch.isfinite(y1.float()).all() and torch.equal(y1, y2)
+    # bit-reproducible: no atomics, and no buffer handed back to the allocator before its last reader is launched (Engine.naf's ca1)
+    assert torch.isfinite(y1.float()).all() and all(torch.equal(y1, y) for y in again)
     p = _psnr(y1.float(), ref)
     REPORT.append({"name": f"full_size_{cfg}", "psnr_bf16_vs_fp32_engine": p, "max_abs": (y1.float() - ref).abs().max().item()})
     assert p >= 48.0, (cfg, p)
