@@ -445,6 +445,33 @@ def test_full_size_parity_against_fp32_engine(cfg):
     assert p >= 48.0, (cfg, p)
 
 
+def test_denoise_unit_is_reproducible_under_allocator_churn():
+    """Regression for a buffer-lifetime bug of round 2: Engine.naf took `.data_ptr()` of the CALayer2 scale tensor as a temporary,
+    so the caching allocator could hand its block to g2 / pool2 -- which the K3 kernel writes while still reading the scale.
+    With random small allocations between calls the pre-fix code gave 316 differing runs out of 531 (tools/determinism_probe.py
+    documents the search); every run must now be bit-identical."""
+    from shiftnet_amd.engine import Act, Engine, Plan
+    name = "gshift_denoise1"
+    V = O.VARIANTS[name]
+    dev = torch.device("cuda:0")
+    eng = Engine(Plan(V, {k: v.bfloat16() for k, v in synth_state_dict(name).items()}, dev))
+    g = torch.Generator().manual_seed(1)
+    pre = "stage1.decoder_level1.encoder_level1.0."
+    for (T, h, w) in ((36, 34, 56), (8, 17, 28)):
+        x = Act(torch.randn(T, h, w, V.c1, generator=g).to(torch.bfloat16).to(dev), V.c1)
+        for mode in (0, 1, 2):
+            ref = None
+            for _ in range(40):
+                junk = [torch.empty(int(torch.randint(1, 600, (1,))) * 512, dtype=torch.uint8, device=dev) for _ in range(6)]
+                del junk
+                y = eng.naf(pre, x, mode).t
+                torch.cuda.synchronize()
+                if ref is None:
+                    ref = y.clone()
+                else:
+                    assert torch.equal(ref, y), (T, h, w, mode)
+
+
 def test_hipgraph_replay_is_bit_identical_to_eager():
     """SN_GRAPH=1 path: second call captures the whole forward into a hipGraph, later calls replay it; results must be bit
     identical to the eager run and must follow the INPUT (the graph reads a static buffer the new input is copied into)."""
