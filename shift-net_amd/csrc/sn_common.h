@@ -106,6 +106,40 @@ __device__ __forceinline__ int sn_next_frame(int t, int T, int wrap) { return t 
 // wave-uniform wave index (threadIdx-derived values are "divergent" to the compiler; make it provably uniform)
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
+// ---- XCD-aware tile walk for the halo-reading tile kernels (K0, K12, dense convs) ------------------------------------------------
+// The dispatcher hands workgroups to the 8 XCDs round-robin in linear order (x fastest), and every XCD has its own 4 MiB L2.  With
+// the natural grid (tiles_x, tiles_y, T) horizontally adjacent tiles -- which share their halo columns: 18 of K0's 34 -- never meet
+// in one L2, so the halo is fetched from the fabric once per tile (PMC round 2: K0 2.4x, K12 1.37x its algorithmic bytes).  Here
+// the grid is (8 * tiles_x, chunk): blockIdx.x & 7 IS the XCD, blockIdx.x >> 3 the tile column, and XCD k owns the contiguous run
+// [k * chunk, (k + 1) * chunk) of "row-frames" (frame-major tile rows), walked in order: neighbours in x run concurrently on the
+// same XCD, neighbours in y one tile row (tiles_x workgroups) apart, both inside one L2.  A device with another XCD count
+// still gets a bijection, just not the locality.  SN_XCD_TILES=0 restores the natural order (A/B measurements).
+#ifndef SN_XCD_TILES
+#define SN_XCD_TILES 1
+#endif
+struct XcdTiles { int ntx, nty, nrf, chunk; uint32_t inv_nty; };
+static inline XcdTiles sn_xcd_tiles(int ntx, int nty, int T) {
+    XcdTiles g; g.ntx = ntx; g.nty = nty; g.nrf = nty * T;
+    g.chunk = SN_XCD_TILES ? (g.nrf + 7) / 8 : g.nrf;
+    g.inv_nty = nty > 1 ? (uint32_t)((0x100000000ull + (uint32_t)nty - 1) / (uint32_t)nty) : 0u;      // exact quotients while nrf * nty < 2^32
+    return g;
+}
+static inline dim3 sn_xcd_grid(const XcdTiles& g) { return SN_XCD_TILES ? dim3(8u * g.ntx, g.chunk, 1) : dim3(g.ntx, g.nrf, 1); }
+// false: this workgroup is padding of the last XCD's chunk (returns before any barrier)
+__device__ __forceinline__ bool sn_xcd_tile(const XcdTiles& g, int& t, int& ty, int& tx) {
+#if SN_XCD_TILES
+    tx = blockIdx.x >> 3;
+    const uint32_t rf = (blockIdx.x & 7) * g.chunk + blockIdx.y;
+#else
+    tx = blockIdx.x;
+    const uint32_t rf = blockIdx.y;
+#endif
+    if (rf >= (uint32_t)g.nrf) return false;
+    t = g.inv_nty ? (int)__umulhi(rf, g.inv_nty) : (int)rf;
+    ty = (int)rf - t * g.nty;
+    return true;
+}
+
 // hipGetLastError() is per-thread sticky state that other libraries in the process (PyTorch's allocator polling
 // events, ...) may leave set; every entry point therefore clears it BEFORE launching and reads it right after.
 static inline void sn_clear_error() { (void)hipGetLastError(); }

@@ -26,6 +26,7 @@ struct ConvK {
     const void* sc; float* pool; const float* oscale; int oscale_stride; const bf16_t* res2;
     bf16_t* brow; bf16_t* bcol;      // conv3_fast only: first/last row and column of the result, [T][2][w][cs_out] / [T][2][h][cs_out]
     int rh, rw, ps;
+    XcdTiles xg;                     // tile walk of conv_mfma_kernel / conv3_fast_kernel (sn_common.h)
     unsigned m_nblk8, m_rw, m_csb, m_cv, m_k;   // ceil(2^24/d) multipliers: integer division by runtime constants without v_div
 };
 
@@ -64,7 +65,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK P) {
     constexpr int XB = TW / 16;
     const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
     const int g = lane >> 4, p = lane & 15;
-    const int t = blockIdx.z, oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+    int t, tyi, txi;
+    if (!sn_xcd_tile(P.xg, t, tyi, txi)) return;
+    const int oy0 = tyi * TH, ox0 = txi * TW;
     const int tile_bytes = P.rh * P.rw * P.ps;
     int* tapoff = (int*)(smem + tile_bytes);
     float* red = (float*)(smem + tile_bytes + ((P.ks * 4 * 4 + 15) & ~15));
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK P) {
         __syncthreads();
         if (tid < 16 * MT) {
             const float s = red[tid] + red[16 * MT + tid] + red[2 * 16 * MT + tid] + red[3 * 16 * MT + tid];
-            const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
+            const int nblk = P.xg.ntx * P.xg.nty, blk = tyi * P.xg.ntx + txi;
             P.pool[((size_t)t * nblk + blk) * (16 * MT) + tid] = s;
         }
     }
@@ -292,7 +295,9 @@ __global__ __launch_bounds__(256) void conv3_fast_kernel(const ConvK P) {
     constexpr int TILE_BYTES = RH * RW * PS;
     const int tid = threadIdx.x & 255, lane = tid & 63, wv = wave_id();     // (& 255: lets the compiler fold the idx < NITEM guards)
     const int g = lane >> 4, p = lane & 15;
-    const int t = blockIdx.z, oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+    int t, tyi, txi;
+    if (!sn_xcd_tile(P.xg, t, tyi, txi)) return;
+    const int oy0 = tyi * TH, ox0 = txi * TW;
     float* red = (float*)(smem + TILE_BYTES);
 
     {
@@ -508,7 +513,7 @@ __global__ __launch_bounds__(256) void conv3_fast_kernel(const ConvK P) {
         __syncthreads();
         if (tid < 16 * MT) {
             const float sm = red[tid] + red[16 * MT + tid] + red[2 * 16 * MT + tid] + red[3 * 16 * MT + tid];
-            const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
+            const int nblk = P.xg.ntx * P.xg.nty, blk = tyi * P.xg.ntx + txi;
             P.pool[((size_t)t * nblk + blk) * (16 * MT) + tid] = sm;
         }
     }
@@ -699,21 +704,23 @@ int launch_cab_fused(const ConvK& K, const uint4* w2, int T, hipStream_t st) {
 template <int MT, int CS>
 int launch_conv3_fast(const ConvK& K, int T, hipStream_t st) {
     constexpr int TH = 8, TW = 32, NPB = CS / 8, PS = 16 * sn_lds_slots(NPB);
-    dim3 grid((K.wout + TW - 1) / TW, (K.hout + TH - 1) / TH, T);
+    ConvK P = K; P.xg = sn_xcd_tiles((K.wout + TW - 1) / TW, (K.hout + TH - 1) / TH, T);
+    const dim3 grid = sn_xcd_grid(P.xg);
     const size_t lds = (size_t)(TH + 2) * (TW + 2) * PS + 4 * 16 * MT * sizeof(float);
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)conv3_fast_kernel<MT, CS, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return SN_ELAUNCH;
     }
-    hipLaunchKernelGGL((conv3_fast_kernel<MT, CS, TH>), grid, dim3(256), lds, st, K);
+    hipLaunchKernelGGL((conv3_fast_kernel<MT, CS, TH>), grid, dim3(256), lds, st, P);
     return sn_check_launch();
 }
 
 template <int TH, int TW>
 int launch_conv(const ConvK& K, int mt, int T, hipStream_t st) {
-    dim3 grid((K.wout + TW - 1) / TW, (K.hout + TH - 1) / TH, T);
     const int rh = (TH - 1) * K.stride + K.k, rw = (TW - 1) * K.stride + K.k;
     ConvK P = K; P.rh = rh; P.rw = rw;
+    P.xg = sn_xcd_tiles((K.wout + TW - 1) / TW, (K.hout + TH - 1) / TH, T);
+    const dim3 grid = sn_xcd_grid(P.xg);
     auto magic = [](int d) { return (unsigned)(((1u << 24) + d - 1) / d); };
     P.m_nblk8 = magic(P.cv >> 3); P.m_rw = magic(rw); P.m_csb = magic(P.cs >> 3); P.m_cv = magic(P.cv); P.m_k = magic(P.k);
     const size_t lds = (size_t)rh * rw * P.ps + ((P.ks * 16 + 15) & ~15) + 4 * 16 * mt * sizeof(float);

@@ -61,12 +61,14 @@ __global__ void gather_kernel(const UnitK U, const int8_t* offs, bf16_t* u, cons
 // ------------------------------------------------------------------------------------------------------------
 // K0: hw[t][p][k] = sum_tap w1[k][tap] * [p+tap in image] * shifted_k(p+tap),  shifted_k(q) = x[fb][q + off_k][ob + k] or 0
 template <int CH>
-__global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const int8_t* __restrict__ offs,
+__global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const XcdTiles G, const int8_t* __restrict__ offs,
                                                       const uint32_t* __restrict__ w1d, bf16_t* hw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RW = 34, PSB = CH * 2 + 4;       // odd number of dwords per pixel: lanes = pixels hit distinct banks
     constexpr int PCS = CH / 8;
-    const int tid = threadIdx.x, t = blockIdx.z, y0 = blockIdx.y * 16, x0 = blockIdx.x * 16;
+    int t, ty_, tx_;
+    if (!sn_xcd_tile(G, t, ty_, tx_)) return;      // XCD-aware walk: the 34-wide windows of x-neighbours overlap by 18 columns
+    const int tid = threadIdx.x, y0 = ty_ * 16, x0 = tx_ * 16;
     const Slabs s = unit_slabs(U, t);
     const bf16_t* src = U.x + (ptrdiff_t)s.fb * U.h * U.w * U.C + s.ob;
     {   // staging: issue ALL global loads first (branch-free, clamped addresses), then mask + write to LDS: one memory
@@ -496,15 +498,16 @@ int sn_temporal_roll(const sn_unit_src* s, void* y, void* stream) {
 int sn_gsts_shiftconv(const sn_unit_src* s, const int8_t* offs, const uint32_t* w1, void* hw, void* stream) {
     sn_clear_error();
     if (!unit_ok(s) || !offs || !w1 || !hw || s->mode == 0) return SN_EINVAL;
-    dim3 grid((s->w + 15) / 16, (s->h + 15) / 16, s->T);
+    const XcdTiles G = sn_xcd_tiles((s->w + 15) / 16, (s->h + 15) / 16, s->T);
+    const dim3 grid = sn_xcd_grid(G);
     if (s->C == 64) {
         const size_t lds = 34 * 34 * (32 * 2 + 4);
         if (hipFuncSetAttribute((const void*)shiftconv_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH;
-        hipLaunchKernelGGL(shiftconv_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, to_k(s), offs, w1, (bf16_t*)hw);
+        hipLaunchKernelGGL(shiftconv_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, to_k(s), G, offs, w1, (bf16_t*)hw);
     } else {
         const size_t lds = 34 * 34 * (40 * 2 + 4);
         if (hipFuncSetAttribute((const void*)shiftconv_kernel<40>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH;
-        hipLaunchKernelGGL(shiftconv_kernel<40>, grid, dim3(256), lds, (hipStream_t)stream, to_k(s), offs, w1, (bf16_t*)hw);
+        hipLaunchKernelGGL(shiftconv_kernel<40>, grid, dim3(256), lds, (hipStream_t)stream, to_k(s), G, offs, w1, (bf16_t*)hw);
     }
     return sn_check_launch();
 }

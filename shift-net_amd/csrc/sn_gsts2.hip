@@ -35,7 +35,7 @@ __device__ __forceinline__ Slabs2 unit_slabs2(const UnitK2& U, int t) {
 #define SN_K12_NWV 8
 #endif
 template <int C, bool WITH_HW>
-__global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const UnitK2 U, const bf16_t* __restrict__ hwb, const uint4* __restrict__ wfrag,
+__global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const UnitK2 U, const XcdTiles G, const bf16_t* __restrict__ hwb, const uint4* __restrict__ wfrag,
                                                          const float* __restrict__ bias, const uint32_t* __restrict__ wdw,
                                                          bf16_t* g1, float* pool, const int blocked, const int dbg_, unsigned long long* prof_) {
 #ifdef SN_EXPERIMENTAL
@@ -51,7 +51,9 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
     __shared__ __attribute__((aligned(16))) char lds_a2[2][NPX * PSA];           // double-buffered a-chunk: one barrier per chunk
     __shared__ __attribute__((aligned(16))) uint16_t lds_tr[NWV][8][64];          // per-wave transpose scratch of the planar epilogue
     const int lane = threadIdx.x & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
-    const int t = blockIdx.z, oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+    int t, tyi, txi;
+    if (!sn_xcd_tile(G, t, tyi, txi)) return;     // XCD-aware walk (sn_common.h): ring rows / columns of neighbouring tiles meet in one L2
+    const int oy0 = tyi * TH, ox0 = txi * TW;
     const int hw = U.h * U.w;
     const Slabs2 sl = unit_slabs2(U, t);
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
                         sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
                         if (lane == 0) {
                             constexpr int NPG = (TH * TW) / 64;
-                            const int nblk = NPG * gridDim.x * gridDim.y, blk = NPG * (blockIdx.y * gridDim.x + blockIdx.x) + pg;
+                            const int nblk = NPG * G.ntx * G.nty, blk = NPG * (tyi * G.ntx + txi) + pg;
                             pool[((size_t)t * nblk + blk) * C + gs * 2 * MT + q * 4 + j] = sm;
                         }
                     }
@@ -253,9 +255,9 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
             tick(4);
         }
     }
-    if (prof && lane == 0 && blockIdx.z == 0 && blockIdx.y * gridDim.x + blockIdx.x < 256) {
+    if (prof && lane == 0 && t == 0 && tyi * G.ntx + txi < 256) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) prof[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wv) * 8 + k] = tacc[k];
+        for (int k = 0; k < 8; ++k) prof[((size_t)(tyi * G.ntx + txi) * 8 + wv) * 8 + k] = tacc[k];
     }
 }
 
@@ -690,9 +692,10 @@ int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, con
     if (!s || !s->x || (s->C != 64 && s->C != 80) || s->mode < 0 || s->mode > 2 || !wfrag || !bias || !wdw || !g1 ||
         (s->mode != 0 && !hw) || (g1_blocked && s->C != 64) || g1_blocked < 0 || g1_blocked > 2) return SN_EINVAL;
     UnitK2 u; u.x = (const bf16_t*)s->x; u.T = s->T; u.h = s->h; u.w = s->w; u.C = s->C; u.mode = s->mode; u.wrap = s->wrap;
-    dim3 grid((s->w + 31) / 32, (s->h + SN_K12_TH - 1) / SN_K12_TH, s->T);
+    const XcdTiles G = sn_xcd_tiles((s->w + 31) / 32, (s->h + SN_K12_TH - 1) / SN_K12_TH, s->T);
+    const dim3 grid = sn_xcd_grid(G);
     hipStream_t st = (hipStream_t)stream;
-#define SN_LAUNCH_K12(CC, HW_) hipLaunchKernelGGL((ln_gemm_gate_kernel<CC, HW_>), grid, dim3(SN_K12_NWV * 64), 0, st, u, (const bf16_t*)hw, \
+#define SN_LAUNCH_K12(CC, HW_) hipLaunchKernelGGL((ln_gemm_gate_kernel<CC, HW_>), grid, dim3(SN_K12_NWV * 64), 0, st, u, G, (const bf16_t*)hw, \
         (const uint4*)wfrag, bias, wdw, (bf16_t*)g1, pool, g1_blocked, SN_DBG_MASK, SN_DBG_BUF(256))
     if (s->C == 64) { if (s->mode) SN_LAUNCH_K12(64, true); else SN_LAUNCH_K12(64, false); }
     else { if (s->mode) SN_LAUNCH_K12(80, true); else SN_LAUNCH_K12(80, false); }
