@@ -76,6 +76,25 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
     load_w(0);
 
     // ---- LayerNorm of every pixel of the ring-extended tile; results stay in registers as MFMA B fragments ----
+    // Lane group g reads k-slots [s*32 + g*8, +8) of its pixel: which slab that is (first / second half of x, or hw) depends on
+    // (s, g) only, so ONE 64-bit slab pointer and pixel stride per k-step are chosen up front and a load costs a 32-bit multiply
+    // and one 64-bit add (the former per-load pointer selects were ~100 VALU instructions of this VALU-bound kernel).
+    const bf16_t* slab[KS];
+    int sstride[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int kk0 = s * 32 + g * 8;
+        const bf16_t* b0 = U.x + (ptrdiff_t)sl.f0 * hw * C + sl.o0 + (kk0 < CH ? kk0 : 0);
+        const bf16_t* b1 = U.x + (ptrdiff_t)sl.f1 * hw * C + sl.o1 + (kk0 >= CH && kk0 < C ? kk0 - CH : 0);
+        slab[s] = kk0 < CH ? b0 : b1;                   // padding slots (kk0 >= K) re-read x and are zeroed below
+        sstride[s] = C;
+        if (WITH_HW) {
+            const bf16_t* b2 = hwb + (size_t)t * hw * CH + (kk0 >= C && kk0 < K ? kk0 - C : 0);
+            const bool ishw = kk0 >= C && kk0 < K;
+            slab[s] = ishw ? b2 : slab[s];
+            sstride[s] = ishw ? CH : C;
+        }
+    }
     bf16x8_t B[NTW][KS];
     bool inimg[NTW];
 #pragma unroll
@@ -87,44 +106,48 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
         const bool in = (tile < NTILES) && (rp < NPX) && gy >= 0 && gy < U.h && gx >= 0 && gx < U.w;
         inimg[n] = in;
         const int ii = in ? gy * U.w + gx : 0;
-        float xv[KS][8];
-        float sum = 0.f;
+        // branch-free: ALWAYS load (a load inside a divergent branch is waited for on the spot, one memory round trip per slab)
+        uint4 raw[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) raw[s] = *(const uint4*)(slab[s] + (dbg & 8 ? 0 : ii * sstride[s]));
+        f32x2_t xv[KS][4];
+        f32x2_t sum2 = {0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const int kk0 = s * 32 + g * 8;
-            // branch-free: pick the address with selects and ALWAYS load (a load inside a divergent branch is waited
-            // for on the spot, one memory round trip per slab); padding slabs re-read x and are zeroed afterwards
-            const bool has = kk0 < K && !(dbg & 8);
-            const bf16_t* s0 = U.x + ((ptrdiff_t)sl.f0 * hw + ii) * C + sl.o0 + (kk0 < CH ? kk0 : 0);
-            const bf16_t* s1 = U.x + ((ptrdiff_t)sl.f1 * hw + ii) * C + sl.o1 + (kk0 >= CH && kk0 < C ? kk0 - CH : 0);
-            const bf16_t* src = kk0 < CH ? s0 : s1;
-            if (WITH_HW) {
-                const bf16_t* s2 = hwb + ((size_t)t * hw + ii) * CH + (kk0 >= C && kk0 < K ? kk0 - C : 0);
-                src = kk0 >= C ? s2 : src;
+            uint4 q = raw[s];
+            if ((KS - 1) * 32 + 24 >= K && s == KS - 1) {     // only the last k-step of the 80-channel variants has padding slots
+                const bool has = s * 32 + g * 8 < K;
+                q.x = has ? q.x : 0u; q.y = has ? q.y : 0u; q.z = has ? q.z : 0u; q.w = has ? q.w : 0u;
             }
-            unpack8(*(const uint4*)src, xv[s]);
+            if (dbg & 8) q = make_uint4(0, 0, 0, 0);
+            xv[s][0] = (f32x2_t){bf_lo(q.x), bf_hi(q.x)}; xv[s][1] = (f32x2_t){bf_lo(q.y), bf_hi(q.y)};
+            xv[s][2] = (f32x2_t){bf_lo(q.z), bf_hi(q.z)}; xv[s][3] = (f32x2_t){bf_lo(q.w), bf_hi(q.w)};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { xv[s][j] = has ? xv[s][j] : 0.f; sum += xv[s][j]; }
+            for (int j = 0; j < 4; ++j) sum2 += xv[s][j];    // packed fp32 (v_pk_add_f32): two partial sums per lane
         }
-        sum = sum_rows4(sum);
-        const float mean = sum * (1.0f / K);
-        float sq = 0.f;
+        const float mean = sum_rows4(sum2[0] + sum2[1]) * (1.0f / K);
+        const f32x2_t mean2 = {mean, mean};
+        f32x2_t sq2 = {0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const bool has = (s * 32 + g * 8) < K;
+            const bool pad = (KS - 1) * 32 + 24 >= K && s == KS - 1 && !(s * 32 + g * 8 < K);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float d = has ? xv[s][j] - mean : 0.f;
-                xv[s][j] = d; sq += d * d;
+            for (int j = 0; j < 4; ++j) {
+                f32x2_t d = xv[s][j] - mean2;
+                if ((KS - 1) * 32 + 24 >= K && s == KS - 1) d = pad ? (f32x2_t){0.f, 0.f} : d;
+                xv[s][j] = d;
+                sq2 = __builtin_elementwise_fma(d, d, sq2);   // v_pk_fma_f32
             }
         }
-        sq = sum_rows4(sq);
+        const float sq = sum_rows4(sq2[0] + sq2[1]);
         const float rstd = 1.0f / sqrtf(sq * (1.0f / K) + 1e-6f);
+        const f32x2_t rstd2 = {rstd, rstd};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xv[s][j] *= rstd;
-            B[n][s] = as_frag(pack8(xv[s]));
+            uint4 o;
+            f32x2_t a = xv[s][0] * rstd2, b = xv[s][1] * rstd2, c = xv[s][2] * rstd2, d = xv[s][3] * rstd2;
+            o.x = pack_bf2(a[0], a[1]); o.y = pack_bf2(b[0], b[1]); o.z = pack_bf2(c[0], c[1]); o.w = pack_bf2(d[0], d[1]);
+            B[n][s] = as_frag(o);
         }
     }
 

@@ -261,6 +261,186 @@ void dw5m_gemm_gate_kernel(const bf16_t* __restrict__ g1p, const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// K3w: the same operator and tile (64 x 8 pixels, 1024 persistent threads, XCD-aware walk), restructured around the finding
+// that dw5m_gemm_gate_kernel is bound by the skew of its five workgroup barriers per tile (42 % of wave cycles in s_barrier).
+// Here every wave stages ITS OWN two channels of the step (12 rows x 80 columns, 3.84 KB) into a wave-private LDS image: LDS
+// operations of one wave execute in order, so the staging needs no barrier at all and the 16 waves drift freely through the
+// Toeplitz phase (loads, LDS writes, B reads and MFMAs of different waves overlap instead of running in lock-step).  A step
+// is 32 channels (wave w = channel pair 16 s + w, both row halves, the band fragment of a (channel, dy) shared by the halves:
+// half the table reads), so phase 1 is two steps and the tile has TWO barriers: r complete / r consumed.  Same LDS budget
+// (table 25.6 KB + 16 x 3.84 KB images + r 66 KB), same r layout and phase 2 as dw5m_gemm_gate_kernel, bit-identical results
+// (tools/ab_k3m.py: 9 shapes incl. ragged ones, g2 and pool equal bit for bit).
+// MEASURED: standalone on a cold 590 MB input (20 x 360 x 640) 419 vs 460 us, 100 vs 100 us at level 2; inside the network, where
+// g1 was written by K12 a moment earlier, 24.2 vs 23.0 ms per window (config 2) -- slower.  The lock-step kernel profits from the
+// warm L2 / Infinity Cache, the free-running one from hiding HBM latency; the product path keeps dw5m_gemm_gate_kernel and this
+// shape is a compile-time option (-DSN_K3M_WAVE=1).
+constexpr int K3W_WIMG = 2 * 12 * K3M_RX * 2;                                   // 3840 B per wave
+constexpr int K3W_LDS = K3M_TAB_BYTES + 16 * K3W_WIMG + (K3M_C / 2) * (K3M_TW * 8 + 4) * 4 + 16 * 32 * 4;      // 155136
+
+__global__ __launch_bounds__(1024, 1)
+void dw5w_gemm_gate_kernel(const bf16_t* __restrict__ g1p, const float* __restrict__ ca_in, const uint32_t* __restrict__ ttab,
+                           const uint4* __restrict__ wfrag, bf16_t* g2, float* pool, int T, int h, int w, int wr) {
+    constexpr int C = K3M_C, TW = K3M_TW, TH = 8, RH = 12, RX = K3M_RX, KS = 2, RP = TW * TH + 4, NWV = 16, NTHR = 1024, NIT = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t* tab = (const uint32_t*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
+    char* wimg = smem + K3M_TAB_BYTES + wv * K3W_WIMG;                          // [2 channels][RH][RX] bf16, private to this wave
+    uint32_t* lds_r = (uint32_t*)(smem + K3M_TAB_BYTES + NWV * K3W_WIMG);       // [32 channel pairs][RP]
+    float* red = (float*)((char*)lds_r + (C / 2) * RP * 4);
+    const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH, tpf = tiles_x * tiles_y, ntiles = T * tpf;
+    const size_t frame = (size_t)h * C * wr;
+
+    for (int e = tid; e < K3M_TAB_BYTES / 4; e += NTHR) ((uint32_t*)smem)[e] = ttab[e];
+    const int ng = wv >> 1, mh = wv & 1;                                        // phase-2 role, as in dw5m_gemm_gate_kernel
+    bf16x8_t A2[4][KS];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) A2[m][s] = as_frag(wfrag[((4 * mh + m) * KS + s) * 64 + lane]);
+
+    // staging item k of this lane: 16 B = 8 columns of (channel cl of the pair, region row, piece xc); 240 items per wave and step
+    int lofs[NIT], irow[NIT], ixc[NIT], icl[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int idx = lane + 64 * k;
+        const int cl = idx >= RH * (RX / 8) ? 1 : 0, rem = idx - cl * (RH * (RX / 8)), row = rem / (RX / 8), xc = rem - row * (RX / 8);
+        const bool live = idx < 2 * RH * (RX / 8);
+        lofs[k] = live ? ((cl * RH + row) * RX + xc * 8) * 2 : -1;
+        irow[k] = row; ixc[k] = xc; icl[k] = cl;
+    }
+    auto plan_tile = [&](int tile, int* gofs) {          // in-frame element offset of each item relative to the pair's first channel, or -1
+        const int t = tile / tpf, rem = tile - t * tpf, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int gy = ty * TH - 2 + irow[k], gx = tx * TW - 8 + ixc[k] * 8;
+            gofs[k] = (lofs[k] >= 0 && gy >= 0 && gy < h && gx >= 0 && gx < wr) ? (gy * C + icl[k]) * wr + gx : -1;
+        }
+        return t;
+    };
+    auto issue_loads = [&](uint4* stg, const int* gofs, int t, int s) {          // unconditional, clamped; masked at the LDS write
+        const bf16_t* gt = g1p + (size_t)t * frame + (size_t)(32 * s + 2 * wv) * wr;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) stg[k] = *(const uint4*)(gt + (gofs[k] < 0 ? 0 : gofs[k]));
+    };
+    auto write_img = [&](const uint4* stg, const int* gofs) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+            if (lofs[k] >= 0) *(uint4*)(wimg + lofs[k]) = gofs[k] < 0 ? make_uint4(0, 0, 0, 0) : stg[k];
+    };
+
+    const int xt = p & 3, rr = p >> 2;
+    const int s0 = 1 - p + 8 * g;                                               // band window of this lane, see dw5m_gemm_gate_kernel
+    const int twx = (s0 < 0 || s0 > 5) ? 0 : ((s0 & 1) ? 10 + (s0 + 5) / 2 : (s0 + 6) / 2);
+    const int tww = (s0 < 6 || s0 > 11) ? 0 : ((s0 & 1) ? 10 + (s0 - 1) / 2 : s0 / 2);
+    const int boff = (rr * RX + 16 * xt + 8 * g) * 2;                           // + ((ci * RH + 4 hf + dy) * RX) * 2
+    const int px0 = rr * TW + 16 * xt + 4 * g;                                  // + 4 hf * TW
+
+    // Toeplitz MFMAs of step s (channels 32 s + 2 wv, + 1) from the private image -> the pair's r plane
+    auto toeplitz = [&](int s, int t) {
+        f32x4_t D[2][2];
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci) {
+            const int c = 32 * s + 2 * wv + ci;
+            f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dy = 0; dy < 5; ++dy) {
+                const int x3 = (int)tab[(c * 5 + dy) * 20 + twx], w0 = (int)tab[(c * 5 + dy) * 20 + tww];
+                const int d1 = __builtin_amdgcn_update_dpp(dpp_movi<0x104>(x3), w0, 0x112, 0xf, 0xf, false);
+                const int d2 = __builtin_amdgcn_update_dpp(dpp_movi<0x114>(w0), x3, 0x102, 0xf, 0xf, false);
+                const bf16x8_t A = as_frag(make_uint4((uint32_t)w0, (uint32_t)d1, (uint32_t)d2, (uint32_t)x3));
+                const char* gb = wimg + boff + ((ci * RH + dy) * RX) * 2;
+                a0 = mfma16(A, as_frag(*(const uint4*)gb), a0);
+                a1 = mfma16(A, as_frag(*(const uint4*)(gb + 4 * RX * 2)), a1);
+            }
+            const float sc = ca_in ? ca_in[(size_t)t * C + c] : 1.f;
+            D[0][ci] = a0 * sc; D[1][ci] = a1 * sc;
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+            *(uint4*)(lds_r + (16 * s + wv) * RP + px0 + 4 * hf * TW) =
+                make_uint4(pack_bf2(D[hf][0][0], D[hf][1][0]), pack_bf2(D[hf][0][1], D[hf][1][1]),
+                           pack_bf2(D[hf][0][2], D[hf][1][2]), pack_bf2(D[hf][0][3], D[hf][1][3]));
+    };
+
+    const int nxcd = (gridDim.x % 8 == 0) ? 8 : 1, wpx = gridDim.x / nxcd, seg = (ntiles + nxcd - 1) / nxcd;
+    const int seg0 = (blockIdx.x % nxcd) * seg, seg1 = seg0 + seg < ntiles ? seg0 + seg : ntiles;
+    int tile = seg0 + blockIdx.x / nxcd;
+
+    uint4 stg[NIT];
+    int gofs[NIT], gofs_n[NIT];
+    int t = plan_tile(tile < seg1 ? tile : 0, gofs), tn = t;
+    issue_loads(stg, gofs, t, 0);
+    write_img(stg, gofs);                                   // step 0 of the first tile
+    issue_loads(stg, gofs, t, 1);                           // step 1 in flight
+    __syncthreads();                                        // band table ready
+    for (; tile < seg1; tile += wpx) {
+        const int rem = tile - t * tpf, tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
+        const int y0 = tyi * TH, x0 = txi * TW;
+        const int ntile = tile + wpx < seg1 ? tile + wpx : tile;         // past the end: re-read this tile
+        tn = plan_tile(ntile, gofs_n);
+        toeplitz(0, t);
+        write_img(stg, gofs);                               // step 1 -> the image (in order behind step 0's reads of this wave)
+        issue_loads(stg, gofs_n, tn, 0);
+        toeplitz(1, t);
+        write_img(stg, gofs_n);                             // next tile's step 0
+        issue_loads(stg, gofs_n, tn, 1);
+        __syncthreads();                                    // r complete
+
+        float ps[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) ps[j][r4] = 0.f;
+#pragma unroll 1
+        for (int n = 0; n < 4; ++n) {
+            const int tp = (ng * 4 + n) * 16 + p;
+            bf16x8_t Bf[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const uint32_t* rp = lds_r + (16 * s + 4 * g) * RP + tp;
+                Bf[s] = as_frag(make_uint4(rp[0], rp[RP], rp[2 * RP], rp[3 * RP]));
+            }
+            f32x4_t acc[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) acc[m] = mfma16(A2[m][s], Bf[s], acc[m]);
+            }
+            const int oy = y0 + tp / TW, ox = x0 + (tp % TW);
+            if (oy < h && ox < w) {
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v[4];
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) { v[r4] = acc[2 * j][r4] * sigmoidf_(acc[2 * j + 1][r4]); ps[j][r4] += v[r4]; }
+                    o[2 * j] = pack_bf2(v[0], v[1]); o[2 * j + 1] = pack_bf2(v[2], v[3]);
+                }
+                *(uint4*)(g2 + (((size_t)t * h + oy) * w + ox) * C + g * 16 + mh * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float sm = row_sum16(ps[j][r4]);
+                if (p == 0) red[wv * 32 + g * 8 + j * 4 + r4] = sm;
+            }
+        __syncthreads();                                    // r consumed, red complete
+        if (pool && tid < C) {
+            float sm = 0.f;
+#pragma unroll
+            for (int k = 0; k < NWV / 2; ++k) sm += red[(2 * k + ((tid >> 3) & 1)) * 32 + (tid >> 4) * 8 + (tid & 7)];
+            pool[((size_t)t * tpf + rem) * C + tid] = sm;
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) gofs[k] = gofs_n[k];
+        t = tn;
+    }
+}
+
 #ifdef SN_EXPERIMENTAL   // K12m: parity green, not faster than sn_ln_gemm_gate yet; off the production path
 // ------------------------------------------------------------------------------------------------------------
 // K12m: g1 = SimpleGate(RepConv2(body[0](norm(u)))) for C = 64 with the depthwise 3x3 on the matrix cores, g1 written
@@ -533,6 +713,21 @@ static int launch_k3m(const void* g1p, const float* ca_in, const void* ttab, con
     return sn_check_launch();
 }
 
+static int launch_k3w(const void* g1p, const float* ca_in, const void* ttab, const void* wfrag, void* g2, float* pool, int T, int h, int w,
+                      void* stream) {
+    const int ntiles = T * ((h + 7) / 8) * ((w + K3M_TW - 1) / K3M_TW);
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1)
+        return SN_ELAUNCH;
+    const int nwg = ntiles < ncu ? ntiles : ncu;
+    if (hipFuncSetAttribute((const void*)dw5w_gemm_gate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, K3W_LDS) != hipSuccess)
+        return SN_ELAUNCH;
+    sn_clear_error();
+    hipLaunchKernelGGL(dw5w_gemm_gate_kernel, dim3(nwg), dim3(1024), K3W_LDS, (hipStream_t)stream, (const bf16_t*)g1p, ca_in,
+                       (const uint32_t*)ttab, (const uint4*)wfrag, (bf16_t*)g2, pool, T, h, w, sn_planar_pitch(w));
+    return sn_check_launch();
+}
+
 extern "C" {
 
 int sn_planar_pitch(int w) { return (w + 7) & ~7; }
@@ -578,6 +773,9 @@ int sn_ln_gemm_gate_m(const sn_unit_src* s, const void* hw, const void* wfrag, c
 #ifndef SN_K3M_TH
 #define SN_K3M_TH 8
 #endif
+#ifndef SN_K3M_WAVE          // 1: wave-private staging, two barriers per tile (dw5w_gemm_gate_kernel; slower inside the network, see there)
+#define SN_K3M_WAVE 0
+#endif
 
 int sn_dw5m_blocks(int h, int w) { return ((h + SN_K3M_TH - 1) / SN_K3M_TH) * ((w + K3M_TW - 1) / K3M_TW); }
 
@@ -585,7 +783,11 @@ int sn_dw5m_gemm_gate(const void* g1p, const float* ca_in, const void* ttab, con
                       int T, int h, int w, int C, void* stream) {
     sn_clear_error();
     if (!g1p || !ttab || !wfrag || !g2 || C != 64 || T < 1 || h < 1 || w < 1) return SN_EINVAL;
+#if SN_K3M_WAVE && SN_K3M_TH == 8
+    return launch_k3w(g1p, ca_in, ttab, wfrag, g2, pool, T, h, w, stream);
+#else
     return launch_k3m<SN_K3M_TH>(g1p, ca_in, ttab, wfrag, g2, pool, T, h, w, stream);
+#endif
 }
 
 }  // extern "C"
