@@ -58,8 +58,24 @@ __device__ __forceinline__ uint4 ld_bilinear(const bf16_t* src, int t, int hs, i
     return pack8(o);
 }
 
+// Register budgets.  Without a waves-per-SIMD target hipcc keeps ~64-100 architectural VGPRs and parks the MFMA accumulators in
+// AGPRs on top of them: the unified file then holds 108 registers per lane for the 24-channel 3x3 conv (4 waves per SIMD) where
+// 72 are needed (7 waves), 144 instead of 110 for the 40-channel one, 171 instead of 148 for K4.  These kernels hide their
+// load -> barrier -> MFMA -> store latency ONLY through co-resident workgroups, so every one states the occupancy it can reach
+// without spilling (probed per instantiation with -Rpass-analysis=kernel-resource-usage; SN_OCC_AGGR=1 accepts 2-6 spilled
+// registers for one more wave, for A/B runs).
+#ifndef SN_OCC_AGGR
+#define SN_OCC_AGGR 0
+#endif
+constexpr int sn_conv_waves(int mt, int th) {         // generic conv: 8x32 / 4x16 tiles; the 16x32 shape is left to the compiler
+    return th == 16 ? 1 : (mt == 1 ? 6 : mt == 2 ? 5 : mt == 3 ? 4 : mt == 4 ? 3 : 2);
+}
+constexpr int sn_conv3_waves(int mt, int cs) {
+    return mt == 1 ? 7 : mt == 2 ? 6 : mt == 3 ? ((cs == 48 && !SN_OCC_AGGR) ? 3 : 4) : mt == 4 ? 3 : 2;
+}
+
 template <int MT, int TH, int TW>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK P) {
+__global__ __launch_bounds__(256, sn_conv_waves(MT, TH)) void conv_mfma_kernel(const ConvK P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTW = (TH * TW) / 64;      // N-tiles (16 pixels) per wave
     constexpr int XB = TW / 16;
@@ -281,7 +297,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK P) {
 // config 2: the prefetch and the loop-carried state take the kernel from 32-48 to 107-155 VGPRs, and at 3.8-5.1 TB/s this kernel
 // hides its load latency through occupancy (6-8 resident workgroups per CU), not through software pipelining.
 template <int MT, int CS, int TH>
-__global__ __launch_bounds__(256) void conv3_fast_kernel(const ConvK P) {
+__global__ __launch_bounds__(256, sn_conv3_waves(MT, CS)) void conv3_fast_kernel(const ConvK P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TW = 32, RH = TH + 2, RW = TW + 2, NPB = CS / 8;
     // LDS bytes per pixel = k slots of 16 B with k the smallest value >= CS/8 that is 2 mod 4.  ds_read_b128 is serviced in the lane
@@ -364,11 +380,14 @@ __global__ __launch_bounds__(256) void conv3_fast_kernel(const ConvK P) {
     }
     __syncthreads();
 
+    // accumulators start at the bias (the zero-initialisation they replace cost the same moves; saves the epilogue adds)
     f32x4_t acc[MT][NTW];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m) {
+        const float4 b4 = P.bias ? *(const float4*)(P.bias + c0 + m * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int n = 0; n < NTW; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NTW; ++n) acc[m][n] = (f32x4_t){b4.x, b4.y, b4.z, b4.w};
+    }
     int pixbase[NTW];
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
@@ -404,12 +423,11 @@ __global__ __launch_bounds__(256) void conv3_fast_kernel(const ConvK P) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) psum[m][r] = 0.f;
-    float4 bia[MT], osc[MT];
+    float4 osc[MT];
+    const bool has_osc = P.oscale != nullptr;                       // wave-uniform: the first conv of a CAB has no output scale
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        bia[m] = P.bias ? *(const float4*)(P.bias + c0 + m * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        osc[m] = P.oscale ? *(const float4*)(P.oscale + (size_t)t * P.oscale_stride + c0 + m * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
-    }
+    for (int m = 0; m < MT; ++m)
+        osc[m] = has_osc ? *(const float4*)(P.oscale + (size_t)t * P.oscale_stride + c0 + m * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
     const float slope = P.prelu;
     // PReLU: for a slope in [0, 1] (every trained / synthetic checkpoint of this family) x >= 0 ? x : a*x == max(x, a*x):
     // two instructions per value; any other slope takes the general max(x,0) + a*min(x,0) form.  Wave-uniform choice.
@@ -419,8 +437,7 @@ __global__ __launch_bounds__(256) void conv3_fast_kernel(const ConvK P) {
         float v[MT][4];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            v[m][0] = acc[m][n][0] + bia[m].x; v[m][1] = acc[m][n][1] + bia[m].y;
-            v[m][2] = acc[m][n][2] + bia[m].z; v[m][3] = acc[m][n][3] + bia[m].w;
+            v[m][0] = acc[m][n][0]; v[m][1] = acc[m][n][1]; v[m][2] = acc[m][n][2]; v[m][3] = acc[m][n][3];
             if (act == 1) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[m][r] = fmaxf(v[m][r], slope * v[m][r]);
@@ -428,7 +445,7 @@ __global__ __launch_bounds__(256) void conv3_fast_kernel(const ConvK P) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[m][r] = fmaf(slope, fminf(v[m][r], 0.f), fmaxf(v[m][r], 0.f));
             }
-            v[m][0] *= osc[m].x; v[m][1] *= osc[m].y; v[m][2] *= osc[m].z; v[m][3] *= osc[m].w;
+            if (has_osc) { v[m][0] *= osc[m].x; v[m][1] *= osc[m].y; v[m][2] *= osc[m].z; v[m][3] *= osc[m].w; }
         }
         const bool ok = valid[n];
         if constexpr (PRE_RES) {
@@ -463,10 +480,12 @@ __global__ __launch_bounds__(256) void conv3_fast_kernel(const ConvK P) {
                 }
             }
             bf16_t* dst = outb + loff[n];
+            if (P.pool) {                                           // wave-uniform
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) psum[m][r] += v[m][r];
+                    for (int r = 0; r < 4; ++r) psum[m][r] += v[m][r];
+            }
             if (P.brow) {       // pass A of the fused CAB: `mid` is never stored, only its border lines (sn_cab_ca needs their sums)
                 const int nn = wv * NTW + n, row = nn / XB, xb = nn - row * XB;
                 const int oy = oy0 + row, ox = ox0 + xb * 16 + p;

@@ -401,8 +401,12 @@ __global__ __launch_bounds__(256) void dw_gemm_gate_kernel(const bf16_t* __restr
 
 // ------------------------------------------------------------------------------------------------------------
 // K4: y = shortcut + W3' . (ca * g2) (+ bias'), beta folded into W3'/bias'; shortcut = rolled x (CAB2) or x (CAB1)
+// waves-per-SIMD target: see the register-budget note in sn_conv.hip (91 VGPRs + 80 AGPRs = 2 waves without it; 148 / 152 = 3 waves)
+#ifndef SN_OCC_AGGR
+#define SN_OCC_AGGR 0
+#endif
 template <int C>
-__global__ __launch_bounds__(256) void scale_gemm_res_kernel(const UnitK U, const bf16_t* __restrict__ g2, const float* __restrict__ ca,
+__global__ __launch_bounds__(256, (C == 64 && SN_OCC_AGGR) ? 4 : 3) void scale_gemm_res_kernel(const UnitK U, const bf16_t* __restrict__ g2, const float* __restrict__ ca,
                                                            const uint4* __restrict__ wfrag, const float* __restrict__ bias, bf16_t* y) {
     constexpr int CH = C / 2, KS = (C + 31) / 32, MT = C / 16, NT = 4;
     const int lane = threadIdx.x & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
