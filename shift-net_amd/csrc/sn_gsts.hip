@@ -60,92 +60,104 @@ __global__ void gather_kernel(const UnitK U, const int8_t* offs, bf16_t* u, cons
 
 // ------------------------------------------------------------------------------------------------------------
 // K0: hw[t][p][k] = sum_tap w1[k][tap] * [p+tap in image] * shifted_k(p+tap),  shifted_k(q) = x[fb][q + off_k][ob + k] or 0
-template <int CH>
+// PP = 8-channel chunks of the 34 x 34 window staged per pass.  Default (SN_K0_PP = 0): the whole borrowed half at once, 79 / 97 KB
+// of LDS = two / one 4-wave workgroups per CU.  -DSN_K0_PP=2 stages two chunks per pass (42 KB, three workgroups per CU): MEASURED
+// slower, 12.4 vs 10.1 ms per window (config 2) and 51.8 vs 48.9 ms (config 3) -- the extra barrier pair and staging prologue per
+// pass cost more than the added occupancy returns; kept as a compile-time shape.
+#ifndef SN_K0_PP
+#define SN_K0_PP 0
+#endif
+template <int CH, int PP>
 __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const XcdTiles G, const int8_t* __restrict__ offs,
                                                       const uint32_t* __restrict__ w1d, bf16_t* hw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int RW = 34, PSB = CH * 2 + 4;       // odd number of dwords per pixel: lanes = pixels hit distinct banks
+    constexpr int RW = 34, PSB = PP * 16 + 4;      // odd number of dwords per pixel: lanes = pixels hit distinct banks
     constexpr int PCS = CH / 8;
     int t, ty_, tx_;
     if (!sn_xcd_tile(G, t, ty_, tx_)) return;      // XCD-aware walk: the 34-wide windows of x-neighbours overlap by 18 columns
     const int tid = threadIdx.x, y0 = ty_ * 16, x0 = tx_ * 16;
     const Slabs s = unit_slabs(U, t);
     const bf16_t* src = U.x + (ptrdiff_t)s.fb * U.h * U.w * U.C + s.ob;
-    {   // staging: issue ALL global loads first (branch-free, clamped addresses), then mask + write to LDS: one memory
-        // round trip per workgroup instead of one per loop iteration
-        constexpr int NIT = (RW * RW * PCS + 255) / 256;
-        uint4 v[NIT];
-        int lo[NIT];
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int idx = tid + k * 256;
-            const int pix = idx / PCS, pc = idx - pix * PCS;
-            const int ry = pix / RW, rx = pix - ry * RW;
-            const int gy = y0 - 9 + ry, gx = x0 - 9 + rx;
-            const bool in = idx < RW * RW * PCS && gy >= 0 && gy < U.h && gx >= 0 && gx < U.w;
-            lo[k] = idx < RW * RW * PCS ? (in ? pix * PSB + pc * 16 : -(pix * PSB + pc * 16) - 1) : 0x7fffffff;
-            v[k] = *(const uint4*)(src + (in ? ((size_t)gy * U.w + gx) * U.C + pc * 8 : 0));
-        }
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            if (lo[k] == 0x7fffffff) continue;
-            const bool in = lo[k] >= 0;
-            uint32_t* d = (uint32_t*)(smem + (in ? lo[k] : -(lo[k] + 1)));
-            d[0] = in ? v[k].x : 0u; d[1] = in ? v[k].y : 0u; d[2] = in ? v[k].z : 0u; d[3] = in ? v[k].w : 0u;
-        }
-    }
-    __syncthreads();
     const int px = tid & 15, py = tid >> 4, oy = y0 + py, ox = x0 + px;
     const bool valid = oy < U.h && ox < U.w;
     // interior tiles (every tap position p+tap of every output pixel is inside the image): no conv-padding masks at all,
     // and each tap is ONE v_dot2c on the zero-extended bf16 value with a packed weight word (bf16 weight in the low half)
     const bool interior = y0 >= 1 && x0 >= 1 && y0 + 16 < U.h && x0 + 16 < U.w;
-    if (interior) {
-        for (int kc = 0; kc < PCS; ++kc) {
-            float o[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = kc * 8 + j;
-                const int dy = offs[2 * k], dx = offs[2 * k + 1];
-                const char* base = smem + ((py + 8 + dy) * RW + (px + 8 + dx)) * PSB + k * 2;
-                float acc = 0.f;
+    for (int pc0 = 0; pc0 < PCS; pc0 += PP) {
+        const int np = PCS - pc0 < PP ? PCS - pc0 : PP;           // chunks of this pass (compile-time after unrolling)
+        {   // staging: issue ALL global loads first (branch-free, clamped addresses), then mask + write to LDS: one memory
+            // round trip per pass instead of one per loop iteration
+            constexpr int NIT = (RW * RW * PP + 255) / 256;
+            uint4 v[NIT];
+            int lo[NIT];
 #pragma unroll
-                for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-                    for (int tx = 0; tx < 3; ++tx)
-                        acc = dot2bf((uint32_t)(*(const bf16_t*)(base + (ty * RW + tx) * PSB)), w1d[k * 9 + ty * 3 + tx], acc);
-                o[j] = acc;
+            for (int k = 0; k < NIT; ++k) {
+                const int idx = tid + k * 256;
+                const int pix = idx / np, pc = idx - pix * np;
+                const int ry = pix / RW, rx = pix - ry * RW;
+                const int gy = y0 - 9 + ry, gx = x0 - 9 + rx;
+                const bool in = idx < RW * RW * np && gy >= 0 && gy < U.h && gx >= 0 && gx < U.w;
+                lo[k] = idx < RW * RW * np ? (in ? pix * PSB + pc * 16 : -(pix * PSB + pc * 16) - 1) : 0x7fffffff;
+                v[k] = *(const uint4*)(src + (in ? ((size_t)gy * U.w + gx) * U.C + (pc0 + pc) * 8 : 0));
             }
-            *(uint4*)(hw + (((size_t)t * U.h + oy) * U.w + ox) * CH + kc * 8) = pack8(o);
+            if (pc0) __syncthreads();                             // every wave is done reading the previous pass
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                if (lo[k] == 0x7fffffff) continue;
+                const bool in = lo[k] >= 0;
+                uint32_t* d = (uint32_t*)(smem + (in ? lo[k] : -(lo[k] + 1)));
+                d[0] = in ? v[k].x : 0u; d[1] = in ? v[k].y : 0u; d[2] = in ? v[k].z : 0u; d[3] = in ? v[k].w : 0u;
+            }
         }
-        return;
-    }
-    float m[9];
+        __syncthreads();
+        if (interior) {
+            for (int kc = pc0; kc < pc0 + np; ++kc) {
+                float o[8];
 #pragma unroll
-    for (int ty = 0; ty < 3; ++ty)
+                for (int j = 0; j < 8; ++j) {
+                    const int k = kc * 8 + j;
+                    const int dy = offs[2 * k], dx = offs[2 * k + 1];
+                    const char* base = smem + ((py + 8 + dy) * RW + (px + 8 + dx)) * PSB + (k - pc0 * 8) * 2;
+                    float acc = 0.f;
 #pragma unroll
-        for (int tx = 0; tx < 3; ++tx) {
-            const int qy = oy + ty - 1, qx = ox + tx - 1;
-            m[ty * 3 + tx] = (qy >= 0 && qy < U.h && qx >= 0 && qx < U.w) ? 1.f : 0.f;
-        }
-    for (int kc = 0; kc < PCS; ++kc) {
-        float o[8];
+                    for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = kc * 8 + j;
-            const int dy = offs[2 * k], dx = offs[2 * k + 1];
-            const char* base = smem + ((py + 8 + dy) * RW + (px + 8 + dx)) * PSB + k * 2;
-            float acc = 0.f;
+                        for (int tx = 0; tx < 3; ++tx)
+                            acc = dot2bf((uint32_t)(*(const bf16_t*)(base + (ty * RW + tx) * PSB)), w1d[k * 9 + ty * 3 + tx], acc);
+                    o[j] = acc;
+                }
+                *(uint4*)(hw + (((size_t)t * U.h + oy) * U.w + ox) * CH + kc * 8) = pack8(o);
+            }
+        } else {
+            float m[9];
 #pragma unroll
             for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
                 for (int tx = 0; tx < 3; ++tx) {
-                    const float v = m[ty * 3 + tx] * bf_to_f(*(const bf16_t*)(base + (ty * RW + tx) * PSB));
-                    acc = dot2bf(__float_as_uint(v) >> 16, w1d[k * 9 + ty * 3 + tx], acc);   // same bf16 weights as the fast path
+                    const int qy = oy + ty - 1, qx = ox + tx - 1;
+                    m[ty * 3 + tx] = (qy >= 0 && qy < U.h && qx >= 0 && qx < U.w) ? 1.f : 0.f;
                 }
-            o[j] = acc;
+            for (int kc = pc0; kc < pc0 + np; ++kc) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = kc * 8 + j;
+                    const int dy = offs[2 * k], dx = offs[2 * k + 1];
+                    const char* base = smem + ((py + 8 + dy) * RW + (px + 8 + dx)) * PSB + (k - pc0 * 8) * 2;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                        for (int tx = 0; tx < 3; ++tx) {
+                            const float v = m[ty * 3 + tx] * bf_to_f(*(const bf16_t*)(base + (ty * RW + tx) * PSB));
+                            acc = dot2bf(__float_as_uint(v) >> 16, w1d[k * 9 + ty * 3 + tx], acc);   // same bf16 weights as the fast path
+                        }
+                    o[j] = acc;
+                }
+                if (valid) *(uint4*)(hw + (((size_t)t * U.h + oy) * U.w + ox) * CH + kc * 8) = pack8(o);
+            }
         }
-        if (valid) *(uint4*)(hw + (((size_t)t * U.h + oy) * U.w + ox) * CH + kc * 8) = pack8(o);
     }
 }
 
@@ -405,14 +417,35 @@ __global__ __launch_bounds__(256) void dw_gemm_gate_kernel(const bf16_t* __restr
 #ifndef SN_OCC_AGGR
 #define SN_OCC_AGGR 0
 #endif
-template <int C>
-__global__ __launch_bounds__(256, (C == 64 && SN_OCC_AGGR) ? 4 : 3) void scale_gemm_res_kernel(const UnitK U, const bf16_t* __restrict__ g2, const float* __restrict__ ca,
-                                                           const uint4* __restrict__ wfrag, const float* __restrict__ bias, bf16_t* y) {
-    constexpr int CH = C / 2, KS = (C + 31) / 32, MT = C / 16, NT = 4;
+// NT = N-tiles (16 pixels) per wave.  NT = 4 (default): 148 / 152 registers, 3 waves per SIMD, the shortcut is loaded after the MFMAs.
+// -DSN_K4_NT=2: half the accumulators and operands per wave, the shortcut fetched BEFORE the MFMAs, 6 / 4 waves per SIMD: MEASURED
+// 22.6 vs 20.5 ms per window for C = 64 and 69.0 vs 71.2 ms for C = 80 -- twice the weight-fragment loads per pixel eat the gain.
+#ifndef SN_K4_NT
+#define SN_K4_NT 4
+#endif
+template <int C, int NT>
+__global__ __launch_bounds__(256, NT == 4 ? ((C == 64 && SN_OCC_AGGR) ? 4 : 3) : (C == 64 ? 6 : 4))
+void scale_gemm_res_kernel(const UnitK U, const bf16_t* __restrict__ g2, const float* __restrict__ ca,
+                           const uint4* __restrict__ wfrag, const float* __restrict__ bias, bf16_t* y) {
+    constexpr int CH = C / 2, KS = (C + 31) / 32, MT = C / 16;
+    constexpr bool PRE = NT < 4;                 // prefetch the shortcut ahead of the MFMAs
     const int lane = threadIdx.x & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
     const int t = blockIdx.y, hw = U.h * U.w;
     const Slabs sl = unit_slabs(U, t);
-    const int ibase = blockIdx.x * 256 + wv * 64;
+    const int ibase = blockIdx.x * (64 * NT) + wv * (16 * NT);
+    const int c0 = g * 4 * MT;                   // lane (g,p) owns channels [c0, c0 + 4 MT): one contiguous 8*MT-byte run of the shortcut and of y
+    const bf16_t* const sbase = c0 < CH ? U.x + (ptrdiff_t)sl.f0 * hw * C + sl.o0 + c0 : U.x + (ptrdiff_t)sl.f1 * hw * C + sl.o1 + c0 - CH;
+    uint32_t scp[PRE ? NT : 1][2 * MT];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int i = ibase + n * 16 + p, ii = i < hw ? i : hw - 1;
+            const bf16_t* sp = sbase + (size_t)ii * C;
+#pragma unroll
+            for (int m = 0; m + 1 < MT; m += 2) { const uint4 q = *(const uint4*)(sp + m * 4); scp[n][2 * m] = q.x; scp[n][2 * m + 1] = q.y; scp[n][2 * m + 2] = q.z; scp[n][2 * m + 3] = q.w; }
+            if (MT & 1) { const uint2 q = *(const uint2*)(sp + (MT - 1) * 4); scp[n][2 * MT - 2] = q.x; scp[n][2 * MT - 1] = q.y; }
+        }
+    }
 
     bf16x8_t B[NT][KS];
 #pragma unroll
@@ -453,14 +486,16 @@ __global__ __launch_bounds__(256, (C == 64 && SN_OCC_AGGR) ? 4 : 3) void scale_g
     for (int n = 0; n < NT; ++n) {
         const int i = ibase + n * 16 + p;
         if (i >= hw) continue;
-        // lane (g,p) owns channels [g*4*MT, (g+1)*4*MT): one contiguous 8*MT-byte run of the shortcut and of y
         uint32_t sc[2 * MT], o[2 * MT];
-        const int c0 = g * 4 * MT;
-        const bf16_t* sp = c0 < CH ? U.x + ((ptrdiff_t)sl.f0 * hw + i) * C + sl.o0 + c0
-                                   : U.x + ((ptrdiff_t)sl.f1 * hw + i) * C + sl.o1 + c0 - CH;
+        if constexpr (PRE) {
 #pragma unroll
-        for (int m = 0; m + 1 < MT; m += 2) { const uint4 q = *(const uint4*)(sp + m * 4); sc[2 * m] = q.x; sc[2 * m + 1] = q.y; sc[2 * m + 2] = q.z; sc[2 * m + 3] = q.w; }
-        if (MT & 1) { const uint2 q = *(const uint2*)(sp + (MT - 1) * 4); sc[2 * MT - 2] = q.x; sc[2 * MT - 1] = q.y; }
+            for (int k = 0; k < 2 * MT; ++k) sc[k] = scp[n][k];
+        } else {
+            const bf16_t* sp = sbase + (size_t)i * C;
+#pragma unroll
+            for (int m = 0; m + 1 < MT; m += 2) { const uint4 q = *(const uint4*)(sp + m * 4); sc[2 * m] = q.x; sc[2 * m + 1] = q.y; sc[2 * m + 2] = q.z; sc[2 * m + 3] = q.w; }
+            if (MT & 1) { const uint2 q = *(const uint2*)(sp + (MT - 1) * 4); sc[2 * MT - 2] = q.x; sc[2 * MT - 1] = q.y; }
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             o[2 * m] = pack_bf2(bf_lo(sc[2 * m]) + acc[m][n][0], bf_hi(sc[2 * m]) + acc[m][n][1]);
@@ -505,13 +540,15 @@ int sn_gsts_shiftconv(const sn_unit_src* s, const int8_t* offs, const uint32_t* 
     const XcdTiles G = sn_xcd_tiles((s->w + 15) / 16, (s->h + 15) / 16, s->T);
     const dim3 grid = sn_xcd_grid(G);
     if (s->C == 64) {
-        const size_t lds = 34 * 34 * (32 * 2 + 4);
-        if (hipFuncSetAttribute((const void*)shiftconv_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH;
-        hipLaunchKernelGGL(shiftconv_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, to_k(s), G, offs, w1, (bf16_t*)hw);
+        constexpr int PP = SN_K0_PP ? SN_K0_PP : 4;
+        const size_t lds = 34 * 34 * (PP * 16 + 4);
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)shiftconv_kernel<32, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH;
+        hipLaunchKernelGGL((shiftconv_kernel<32, PP>), grid, dim3(256), lds, (hipStream_t)stream, to_k(s), G, offs, w1, (bf16_t*)hw);
     } else {
-        const size_t lds = 34 * 34 * (40 * 2 + 4);
-        if (hipFuncSetAttribute((const void*)shiftconv_kernel<40>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH;
-        hipLaunchKernelGGL(shiftconv_kernel<40>, grid, dim3(256), lds, (hipStream_t)stream, to_k(s), G, offs, w1, (bf16_t*)hw);
+        constexpr int PP = SN_K0_PP ? SN_K0_PP : 5;
+        const size_t lds = 34 * 34 * (PP * 16 + 4);
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)shiftconv_kernel<40, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH;
+        hipLaunchKernelGGL((shiftconv_kernel<40, PP>), grid, dim3(256), lds, (hipStream_t)stream, to_k(s), G, offs, w1, (bf16_t*)hw);
     }
     return sn_check_launch();
 }
@@ -565,9 +602,10 @@ int sn_scale_gemm_res(const sn_unit_src* s, const void* g2, const float* ca, con
     sn_clear_error();
     if (!unit_ok(s) || !g2 || !ca || !wfrag || !y || y == s->x) return SN_EINVAL;
     const int npx = s->h * s->w;
-    dim3 grid((npx + 255) / 256, s->T);
-    if (s->C == 64) hipLaunchKernelGGL(scale_gemm_res_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, to_k(s), (const bf16_t*)g2, ca, (const uint4*)wfrag, bias, (bf16_t*)y);
-    else hipLaunchKernelGGL(scale_gemm_res_kernel<80>, grid, dim3(256), 0, (hipStream_t)stream, to_k(s), (const bf16_t*)g2, ca, (const uint4*)wfrag, bias, (bf16_t*)y);
+    constexpr int PXWG = 64 * SN_K4_NT;
+    dim3 grid((npx + PXWG - 1) / PXWG, s->T);
+    if (s->C == 64) hipLaunchKernelGGL((scale_gemm_res_kernel<64, SN_K4_NT>), grid, dim3(256), 0, (hipStream_t)stream, to_k(s), (const bf16_t*)g2, ca, (const uint4*)wfrag, bias, (bf16_t*)y);
+    else hipLaunchKernelGGL((scale_gemm_res_kernel<80, SN_K4_NT>), grid, dim3(256), 0, (hipStream_t)stream, to_k(s), (const bf16_t*)g2, ca, (const uint4*)wfrag, bias, (bf16_t*)y);
     return sn_check_launch();
 }
 
