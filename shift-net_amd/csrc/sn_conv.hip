@@ -70,7 +70,14 @@ __device__ __forceinline__ uint4 ld_bilinear(const bf16_t* src, int t, int hs, i
 constexpr int sn_conv_waves(int mt, int th) {         // generic conv: 8x32 / 4x16 tiles; the 16x32 shape is left to the compiler
     return th == 16 ? 1 : (mt == 1 ? 6 : mt == 2 ? 5 : mt == 3 ? 4 : mt == 4 ? 3 : 2);
 }
-constexpr int sn_conv3_waves(int mt, int cs) {
+// SN_CONV3_WIDE=1 routes the 8-channel-input conv (feat_extract.0) and the concatenating 3x3 convs (rconcat, conv_hr0: 2-3 inputs of
+// 16 / 24 channels) through conv3_fast_kernel<.., NIN> as well.  Parity green (tests/test_gpu_parity.py::test_conv, whole-net), MEASURED
+// neutral once the generic kernel had its register budget (config 2: 122.7 vs 122.0 ms, config 3: 673.7 vs 664.8 ms): off by default.
+#ifndef SN_CONV3_WIDE
+#define SN_CONV3_WIDE 0
+#endif
+constexpr int sn_conv3_waves(int mt, int cs, int nin = 1) {
+    if (nin > 1 || cs == 8) return mt == 1 ? 6 : 4;          // concatenated-input / 8-channel-input instances (probed like the rest)
     return mt == 1 ? 7 : mt == 2 ? 6 : mt == 3 ? ((cs == 48 && !SN_OCC_AGGR) ? 3 : 4) : mt == 4 ? 3 : 2;
 }
 
@@ -296,8 +303,8 @@ __global__ __launch_bounds__(256, sn_conv_waves(MT, TH)) void conv_mfma_kernel(c
 // round-1 attempt on the generic kernel) measured slower -- 16-channel convs 16.5 -> 20.4 ms, 24-channel 15.7 -> 18.2 ms per window of
 // config 2: the prefetch and the loop-carried state take the kernel from 32-48 to 107-155 VGPRs, and at 3.8-5.1 TB/s this kernel
 // hides its load latency through occupancy (6-8 resident workgroups per CU), not through software pipelining.
-template <int MT, int CS, int TH>
-__global__ __launch_bounds__(256, sn_conv3_waves(MT, CS)) void conv3_fast_kernel(const ConvK P) {
+template <int MT, int CS, int TH, int NIN = 1>
+__global__ __launch_bounds__(256, sn_conv3_waves(MT, CS, NIN)) void conv3_fast_kernel(const ConvK P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TW = 32, RH = TH + 2, RW = TW + 2, NPB = CS / 8;
     // LDS bytes per pixel = k slots of 16 B with k the smallest value >= CS/8 that is 2 mod 4.  ds_read_b128 is serviced in the lane
@@ -317,17 +324,32 @@ __global__ __launch_bounds__(256, sn_conv3_waves(MT, CS)) void conv3_fast_kernel
     float* red = (float*)(smem + TILE_BYTES);
 
     {
+        // NIN > 1: the input is the channel concatenation of NIN tensors of CS / NIN channels each (rconcat, conv_hr0): block blk of a
+        // pixel comes from tensor blk / NPBI; the LDS image is the concatenated pixel, so everything after the staging is unchanged.
+        constexpr int CSI = CS / NIN, NPBI = CSI / 8;
         const int iy0 = oy0 - 1, ix0 = ox0 - 1;
-        const bf16_t* inb = P.in0 + (size_t)t * P.hin * P.win * CS;
+        const size_t foff = (size_t)t * P.hin * P.win * CSI;
+        const bf16_t* inb = P.in0 + foff;
+        const bf16_t* inb1 = NIN > 1 ? P.in1 + foff : nullptr;
+        const bf16_t* inb2 = NIN > 2 ? P.in2 + foff : nullptr;
+        auto source = [&](int blk, int& cb) -> const bf16_t* {          // tensor and 8-channel block inside it of concatenated block blk
+            if constexpr (NIN == 1) { cb = blk; return inb; }
+            else { const int ii = blk / NPBI; cb = blk - ii * NPBI; return ii == 0 ? inb : (ii == 1 ? inb1 : inb2); }
+        };
         const bool interior = iy0 >= 0 && iy0 + RH <= P.hin && ix0 >= 0 && ix0 + RW <= P.win;    // workgroup-uniform
         uint4 v[NIT];
         if (interior) {
-            const bf16_t* base = inb + ((size_t)iy0 * P.win + ix0) * CS;
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
                 const int idx = tid + k * 256, idc = idx < NITEM ? idx : NITEM - 1;
                 const int r = idc / ROWP, i = idc - r * ROWP;
-                v[k] = *(const uint4*)(base + (size_t)r * P.win * CS + i * 8);
+                if constexpr (NIN == 1) {
+                    v[k] = *(const uint4*)(inb + ((size_t)iy0 * P.win + ix0) * CS + (size_t)r * P.win * CS + i * 8);     // a region row is one contiguous run
+                } else {
+                    const int px = i / NPB, blk = i - px * NPB;
+                    int cb; const bf16_t* sp = source(blk, cb);
+                    v[k] = *(const uint4*)(sp + ((size_t)(iy0 + r) * P.win + ix0 + px) * CSI + cb * 8);
+                }
             }
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
@@ -340,10 +362,11 @@ __global__ __launch_bounds__(256, sn_conv3_waves(MT, CS)) void conv3_fast_kernel
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
                 const int idx = tid + k * 256, idc = idx < NITEM ? idx : NITEM - 1;
-                const int r = idc / ROWP, i = idc - r * ROWP, px = i / NPB;
+                const int r = idc / ROWP, i = idc - r * ROWP, px = i / NPB, blk = i - px * NPB;
                 const int gy = iy0 + r, gx = ix0 + px;
                 in[k] = gy >= 0 && gy < P.hin && gx >= 0 && gx < P.win;
-                v[k] = *(const uint4*)(inb + (in[k] ? ((size_t)gy * P.win + ix0) * CS + i * 8 : 0));   // branch-free, clamped
+                int cb; const bf16_t* sp = source(blk, cb);
+                v[k] = *(const uint4*)(sp + (in[k] ? ((size_t)gy * P.win + gx) * CSI + cb * 8 : 0));   // branch-free, clamped
             }
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
@@ -720,17 +743,17 @@ int launch_cab_fused(const ConvK& K, const uint4* w2, int T, hipStream_t st) {
 
 #endif  // SN_EXPERIMENTAL
 
-template <int MT, int CS>
+template <int MT, int CS, int NIN = 1>
 int launch_conv3_fast(const ConvK& K, int T, hipStream_t st) {
     constexpr int TH = 8, TW = 32, NPB = CS / 8, PS = 16 * sn_lds_slots(NPB);
     ConvK P = K; P.xg = sn_xcd_tiles((K.wout + TW - 1) / TW, (K.hout + TH - 1) / TH, T);
     const dim3 grid = sn_xcd_grid(P.xg);
     const size_t lds = (size_t)(TH + 2) * (TW + 2) * PS + 4 * 16 * MT * sizeof(float);
     if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)conv3_fast_kernel<MT, CS, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv3_fast_kernel<MT, CS, TH, NIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return SN_ELAUNCH;
     }
-    hipLaunchKernelGGL((conv3_fast_kernel<MT, CS, TH>), grid, dim3(256), lds, st, P);
+    hipLaunchKernelGGL((conv3_fast_kernel<MT, CS, TH, NIN>), grid, dim3(256), lds, st, P);
     return sn_check_launch();
 }
 
@@ -1015,11 +1038,19 @@ int sn_conv2d(const sn_conv_desc* d, void* stream) {
     K.ps = d->stride == 1 ? 16 * sn_lds_slots(blocks) : ((blocks & 1) ? K.cv * 2 : K.cv * 2 + 16);     // stride 2: odd slot count (pixels 2 apart)
     K.rh = K.rw = 0;
     int th, tw; conv_tile(d, &th, &tw);
-    if (d->k == 3 && d->stride == 1 && d->pad == 1 && d->n_in == 1 && d->in_mode == 0 && d->out_mode == 0 && d->ks == (9 * d->cs_in + 31) / 32) {
-        // the specialised 3x3 path (same tile shape: sn_conv_pool_blocks is unchanged)
+    if (d->k == 3 && d->stride == 1 && d->pad == 1 && d->in_mode == 0 && d->out_mode == 0 && d->ks == (9 * d->n_in * d->cs_in + 31) / 32) {
+        // the specialised 3x3 path (same tile shape: sn_conv_pool_blocks is unchanged); key = inputs, M-tiles, concatenated channels
         hipStream_t st = (hipStream_t)stream;
-        const int key = d->mt * 1000 + d->cs_in;
+        const int key = (d->n_in - 1) * 100000 + d->mt * 1000 + d->n_in * d->cs_in;
         switch (key) {
+#if SN_CONV3_WIDE       // feat_extract.0 (8 input channels) and the concatenating convs rconcat / conv_hr0 (2-3 inputs of 16 / 24 channels)
+            case 1008: return launch_conv3_fast<1, 8>(K, d->T, st);
+            case 2008: return launch_conv3_fast<2, 8>(K, d->T, st);
+            case 101032: return launch_conv3_fast<1, 32, 2>(K, d->T, st);
+            case 102048: return launch_conv3_fast<2, 48, 2>(K, d->T, st);
+            case 201048: return launch_conv3_fast<1, 48, 3>(K, d->T, st);
+            case 202072: return launch_conv3_fast<2, 72, 3>(K, d->T, st);
+#endif
             case 1016: return launch_conv3_fast<1, 16>(K, d->T, st);
             case 2024: return launch_conv3_fast<2, 24>(K, d->T, st);
             case 4064: return launch_conv3_fast<4, 64>(K, d->T, st);
