@@ -125,19 +125,24 @@ static inline XcdTiles sn_xcd_tiles(int ntx, int nty, int T) {
     return g;
 }
 static inline dim3 sn_xcd_grid(const XcdTiles& g) { return SN_XCD_TILES ? dim3(8u * g.ntx, g.chunk, 1) : dim3(g.ntx, g.nrf, 1); }
-// false: this workgroup is padding of the last XCD's chunk (returns before any barrier)
-__device__ __forceinline__ bool sn_xcd_tile(const XcdTiles& g, int& t, int& ty, int& tx) {
+// (bx, by) = block index -> (t, ty, tx); false: this workgroup is padding of the last XCD's chunk.  Host-callable so that
+// tests/test_host_logic.py can check, without a GPU, that every tile of every grid shape is produced exactly once.
+__host__ __device__ inline bool sn_xcd_decode(const XcdTiles& g, uint32_t bx, uint32_t by, int& t, int& ty, int& tx) {
 #if SN_XCD_TILES
-    tx = blockIdx.x >> 3;
-    const uint32_t rf = (blockIdx.x & 7) * g.chunk + blockIdx.y;
+    tx = (int)(bx >> 3);
+    const uint32_t rf = (bx & 7) * (uint32_t)g.chunk + by;
 #else
-    tx = blockIdx.x;
-    const uint32_t rf = blockIdx.y;
+    tx = (int)bx;
+    const uint32_t rf = by;
 #endif
     if (rf >= (uint32_t)g.nrf) return false;
-    t = g.inv_nty ? (int)__umulhi(rf, g.inv_nty) : (int)rf;
+    t = g.inv_nty ? (int)(((uint64_t)rf * g.inv_nty) >> 32) : (int)rf;       // = __umulhi(rf, inv_nty): s_mul_hi_u32 on the device
     ty = (int)rf - t * g.nty;
     return true;
+}
+// returns before any barrier when false
+__device__ __forceinline__ bool sn_xcd_tile(const XcdTiles& g, int& t, int& ty, int& tx) {
+    return sn_xcd_decode(g, blockIdx.x, blockIdx.y, t, ty, tx);
 }
 
 // hipGetLastError() is per-thread sticky state that other libraries in the process (PyTorch's allocator polling

@@ -124,3 +124,23 @@ def test_cli_window_arithmetic_and_metrics():
     assert abs(cli.ssim_calculate(b.astype(np.float64), b) - 1.0) < 1e-6
     x = cli.numpy2tensor([b, b])
     assert x.shape == (1, 2, 3, 8, 8) and abs(float(x.max()) - 110 / 255) < 1e-7
+
+
+def test_xcd_tile_walk_is_a_bijection(tmp_path):
+    """The XCD-aware tile walk of K0 / K12 / the dense convs (csrc/sn_common.h: sn_xcd_tiles, sn_xcd_grid, sn_xcd_decode) maps the launch
+    grid onto (frame, tile row, tile column): every tile exactly once, padding workgroups rejected, for 729 grid shapes including the
+    remainder chunks and nty == 1.  The decode function is __host__ __device__, so the very code the kernels run is checked here with a
+    host-only hipcc build (no GPU)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc")
+    exe = str(tmp_path / "xcd_tiles_check")
+    for flags in ([], ["-DSN_XCD_TILES=0"]):
+        r = subprocess.run([hipcc, "-O1", "-std=c++17", "--offload-host-only", "-I", os.path.join(root, "shift-net_amd", "csrc")] + flags +
+                           [os.path.join(root, "tests", "host", "xcd_tiles_check.cpp"), "-o", exe], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "xcd tiles ok" in r.stdout, r.stdout[-1000:] + r.stderr[-1000:]
