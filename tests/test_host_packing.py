@@ -241,3 +241,25 @@ def test_cab_pooled_mean_closed_form():
             s_tap = tot - rowex[ky] - colex[kx] + cor[ky][kx]            # [cin]
             got += w2[:, :, ky, kx].numpy() @ s_tap
     np.testing.assert_allclose(got / (h * w), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_packed_fp16_and_dot2_weight_words():
+    """Operand words of the packed stencils: pk_f16_words (K12: v_pk_fma_f16, word k = fp16 of elements 2k | 2k+1 << 16, round to
+    nearest) and dot2_words (K0: v_dot2c_f32_bf16, element j in half j & 1 of its own word, other half zero)."""
+    import numpy as np
+    import torch
+    from shiftnet_amd import prep
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(9, 64, generator=g) * 0.3
+    w[0, 0], w[0, 1] = 1.0 + 2.0 ** -12, -65504.0          # rounds to 1.0 in fp16; largest finite fp16
+    words = prep.pk_f16_words(w)
+    assert words.dtype == torch.int32 and words.shape == (9, 32)
+    u = words.numpy().astype(np.int64) & 0xFFFFFFFF
+    lo = (u & 0xFFFF).astype(np.uint16).view(np.float16)
+    hi = (u >> 16).astype(np.uint16).view(np.float16)
+    ref = w.to(torch.float16).numpy()
+    assert np.array_equal(lo, ref[:, 0::2]) and np.array_equal(hi, ref[:, 1::2])
+    assert lo[0, 0] == np.float16(1.0) and hi[0, 0] == np.float16(-65504.0)
+    d2 = prep.dot2_words(w).numpy().astype(np.int64) & 0xFFFFFFFF
+    bf = (w.to(torch.bfloat16).view(torch.int16).to(torch.int32) & 0xFFFF).numpy()
+    assert np.array_equal(d2[:, 0::2], bf[:, 0::2]) and np.array_equal(d2[:, 1::2], bf[:, 1::2].astype(np.int64) << 16)
