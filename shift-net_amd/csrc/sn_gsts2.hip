@@ -34,6 +34,12 @@ __device__ __forceinline__ Slabs2 unit_slabs2(const UnitK2& U, int t) {
 #define SN_K12_TH 8
 #define SN_K12_NWV 8
 #endif
+#ifndef SN_K12_WSTREAM
+#define SN_K12_WSTREAM 0
+#endif
+#ifndef SN_K12_LDS_PAD
+#define SN_K12_LDS_PAD 0
+#endif
 template <int C, bool WITH_HW>
 __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const UnitK2 U, const XcdTiles G, const bf16_t* __restrict__ hwb, const uint4* __restrict__ wfrag,
                                                          const float* __restrict__ bias, const uint32_t* __restrict__ wdw,
@@ -50,6 +56,10 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
     constexpr int PSA = 80;                                                        // LDS bytes per pixel of an a-chunk (64 + 16 pad)
     __shared__ __attribute__((aligned(16))) char lds_a2[2][NPX * PSA];           // double-buffered a-chunk: one barrier per chunk
     __shared__ __attribute__((aligned(16))) uint16_t lds_tr[NWV][8][64];          // per-wave transpose scratch of the planar epilogue
+#if SN_K12_LDS_PAD      // occupancy experiment: extra LDS per workgroup forces ONE workgroup per CU (see the WSTREAM note below)
+    __shared__ char lds_pad[SN_K12_LDS_PAD];
+    if (U.T < 0) lds_pad[threadIdx.x] = 1;
+#endif
     const int lane = threadIdx.x & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
     int t, tyi, txi;
     if (!sn_xcd_tile(G, t, tyi, txi)) return;     // XCD-aware walk (sn_common.h): ring rows / columns of neighbouring tiles meet in one L2
@@ -61,17 +71,28 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
         if (prof) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tacc[slot] += now - tlast; tlast = now; }
     };
 
-    // weight fragments and bias of one chunk, fetched one chunk AHEAD (they come from L2: ~1 us when loaded at the point of use)
-    bf16x8_t Wf[2][KS];
+    // weight fragments and bias of one chunk, fetched one chunk AHEAD (they come from L2: ~1 us when loaded at the point of use).
+    // WSTREAM (-DSN_K12_WSTREAM=1, C = 80 only): the fragments are streamed one k-step ahead inside the chunk's MFMA loop (16 instead of
+    // 32 registers) and the LayerNorm sweeps re-derive the fp32 values from the raw words: the C = 80 CAB2 instance drops from 152 to
+    // 116 VGPRs, i.e. from ONE to TWO 8-wave workgroups per CU, bit-identical output (tools/ab_k12.py).  MEASURED at 20 x 360 x 640:
+    // 1284-1309 us vs 985-1117 us for CAB2 (slower), 745-768 vs 751-780 us for CAB1 (same occupancy either way: neutral).  The
+    // converse experiment (-DSN_K12_LDS_PAD=24576: one workgroup per CU for C = 64) is neutral as well (591 vs 585 us): K12's
+    // throughput does not come from co-resident workgroups, one 8-wave workgroup already saturates whatever bounds it.
+    constexpr bool WSTREAM = SN_K12_WSTREAM && C == 80;
+    bf16x8_t Wf[2][WSTREAM ? 1 : KS];
     float4 Wb[2];
     auto load_w = [&](int q) {
+        if constexpr (!WSTREAM) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            Wf[0][s] = as_frag(wfrag[((2 * q) * KS + s) * 64 + lane]);
-            Wf[1][s] = as_frag(wfrag[((2 * q + 1) * KS + s) * 64 + lane]);
+            for (int s = 0; s < KS; ++s) {
+                Wf[0][s] = as_frag(wfrag[((2 * q) * KS + s) * 64 + lane]);
+                Wf[1][s] = as_frag(wfrag[((2 * q + 1) * KS + s) * 64 + lane]);
+            }
         }
-        Wb[0] = *(const float4*)(bias + g * 4 * MT + (2 * q) * 4);
-        Wb[1] = *(const float4*)(bias + g * 4 * MT + (2 * q + 1) * 4);
+        if constexpr (!WSTREAM) {
+            Wb[0] = *(const float4*)(bias + g * 4 * MT + (2 * q) * 4);
+            Wb[1] = *(const float4*)(bias + g * 4 * MT + (2 * q + 1) * 4);
+        }
     };
     load_w(0);
 
@@ -110,6 +131,54 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
         uint4 raw[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) raw[s] = *(const uint4*)(slab[s] + (dbg & 8 ? 0 : ii * sstride[s]));
+        if constexpr (WSTREAM) {
+            // register-lean form: the fp32 values are re-derived from the raw words in each of the three sweeps instead of being
+            // kept (32 registers less at the kernel's register peak, 16 more unpack instructions per k-step)
+            const bool lastpad = (KS - 1) * 32 + 24 >= K;
+            auto up = [&](int s, int j) -> f32x2_t {
+                const uint32_t wd = j == 0 ? raw[s].x : j == 1 ? raw[s].y : j == 2 ? raw[s].z : raw[s].w;
+                return (f32x2_t){bf_lo(wd), bf_hi(wd)};
+            };
+            if (lastpad) {
+                const bool has = (KS - 1) * 32 + g * 8 < K;
+                raw[KS - 1].x = has ? raw[KS - 1].x : 0u; raw[KS - 1].y = has ? raw[KS - 1].y : 0u;
+                raw[KS - 1].z = has ? raw[KS - 1].z : 0u; raw[KS - 1].w = has ? raw[KS - 1].w : 0u;
+            }
+            f32x2_t sum2 = {0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum2 += up(s, j);
+            const float mean = sum_rows4(sum2[0] + sum2[1]) * (1.0f / K);
+            const f32x2_t mean2 = {mean, mean};
+            f32x2_t sq2 = {0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bool pad = lastpad && s == KS - 1 && !(s * 32 + g * 8 < K);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x2_t d = up(s, j) - mean2;
+                    if (lastpad && s == KS - 1) d = pad ? (f32x2_t){0.f, 0.f} : d;
+                    sq2 = __builtin_elementwise_fma(d, d, sq2);
+                }
+            }
+            const float sq = sum_rows4(sq2[0] + sq2[1]);
+            const float rstd = 1.0f / sqrtf(sq * (1.0f / K) + 1e-6f);
+            const f32x2_t rstd2 = {rstd, rstd};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bool pad = lastpad && s == KS - 1 && !(s * 32 + g * 8 < K);
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x2_t d = (up(s, j) - mean2) * rstd2;
+                    if (lastpad && s == KS - 1) d = pad ? (f32x2_t){0.f, 0.f} : d;
+                    o[j] = pack_bf2(d[0], d[1]);
+                }
+                B[n][s] = as_frag(make_uint4(o[0], o[1], o[2], o[3]));
+            }
+            continue;
+        }
         f32x2_t xv[KS][4];
         f32x2_t sum2 = {0.f, 0.f};
 #pragma unroll
@@ -155,13 +224,28 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
     auto gemm_chunk = [&](int q) {
         char* lds_a = lds_a2[q & 1];
         f32x4_t acc0[NTW], acc1[NTW];
-        const float4 b0 = Wb[0], b1 = Wb[1];
+        float4 b0, b1;
+        if constexpr (WSTREAM) {      // bias fetched here, not a chunk ahead: 8 registers less across the stencil phase
+            b0 = *(const float4*)(bias + g * 4 * MT + (2 * q) * 4); b1 = *(const float4*)(bias + g * 4 * MT + (2 * q + 1) * 4);
+        } else { b0 = Wb[0]; b1 = Wb[1]; }
 #pragma unroll
         for (int n = 0; n < NTW; ++n) { acc0[n] = (f32x4_t){b0.x, b0.y, b0.z, b0.w}; acc1[n] = (f32x4_t){b1.x, b1.y, b1.z, b1.w}; }
+        if constexpr (WSTREAM) {
+            bf16x8_t w0 = as_frag(wfrag[((2 * q) * KS) * 64 + lane]), w1 = as_frag(wfrag[((2 * q + 1) * KS) * 64 + lane]);
 #pragma unroll
-        for (int s = (dbg & 16) ? KS : 0; s < KS; ++s) {
+            for (int s = 0; s < KS; ++s) {
+                const int sn = s + 1 < KS ? s + 1 : s;
+                const bf16x8_t n0 = as_frag(wfrag[((2 * q) * KS + sn) * 64 + lane]), n1 = as_frag(wfrag[((2 * q + 1) * KS + sn) * 64 + lane]);
 #pragma unroll
-            for (int n = 0; n < NTW; ++n) { acc0[n] = mfma16(Wf[0][s], B[n][s], acc0[n]); acc1[n] = mfma16(Wf[1][s], B[n][s], acc1[n]); }
+                for (int n = 0; n < NTW; ++n) { acc0[n] = mfma16(w0, B[n][s], acc0[n]); acc1[n] = mfma16(w1, B[n][s], acc1[n]); }
+                w0 = n0; w1 = n1;
+            }
+        } else {
+#pragma unroll
+            for (int s = (dbg & 16) ? KS : 0; s < KS; ++s) {
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) { acc0[n] = mfma16(Wf[0][s], B[n][s], acc0[n]); acc1[n] = mfma16(Wf[1][s], B[n][s], acc1[n]); }
+            }
         }
 #pragma unroll
         for (int n = 0; n < NTW; ++n) {
