@@ -9,8 +9,6 @@
  *     included), the library never allocates or frees, reads no environment variable and keeps no global mutable
  *     state (thread compatible).  Kernels launch on the calling thread's CURRENT HIP device: make the device that owns
  *     `stream` and the buffers current first (the Python engine wraps every forward in torch.cuda.device(dev));
- *   - superseded kernel generations and profiling hooks are NOT part of this ABI: they are compiled only with
- *     -DSN_EXPERIMENTAL and declared in shiftnet_hip_experimental.h;
  *   - work is enqueued on `stream` (a hipStream_t passed as void*) and returns immediately;
  *   - return 0 on success, negative errno-style code otherwise (-22 bad argument, -5 launch failure); nothing throws;
  *   - activations: NHWC bf16 [T][H][W][Cs], Cs a multiple of 8, pad channels must be (and are kept) zero;
@@ -25,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 1
+#define SN_ABI_VERSION 3      /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
 
 /* element types of NCHW tensors exchanged with the PyTorch side */
 #define SN_F32 0
@@ -76,9 +74,6 @@ typedef struct sn_conv_desc {
     int oscale_stride;
     const void* res2;    /* NULL or a second NHWC residual of the same shape as `res`, added after it: the "+ shortcut" that
                             follows the last TFR_UNet of a stage (gshift_deblur1.py:769,779) rides on that UNet's last conv */
-    void* border_rows;   /* NULL, or (3x3 stride-1 single-input NHWC convs only) [T][2][w_out][cs_out]: the result's first and last row; */
-    void* border_cols;   /* [T][2][h_out][cs_out]: its first and last column.  With both given `out` may be NULL: a sums-only launch
-                            (pool + border lines) = pass A of the (experimental) fused CAB, whose conv1 result never reaches HBM */
 } sn_conv_desc;
 int sn_conv2d(const sn_conv_desc* d, void* stream);   /* d is a HOST pointer, read during the call */
 /* number of workgroups per frame sn_conv2d launches for this descriptor (= rows of `pool` per frame); host only */
@@ -95,16 +90,10 @@ int sn_ca_mlp(const float* partial, int nblk, int cpad, int c, int cr, float inv
  * epilogue) and the first/last rows and columns of mid.  Then the usual 1x1 -> ReLU -> 1x1 -> sigmoid (:61-70).
  * mid:[T][h][w][cs] bf16, w2:[cin=c][9][cpad] f32 (bias-free 3x3, zero beyond c), ca:[T][cpad] out.  Lets sn_conv2d apply the scale and the
  * residual in conv2's epilogue (no separate pass over res).
- * border_rows / border_cols: see sn_conv_desc (NULL: the lines are read from mid).
  * scratch: sn_cab_ca_scratch_floats(T) floats of workspace (partial sums of the split reduction). */
 int sn_cab_ca_scratch_floats(int T);
 int sn_cab_ca(const float* partial, int nblk, int cpad, const void* mid, int cs, int c, int cr, int h, int w,
-              const float* w2, const float* wa, const float* wb, float* scratch, float* ca, int T, void* stream,
-              const void* border_rows, const void* border_cols);   /* the border lines of mid instead of mid itself (mid may then be NULL) */
-
-/* CAB tail "res = self.CA(res); res += x" (gshift_deblur1.py:155-157): out = res * ca[t][c] + x. */
-int sn_scale_residual(const void* res, const void* x, const float* ca, int cpad, void* out,
-                      int T, int hw, int cs, void* stream);
+              const float* w2, const float* wa, const float* wb, float* scratch, float* ca, int T, void* stream);
 
 /* ---- grouped spatial-temporal shift unit: channel_shift -> CAB2 -> CAB1 (gshift_deblur1.py:504-547) ---- */
 typedef struct sn_unit_src {
@@ -138,7 +127,7 @@ int sn_gsts_shiftconv(const sn_unit_src* s, const int8_t* offs, const uint32_t* 
  * hw may be NULL for mode 0.
  * wdw: [9][C] u32: word k of a tap row holds the fp16 weights of positions (2k, 2k+1) of a's storage order (v_pk_fma_f16
  * operand, prep.pk_f16_words of the [9][2C] table with the identity folded into the centre tap).
- * g1_blocked = 0: g1 natural NHWC [T][h][w][C] (sn_grp5_gemm_gate); 1 (C = 64 only): channel-blocked [T][4][h][w][16] (experimental K3');
+ * g1_blocked = 0: g1 natural NHWC [T][h][w][C] (sn_grp5_gemm_gate);
  * g1_blocked = 2 (C = 64 only): channel-planar [T][h][C][sn_planar_pitch(w)], zeros in the pad columns (sn_dw5m_gemm_gate).
  * pool: NULL or [T][sn_lngate_blocks][C]. */
 int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, const uint32_t* wdw,

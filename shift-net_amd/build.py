@@ -10,9 +10,6 @@ OUT = os.path.join(HERE, "lib", "libshiftnet_hip.so")
 SOURCES = ["sn_conv.hip", "sn_gsts.hip", "sn_gsts2.hip", "sn_gsts3.hip", "sn_f32.hip", "sn_io.hip"]
 
 
-OUT_EXP = os.path.join(HERE, "lib", "libshiftnet_hip_exp.so")     # -DSN_EXPERIMENTAL: superseded kernels + profiling hooks
-
-
 def needs_build(out: str = OUT) -> bool:
     if not os.path.exists(out):
         return True
@@ -21,17 +18,14 @@ def needs_build(out: str = OUT) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, experimental: bool = False) -> str:
-    OUT = OUT_EXP if experimental else globals()["OUT"]
+def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build(OUT):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize",
            "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
-    if experimental:
-        cmd.insert(1, "-DSN_EXPERIMENTAL")
-    for f in os.environ.get("SN_HIPCC_FLAGS", "").split():      # A/B builds of compile-time shapes, e.g. SN_HIPCC_FLAGS=-DSN_GRP5_NH=2
+    for f in os.environ.get("SN_HIPCC_FLAGS", "").split():      # extra compiler flags for one-off builds (e.g. --save-temps)
         cmd.insert(1, f)
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
@@ -45,4 +39,4 @@ def build(force: bool = False, verbose: bool = False, experimental: bool = False
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose="-v" in sys.argv, experimental="--experimental" in sys.argv))
+    print(build(force=True, verbose="-v" in sys.argv))

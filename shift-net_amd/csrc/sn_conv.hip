@@ -24,7 +24,6 @@ struct ConvK {
     const float* bias; int act; float prelu;
     const bf16_t* res; bf16_t* out; int cs_out, out_mode, c_out, nchw_dtype;
     const void* sc; float* pool; const float* oscale; int oscale_stride; const bf16_t* res2;
-    bf16_t* brow; bf16_t* bcol;      // conv3_fast only: first/last row and column of the result, [T][2][w][cs_out] / [T][2][h][cs_out]
     int rh, rw, ps;
     XcdTiles xg;                     // tile walk of conv_mfma_kernel / conv3_fast_kernel (sn_common.h)
     unsigned m_nblk8, m_rw, m_csb, m_cv, m_k;   // ceil(2^24/d) multipliers: integer division by runtime constants without v_div
@@ -62,23 +61,15 @@ __device__ __forceinline__ uint4 ld_bilinear(const bf16_t* src, int t, int hs, i
 // AGPRs on top of them: the unified file then holds 108 registers per lane for the 24-channel 3x3 conv (4 waves per SIMD) where
 // 72 are needed (7 waves), 144 instead of 110 for the 40-channel one, 171 instead of 148 for K4.  These kernels hide their
 // load -> barrier -> MFMA -> store latency ONLY through co-resident workgroups, so every one states the occupancy it can reach
-// without spilling (probed per instantiation with -Rpass-analysis=kernel-resource-usage; SN_OCC_AGGR=1 accepts 2-6 spilled
-// registers for one more wave, for A/B runs).
-#ifndef SN_OCC_AGGR
-#define SN_OCC_AGGR 0
-#endif
+// without spilling (probed per instantiation with -Rpass-analysis=kernel-resource-usage; accepting 2-6 spilled
+// registers for one more wave lost time everywhere it was tried).
 constexpr int sn_conv_waves(int mt, int th) {         // generic conv: 8x32 / 4x16 tiles; the 16x32 shape is left to the compiler
     return th == 16 ? 1 : (mt == 1 ? 6 : mt == 2 ? 5 : mt == 3 ? 4 : mt == 4 ? 3 : 2);
 }
-// SN_CONV3_WIDE=1 routes the 8-channel-input conv (feat_extract.0) and the concatenating 3x3 convs (rconcat, conv_hr0: 2-3 inputs of
-// 16 / 24 channels) through conv3_fast_kernel<.., NIN> as well.  Parity green (tests/test_gpu_parity.py::test_conv, whole-net), MEASURED
-// neutral once the generic kernel had its register budget (config 2: 122.7 vs 122.0 ms, config 3: 673.7 vs 664.8 ms): off by default.
-#ifndef SN_CONV3_WIDE
-#define SN_CONV3_WIDE 0
-#endif
-constexpr int sn_conv3_waves(int mt, int cs, int nin = 1) {
-    if (nin > 1 || cs == 8) return mt == 1 ? 6 : 4;          // concatenated-input / 8-channel-input instances (probed like the rest)
-    return mt == 1 ? 7 : mt == 2 ? 6 : mt == 3 ? ((cs == 48 && !SN_OCC_AGGR) ? 3 : 4) : mt == 4 ? 3 : 2;
+// (feat_extract.0 -- 8 input channels -- and the concatenating 3x3 convs rconcat / conv_hr0 stay on the generic kernel: routing them
+// through conv3_fast_kernel measured neutral in round 2, 122.7 vs 122.0 ms and 673.7 vs 664.8 ms.)
+constexpr int sn_conv3_waves(int mt, int cs) {
+    return mt == 1 ? 7 : mt == 2 ? 6 : mt == 3 ? (cs == 48 ? 3 : 4) : mt == 4 ? 3 : 2;
 }
 
 template <int MT, int TH, int TW>
@@ -303,8 +294,8 @@ __global__ __launch_bounds__(256, sn_conv_waves(MT, TH)) void conv_mfma_kernel(c
 // round-1 attempt on the generic kernel) measured slower -- 16-channel convs 16.5 -> 20.4 ms, 24-channel 15.7 -> 18.2 ms per window of
 // config 2: the prefetch and the loop-carried state take the kernel from 32-48 to 107-155 VGPRs, and at 3.8-5.1 TB/s this kernel
 // hides its load latency through occupancy (6-8 resident workgroups per CU), not through software pipelining.
-template <int MT, int CS, int TH, int NIN = 1>
-__global__ __launch_bounds__(256, sn_conv3_waves(MT, CS, NIN)) void conv3_fast_kernel(const ConvK P) {
+template <int MT, int CS, int TH>
+__global__ __launch_bounds__(256, sn_conv3_waves(MT, CS)) void conv3_fast_kernel(const ConvK P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TW = 32, RH = TH + 2, RW = TW + 2, NPB = CS / 8;
     // LDS bytes per pixel = k slots of 16 B with k the smallest value >= CS/8 that is 2 mod 4.  ds_read_b128 is serviced in the lane
@@ -324,18 +315,8 @@ __global__ __launch_bounds__(256, sn_conv3_waves(MT, CS, NIN)) void conv3_fast_k
     float* red = (float*)(smem + TILE_BYTES);
 
     {
-        // NIN > 1: the input is the channel concatenation of NIN tensors of CS / NIN channels each (rconcat, conv_hr0): block blk of a
-        // pixel comes from tensor blk / NPBI; the LDS image is the concatenated pixel, so everything after the staging is unchanged.
-        constexpr int CSI = CS / NIN, NPBI = CSI / 8;
         const int iy0 = oy0 - 1, ix0 = ox0 - 1;
-        const size_t foff = (size_t)t * P.hin * P.win * CSI;
-        const bf16_t* inb = P.in0 + foff;
-        const bf16_t* inb1 = NIN > 1 ? P.in1 + foff : nullptr;
-        const bf16_t* inb2 = NIN > 2 ? P.in2 + foff : nullptr;
-        auto source = [&](int blk, int& cb) -> const bf16_t* {          // tensor and 8-channel block inside it of concatenated block blk
-            if constexpr (NIN == 1) { cb = blk; return inb; }
-            else { const int ii = blk / NPBI; cb = blk - ii * NPBI; return ii == 0 ? inb : (ii == 1 ? inb1 : inb2); }
-        };
+        const bf16_t* inb = P.in0 + (size_t)t * P.hin * P.win * CS;
         const bool interior = iy0 >= 0 && iy0 + RH <= P.hin && ix0 >= 0 && ix0 + RW <= P.win;    // workgroup-uniform
         uint4 v[NIT];
         if (interior) {
@@ -343,13 +324,7 @@ __global__ __launch_bounds__(256, sn_conv3_waves(MT, CS, NIN)) void conv3_fast_k
             for (int k = 0; k < NIT; ++k) {
                 const int idx = tid + k * 256, idc = idx < NITEM ? idx : NITEM - 1;
                 const int r = idc / ROWP, i = idc - r * ROWP;
-                if constexpr (NIN == 1) {
-                    v[k] = *(const uint4*)(inb + ((size_t)iy0 * P.win + ix0) * CS + (size_t)r * P.win * CS + i * 8);     // a region row is one contiguous run
-                } else {
-                    const int px = i / NPB, blk = i - px * NPB;
-                    int cb; const bf16_t* sp = source(blk, cb);
-                    v[k] = *(const uint4*)(sp + ((size_t)(iy0 + r) * P.win + ix0 + px) * CSI + cb * 8);
-                }
+                v[k] = *(const uint4*)(inb + ((size_t)iy0 * P.win + ix0) * CS + (size_t)r * P.win * CS + i * 8);     // a region row is one contiguous run
             }
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
@@ -365,8 +340,7 @@ __global__ __launch_bounds__(256, sn_conv3_waves(MT, CS, NIN)) void conv3_fast_k
                 const int r = idc / ROWP, i = idc - r * ROWP, px = i / NPB, blk = i - px * NPB;
                 const int gy = iy0 + r, gx = ix0 + px;
                 in[k] = gy >= 0 && gy < P.hin && gx >= 0 && gx < P.win;
-                int cb; const bf16_t* sp = source(blk, cb);
-                v[k] = *(const uint4*)(sp + (in[k] ? ((size_t)gy * P.win + gx) * CSI + cb * 8 : 0));   // branch-free, clamped
+                v[k] = *(const uint4*)(inb + (in[k] ? ((size_t)gy * P.win + gx) * CS + blk * 8 : 0));   // branch-free, clamped
             }
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
@@ -381,7 +355,7 @@ __global__ __launch_bounds__(256, sn_conv3_waves(MT, CS, NIN)) void conv3_fast_k
     // offset (a frame has < 2^31 elements), instead of a 64-bit multiply chain per N-tile.
     const bool full = (oy0 + TH <= P.hout) && (ox0 + TW <= P.wout);           // workgroup-uniform: no bounds masks at all
     const size_t tbase = (((size_t)t * P.hout + oy0) * P.wout + ox0) * P.cs_out;
-    bf16_t* const outb = P.out ? P.out + tbase : nullptr;
+    bf16_t* const outb = P.out + tbase;
     const bf16_t* const resb = P.res ? P.res + tbase : nullptr;
     const bf16_t* const res2b = P.res2 ? P.res2 + tbase : nullptr;
     const int c0 = g * 4 * MT;                                      // this lane's 4*MT consecutive channels of its pixel
@@ -509,24 +483,6 @@ __global__ __launch_bounds__(256, sn_conv3_waves(MT, CS, NIN)) void conv3_fast_k
 #pragma unroll
                     for (int r = 0; r < 4; ++r) psum[m][r] += v[m][r];
             }
-            if (P.brow) {       // pass A of the fused CAB: `mid` is never stored, only its border lines (sn_cab_ca needs their sums)
-                const int nn = wv * NTW + n, row = nn / XB, xb = nn - row * XB;
-                const int oy = oy0 + row, ox = ox0 + xb * 16 + p;
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    if (c0 + m * 4 >= P.cs_out) continue;
-                    uint2 o; o.x = pack_bf2(v[m][0], v[m][1]); o.y = pack_bf2(v[m][2], v[m][3]);
-                    if (oy == 0 || oy == P.hout - 1)
-                        *(uint2*)(P.brow + (((size_t)t * 2 + (oy == 0 ? 0 : 1)) * P.wout + ox) * P.cs_out + c0 + m * 4) = o;
-                    if (oy == 0 && P.hout == 1)
-                        *(uint2*)(P.brow + (((size_t)t * 2 + 1) * P.wout + ox) * P.cs_out + c0 + m * 4) = o;
-                    if (ox == 0 || ox == P.wout - 1)
-                        *(uint2*)(P.bcol + (((size_t)t * 2 + (ox == 0 ? 0 : 1)) * P.hout + oy) * P.cs_out + c0 + m * 4) = o;
-                    if (ox == 0 && P.wout == 1)
-                        *(uint2*)(P.bcol + (((size_t)t * 2 + 1) * P.hout + oy) * P.cs_out + c0 + m * 4) = o;
-                }
-            }
-            if (!P.out) continue;                                   // wave-uniform: sums-only launch
             if constexpr (MT == 2 || MT == 4) {
 #pragma unroll
                 for (int m = 0; m < MT; m += 2)
@@ -561,199 +517,18 @@ __global__ __launch_bounds__(256, sn_conv3_waves(MT, CS, NIN)) void conv3_fast_k
     }
 }
 
-#ifdef SN_EXPERIMENTAL   // fused CAB: parity green, measured SLOWER than two conv launches (see the note at sn_cab_fused); not on the product path
-// ------------------------------------------------------------------------------------------------------------
-// Fused CAB, pass B:  out = x + ca * conv2(PReLU(conv1(x)))  [+ res2]   (gshift_deblur1.py:141-156) with `mid` in LDS.
-// The CALayer scale `ca` is known beforehand from pass A (conv3_fast_kernel with P.out == NULL: sums and border lines of mid,
-// closed form in sn_cab_ca), so a CAB costs three tensor passes -- read x (pass A), read x + write out (pass B) -- instead of
-// five (conv1: read x, write mid; conv2: read mid, read x, write out).  The dense convs are memory-bound (PMC: 3.8-5.1 TB/s,
-// MFMA pipe 11-14 % busy), so recomputing conv1 on the tile's 1-pixel ring (340 instead of 256 pixels) is paid in idle issue slots.
-//   stage x on (TH+4) x (TW+4) -> conv1 + PReLU on (TH+2) x (TW+2), ZERO outside the image (conv2's padding), bf16 into LDS ->
-//   conv2 on TH x TW from that image -> x ca, + x (from the staged tile), [+ res2] -> store.
-template <int MT, int CS>
-__global__ __launch_bounds__(256) void cab_fused_kernel(const ConvK P, const uint4* __restrict__ w2frag) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TH = 8, TW = 32, XH = TH + 4, XW = TW + 4, MH = TH + 2, MW = TW + 2, NPB = CS / 8;
-    constexpr int PS = 16 * sn_lds_slots(NPB);
-    constexpr int KTOT = 9 * CS, KS = (KTOT + 31) / 32;
-    constexpr int NTW = (TH * TW) / 64, XB = TW / 16;
-    constexpr int ROWP = XW * NPB, NITEM = XH * ROWP, NIT = (NITEM + 255) / 256;
-    constexpr int NMID = MH * MW, NMT = (NMID + 15) / 16, NMW = (NMT + 3) / 4;        // 340 mid pixels = 22 N-tiles, <= 6 per wave
-    char* xs = smem;                                     // [XH*XW][PS] staged x
-    char* ms = smem + XH * XW * PS;                      // [MH*MW][PS] mid = PReLU(conv1(x)), zero outside the image
-    const int tid = threadIdx.x & 255, lane = tid & 63, wv = wave_id();
-    const int g = lane >> 4, p = lane & 15;
-    const int t = blockIdx.z, oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
-    const int c0 = g * 4 * MT;
-
-    {   // ---- stage x: rows oy0-2 .. oy0+TH+1, columns ox0-2 .. ox0+TW+1; a region row is one contiguous run in memory ----
-        const int iy0 = oy0 - 2, ix0 = ox0 - 2;
-        const bf16_t* inb = P.in0 + (size_t)t * P.hin * P.win * CS;
-        uint4 v[NIT];
-        bool in[NIT];
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int idx = tid + k * 256, idc = idx < NITEM ? idx : NITEM - 1;
-            const int r = idc / ROWP, i = idc - r * ROWP, px = i / NPB;
-            const int gy = iy0 + r, gx = ix0 + px;
-            in[k] = gy >= 0 && gy < P.hin && gx >= 0 && gx < P.win;
-            v[k] = *(const uint4*)(inb + (in[k] ? ((ptrdiff_t)gy * P.win + ix0) * CS + i * 8 : 0));      // branch-free, clamped
-        }
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int idx = tid + k * 256;
-            const int r = idx / ROWP, i = idx - r * ROWP, px = i / NPB, blk = i - px * NPB;
-            if (idx < NITEM) *(uint4*)(xs + (r * XW + px) * PS + blk * 16) = in[k] ? v[k] : make_uint4(0, 0, 0, 0);
-        }
-    }
-    __syncthreads();
-
-    auto toff_of = [&](int s, int rw) {                 // LDS byte offset of lane group g's 8 channels at k-step s in an image of row width rw
-        int toff = 0;
-#pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-            const int kk0 = (s * 4 + gg) * 8;
-            const int tap = kk0 / CS, cc0 = kk0 - tap * CS, dy = tap / 3, dx = tap - dy * 3;
-            const int o = kk0 < KTOT ? (dy * rw + dx) * PS + cc0 * 2 : 0;
-            toff = g == gg ? o : toff;
-        }
-        return toff;
-    };
-
-    // ---- conv1 + PReLU on the (TH+2) x (TW+2) ring-extended tile -> ms ----
-    const float slope = P.prelu;
-    const int act = (slope >= 0.f && slope <= 1.f) ? 1 : 2;
-#pragma unroll 1
-    for (int j0 = 0; j0 < NMW; j0 += 3) {               // three N-tiles at a time share every weight fragment
-        f32x4_t acc[MT][3];
-        int qb[3], qpix[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int nt = wv + 4 * (j0 + j);
-            int q = nt * 16 + p;
-            qpix[j] = (nt < NMT && q < NMID) ? q : -1;
-            q = q < NMID ? q : NMID - 1;
-            const int ry = q / MW, rx = q - ry * MW;
-            qb[j] = (ry * XW + rx) * PS;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll(MT >= 3 ? 2 : KS)        // wide CABs: partial unroll, otherwise every weight fragment of the k-walk is hoisted (235+ VGPRs)
-        for (int s = 0; s < KS; ++s) {
-            const int toff = toff_of(s, XW);
-            bf16x8_t a[MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) a[m] = as_frag(P.wfrag[(m * KS + s) * 64 + lane]);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const bf16x8_t b = as_frag(*(const uint4*)(xs + qb[j] + toff));
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m][j] = mfma16(a[m], b, acc[m][j]);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            if (qpix[j] < 0) continue;
-            const int ry = qpix[j] / MW, rx = qpix[j] - ry * MW;
-            const int gy = oy0 - 1 + ry, gx = ox0 - 1 + rx;
-            const bool inimg = gy >= 0 && gy < P.hout && gx >= 0 && gx < P.wout;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                if (c0 + m * 4 >= CS) continue;
-                float v[4] = {acc[m][j][0], acc[m][j][1], acc[m][j][2], acc[m][j][3]};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = act == 1 ? fmaxf(v[r], slope * v[r]) : fmaf(slope, fminf(v[r], 0.f), fmaxf(v[r], 0.f));
-                    v[r] = inimg ? v[r] : 0.f;            // conv2 zero-pads mid OUTSIDE the image, it does not see conv1 of padding
-                }
-                uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-                *(uint2*)(ms + qpix[j] * PS + (c0 + m * 4) * 2) = o;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- conv2 on TH x TW from ms ----
-    f32x4_t acc[MT][NTW];
-    int pixbase[NTW];
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) {
-        const int nn = wv * NTW + n, row = nn / XB, xb = nn - row * XB;
-        pixbase[n] = (row * MW + xb * 16 + p) * PS;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll(MT >= 3 ? 2 : KS)
-    for (int s = 0; s < KS; ++s) {
-        const int toff = toff_of(s, MW);
-        bf16x8_t a[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) a[m] = as_frag(w2frag[(m * KS + s) * 64 + lane]);
-        bf16x8_t b[NTW];
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) b[n] = as_frag(*(const uint4*)(ms + pixbase[n] + toff));
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NTW; ++n) acc[m][n] = mfma16(a[m], b[n], acc[m][n]);
-    }
-
-    // ---- epilogue: x ca, + x (staged tile), [+ res2], store ----
-    const size_t tbase = (((size_t)t * P.hout + oy0) * P.wout + ox0) * P.cs_out;
-    bf16_t* const outb = P.out + tbase;
-    const bf16_t* const res2b = P.res2 ? P.res2 + tbase : nullptr;
-    float4 osc[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) osc[m] = *(const float4*)(P.oscale + (size_t)t * P.oscale_stride + c0 + m * 4);
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) {
-        const int nn = wv * NTW + n, row = nn / XB, xb = nn - row * XB;
-        const int col = xb * 16 + p;
-        if (oy0 + row >= P.hout || ox0 + col >= P.wout) continue;
-        const int loff = (row * P.wout + col) * P.cs_out + c0;
-        const char* xres = xs + ((row + 2) * XW + col + 2) * PS + c0 * 2;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            if (c0 + m * 4 >= P.cs_out) continue;
-            float v[4] = {acc[m][n][0] * osc[m].x, acc[m][n][1] * osc[m].y, acc[m][n][2] * osc[m].z, acc[m][n][3] * osc[m].w};
-            const uint2 rr = *(const uint2*)(xres + m * 8);
-            v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
-            if (res2b) {
-                const uint2 r2 = *(const uint2*)(res2b + loff + m * 4);
-                v[0] += bf_lo(r2.x); v[1] += bf_hi(r2.x); v[2] += bf_lo(r2.y); v[3] += bf_hi(r2.y);
-            }
-            uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-            *(uint2*)(outb + loff + m * 4) = o;
-        }
-    }
-}
 
 template <int MT, int CS>
-int launch_cab_fused(const ConvK& K, const uint4* w2, int T, hipStream_t st) {
-    constexpr int NPB = CS / 8, PS = 16 * sn_lds_slots(NPB);
-    dim3 grid((K.wout + 31) / 32, (K.hout + 7) / 8, T);
-    const size_t lds = (size_t)(12 * 36 + 10 * 34) * PS;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)cab_fused_kernel<MT, CS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return SN_ELAUNCH;
-    }
-    hipLaunchKernelGGL((cab_fused_kernel<MT, CS>), grid, dim3(256), lds, st, K, w2);
-    return sn_check_launch();
-}
-
-#endif  // SN_EXPERIMENTAL
-
-template <int MT, int CS, int NIN = 1>
 int launch_conv3_fast(const ConvK& K, int T, hipStream_t st) {
     constexpr int TH = 8, TW = 32, NPB = CS / 8, PS = 16 * sn_lds_slots(NPB);
     ConvK P = K; P.xg = sn_xcd_tiles((K.wout + TW - 1) / TW, (K.hout + TH - 1) / TH, T);
     const dim3 grid = sn_xcd_grid(P.xg);
     const size_t lds = (size_t)(TH + 2) * (TW + 2) * PS + 4 * 16 * MT * sizeof(float);
     if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)conv3_fast_kernel<MT, CS, TH, NIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv3_fast_kernel<MT, CS, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return SN_ELAUNCH;
     }
-    hipLaunchKernelGGL((conv3_fast_kernel<MT, CS, TH, NIN>), grid, dim3(256), lds, st, P);
+    hipLaunchKernelGGL((conv3_fast_kernel<MT, CS, TH>), grid, dim3(256), lds, st, P);
     return sn_check_launch();
 }
 
@@ -837,10 +612,10 @@ __global__ __launch_bounds__(1024) void ca_mlp_kernel(const float* partial, int 
 // workgroup per frame was a 40 us latency chain, 101 times per window -- then one workgroup per frame finishes.
 #define SN_CABCA_NS 16
 __global__ __launch_bounds__(256) void cab_ca_part_kernel(const float* partial, int nblk, int cpad, const bf16_t* mid, int cs,
-                                                        int h, int w, float* scratch, const bf16_t* brow, const bf16_t* bcol) {
+                                                        int h, int w, float* scratch) {
     __shared__ float acc[256];
     const int t = blockIdx.y, sidx = blockIdx.x, tid = threadIdx.x;
-    const bf16_t* mt = mid ? mid + (size_t)t * h * w * cs : nullptr;
+    const bf16_t* mt = mid + (size_t)t * h * w * cs;
     float* out = scratch + ((size_t)t * SN_CABCA_NS + sidx) * 5 * 128;
     {
         const int nsplit = 256 / cpad, ch = tid % cpad, part = tid / cpad;
@@ -864,13 +639,8 @@ __global__ __launch_bounds__(256) void cab_ca_part_kernel(const float* partial, 
         float sm = 0.f;
         if (seg < nseg)
             for (int i = sidx * nseg + seg; i < len; i += SN_CABCA_NS * nseg) {
-                if (brow) {           // fused CAB: mid exists only as its border lines ([T][2][w][cs] rows, [T][2][h][cs] columns)
-                    const bf16_t* ln = line < 2 ? brow + ((size_t)blockIdx.y * 2 + line) * w * cs : bcol + ((size_t)blockIdx.y * 2 + (line - 2)) * h * cs;
-                    sm += bf_to_f(ln[(size_t)i * cs + ch]);
-                } else {
-                    const int y = line == 0 ? 0 : (line == 1 ? h - 1 : i), x = line == 2 ? 0 : (line == 3 ? w - 1 : i);
-                    sm += bf_to_f(mt[((size_t)y * w + x) * cs + ch]);
-                }
+                const int y = line == 0 ? 0 : (line == 1 ? h - 1 : i), x = line == 2 ? 0 : (line == 3 ? w - 1 : i);
+                sm += bf_to_f(mt[((size_t)y * w + x) * cs + ch]);
             }
         acc[tid] = sm;
         __syncthreads();
@@ -884,13 +654,13 @@ __global__ __launch_bounds__(256) void cab_ca_part_kernel(const float* partial, 
 }
 
 __global__ __launch_bounds__(1024) void cab_ca_kernel(const float* scratch, int cpad, const bf16_t* mid, int cs, int c, int cr,
-                                                     int h, int w, const float* w2, const float* wa, const float* wb, float* ca, const bf16_t* brow) {
+                                                     int h, int w, const float* w2, const float* wa, const float* wb, float* ca) {
     __shared__ float acc[1024];
     __shared__ float S[9][128];      // 0 total, 1 row0, 2 row h-1, 3 col0, 4 col w-1, 5..8 corners (0,0) (0,w-1) (h-1,0) (h-1,w-1)
     __shared__ float mean[128];
     __shared__ float hid[128];
     const int t = blockIdx.x, tid = threadIdx.x;
-    const bf16_t* mt = mid ? mid + (size_t)t * h * w * cs : nullptr;
+    const bf16_t* mt = mid + (size_t)t * h * w * cs;
     if (tid < 5 * 128) {
         const int k = tid >> 7, ch = tid & 127;
         float m = 0.f;
@@ -901,16 +671,10 @@ __global__ __launch_bounds__(1024) void cab_ca_kernel(const float* scratch, int 
         S[k][ch] = m;
     }
     if (tid < cs) {
-        if (brow) {
-            const bf16_t* r0 = brow + (size_t)t * 2 * w * cs, *r1 = r0 + (size_t)w * cs;
-            S[5][tid] = bf_to_f(r0[tid]); S[6][tid] = bf_to_f(r0[(size_t)(w - 1) * cs + tid]);
-            S[7][tid] = bf_to_f(r1[tid]); S[8][tid] = bf_to_f(r1[(size_t)(w - 1) * cs + tid]);
-        } else {
-            S[5][tid] = bf_to_f(mt[tid]);
-            S[6][tid] = bf_to_f(mt[((size_t)(w - 1)) * cs + tid]);
-            S[7][tid] = bf_to_f(mt[((size_t)(h - 1) * w) * cs + tid]);
-            S[8][tid] = bf_to_f(mt[((size_t)(h - 1) * w + w - 1) * cs + tid]);
-        }
+        S[5][tid] = bf_to_f(mt[tid]);
+        S[6][tid] = bf_to_f(mt[((size_t)(w - 1)) * cs + tid]);
+        S[7][tid] = bf_to_f(mt[((size_t)(h - 1) * w) * cs + tid]);
+        S[8][tid] = bf_to_f(mt[((size_t)(h - 1) * w + w - 1) * cs + tid]);
     }
     __syncthreads();
     {   // pooled res[co] = (1/hw) sum_ci sum_tap w2[ci][tap][co] * S_tap[ci]; thread = (slice of ci, co), then a tree over slices
@@ -951,21 +715,6 @@ __global__ __launch_bounds__(1024) void cab_ca_kernel(const float* scratch, int 
             o = sigmoidf_(o);
         }
         ca[(size_t)t * cpad + tid] = o;
-    }
-}
-
-__global__ void scale_residual_kernel(const uint4* res, const uint4* x, const float* ca, int cpad, uint4* out, int hw, int cs8) {
-    const int t = blockIdx.y;
-    const size_t n = (size_t)hw * cs8;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int cb = (int)(i % cs8);
-        float r[8], xv[8];
-        unpack8(res[(size_t)t * n + i], r);
-        unpack8(x[(size_t)t * n + i], xv);
-        const float* s = ca + (size_t)t * cpad + cb * 8;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = r[j] * s[j] + xv[j];
-        out[(size_t)t * n + i] = pack8(r);
     }
 }
 
@@ -1017,8 +766,7 @@ int sn_conv_pool_blocks(const sn_conv_desc* d) {
 int sn_conv2d(const sn_conv_desc* d, void* stream) {
     sn_clear_error();
     if (!d || d->n_in < 1 || d->n_in > 3 || (d->cs_in & 7) || (d->cs_out & 7) || !d->wfrag) return SN_EINVAL;
-    if (!d->out && !(d->border_rows && d->border_cols && d->pool)) return SN_EINVAL;      // sums-only launch: pass A of the fused CAB
-    if ((d->border_rows == nullptr) != (d->border_cols == nullptr)) return SN_EINVAL;
+    if (!d->out) return SN_EINVAL;
     if (d->k < 1 || d->k > 5 || (d->stride != 1 && d->stride != 2) || d->mt < 1 || d->mt > 6 || d->ks < 1) return SN_EINVAL;
     if (d->in_mode == 1 && ((d->h_in | d->w_in) & 1)) return SN_EINVAL;
     if (d->out_mode == 2 && (!d->sc || d->c_out > 4 * d->mt)) return SN_EINVAL;
@@ -1033,24 +781,15 @@ int sn_conv2d(const sn_conv_desc* d, void* stream) {
     K.wfrag = (const uint4*)d->wfrag; K.ks = d->ks; K.bias = d->bias; K.act = d->act; K.prelu = d->prelu;
     K.res = (const bf16_t*)d->res; K.out = (bf16_t*)d->out; K.cs_out = d->cs_out; K.out_mode = d->out_mode;
     K.c_out = d->c_out; K.nchw_dtype = d->nchw_dtype; K.sc = d->sc; K.pool = d->pool; K.oscale = d->oscale; K.oscale_stride = d->oscale_stride; K.res2 = (const bf16_t*)d->res2;
-    K.brow = (bf16_t*)d->border_rows; K.bcol = (bf16_t*)d->border_cols;
     const int blocks = K.cv >> 3;
     K.ps = d->stride == 1 ? 16 * sn_lds_slots(blocks) : ((blocks & 1) ? K.cv * 2 : K.cv * 2 + 16);     // stride 2: odd slot count (pixels 2 apart)
     K.rh = K.rw = 0;
     int th, tw; conv_tile(d, &th, &tw);
     if (d->k == 3 && d->stride == 1 && d->pad == 1 && d->in_mode == 0 && d->out_mode == 0 && d->ks == (9 * d->n_in * d->cs_in + 31) / 32) {
-        // the specialised 3x3 path (same tile shape: sn_conv_pool_blocks is unchanged); key = inputs, M-tiles, concatenated channels
+        // the specialised single-input 3x3 path (same tile shape: sn_conv_pool_blocks is unchanged); key = M-tiles, channels
         hipStream_t st = (hipStream_t)stream;
-        const int key = (d->n_in - 1) * 100000 + d->mt * 1000 + d->n_in * d->cs_in;
+        const int key = d->n_in == 1 ? d->mt * 1000 + d->cs_in : 0;
         switch (key) {
-#if SN_CONV3_WIDE       // feat_extract.0 (8 input channels) and the concatenating convs rconcat / conv_hr0 (2-3 inputs of 16 / 24 channels)
-            case 1008: return launch_conv3_fast<1, 8>(K, d->T, st);
-            case 2008: return launch_conv3_fast<2, 8>(K, d->T, st);
-            case 101032: return launch_conv3_fast<1, 32, 2>(K, d->T, st);
-            case 102048: return launch_conv3_fast<2, 48, 2>(K, d->T, st);
-            case 201048: return launch_conv3_fast<1, 48, 3>(K, d->T, st);
-            case 202072: return launch_conv3_fast<2, 72, 3>(K, d->T, st);
-#endif
             case 1016: return launch_conv3_fast<1, 16>(K, d->T, st);
             case 2024: return launch_conv3_fast<2, 24>(K, d->T, st);
             case 4064: return launch_conv3_fast<4, 64>(K, d->T, st);
@@ -1060,39 +799,11 @@ int sn_conv2d(const sn_conv_desc* d, void* stream) {
             default: break;                       // any other width: the generic kernel below
         }
     }
-    if (d->border_rows || !d->out) return SN_EINVAL;          // only the specialised 3x3 kernel knows sums-only / border-line launches
     if (th == 16) return launch_conv<16, 32>(K, d->mt, d->T, (hipStream_t)stream);
     if (th == 8) return launch_conv<8, 32>(K, d->mt, d->T, (hipStream_t)stream);
     return launch_conv<4, 16>(K, d->mt, d->T, (hipStream_t)stream);
 }
 
-#ifdef SN_EXPERIMENTAL
-// Measured on MI355X (round 2): config 2 130.7 ms per window with the fused CABs vs 124.7 ms with two sn_conv2d launches per CAB,
-// config 3 816 vs 710 ms.  The dense convs are LATENCY-bound, not bandwidth-bound (67 % of wave cycles parked on loads at 3.8-5.1
-// TB/s): one workgroup = load -> compute -> store with 4-8 workgroups per CU covering each other.  The fused pass B lengthens that
-// chain (stage, conv1 on 340 pixels, barrier, conv2, store) at a third of the occupancy, and pass A (sums only) saves just 15 % of a
-// conv: three passes instead of five do not pay until the kernel is persistent with the next tile's loads in flight.
-int sn_cab_fused(const sn_conv_desc* d, const void* wfrag2, void* stream) {
-    sn_clear_error();
-    if (!d || !wfrag2 || !d->wfrag || !d->out || !d->in[0] || !d->oscale || d->n_in != 1 || d->k != 3 || d->stride != 1 || d->pad != 1 ||
-        d->in_mode != 0 || d->out_mode != 0 || d->cs_in != d->cs_out || d->h_in != d->h_out || d->w_in != d->w_out || d->bias || d->act != 1 ||
-        d->ks != (9 * d->cs_in + 31) / 32 || d->oscale_stride < 16 * d->mt || d->res || d->pool) return SN_EINVAL;
-    ConvK K{};
-    K.in0 = (const bf16_t*)d->in[0]; K.n_in = 1; K.cs = d->cs_in; K.cv = d->cs_in;
-    K.hin = d->h_in; K.win = d->w_in; K.hout = d->h_out; K.wout = d->w_out; K.k = 3; K.stride = 1; K.pad = 1;
-    K.wfrag = (const uint4*)d->wfrag; K.ks = d->ks; K.prelu = d->prelu; K.act = 1;
-    K.out = (bf16_t*)d->out; K.cs_out = d->cs_out; K.oscale = d->oscale; K.oscale_stride = d->oscale_stride; K.res2 = (const bf16_t*)d->res2;
-    hipStream_t st = (hipStream_t)stream;
-    switch (d->mt * 1000 + d->cs_in) {
-        case 1016: return launch_cab_fused<1, 16>(K, (const uint4*)wfrag2, d->T, st);
-        case 2024: return launch_cab_fused<2, 24>(K, (const uint4*)wfrag2, d->T, st);
-        case 3040: return launch_cab_fused<3, 40>(K, (const uint4*)wfrag2, d->T, st);
-        case 3048: return launch_cab_fused<3, 48>(K, (const uint4*)wfrag2, d->T, st);
-        default: return SN_EINVAL;              // wider CABs (64, 80 channels) stay on the two-conv path (LDS: > 120 KB per workgroup)
-    }
-}
-
-#endif  // SN_EXPERIMENTAL
 
 int sn_ca_mlp(const float* partial, int nblk, int cpad, int c, int cr, float inv_hw,
               const float* wa, const float* wb, float* ca, int T, void* stream) {
@@ -1105,26 +816,14 @@ int sn_ca_mlp(const float* partial, int nblk, int cpad, int c, int cr, float inv
 int sn_cab_ca_scratch_floats(int T) { return T * SN_CABCA_NS * 5 * 128; }
 
 int sn_cab_ca(const float* partial, int nblk, int cpad, const void* mid, int cs, int c, int cr, int h, int w,
-              const float* w2, const float* wa, const float* wb, float* scratch, float* ca, int T, void* stream,
-              const void* border_rows, const void* border_cols) {
+              const float* w2, const float* wa, const float* wb, float* scratch, float* ca, int T, void* stream) {
     sn_clear_error();
-    if (!partial || !w2 || !wa || !wb || !ca || !scratch || cpad < 16 || cpad > 128 || cs > 128 || (cs & 7) || c > cs ||
+    if (!partial || !mid || !w2 || !wa || !wb || !ca || !scratch || cpad < 16 || cpad > 128 || cs > 128 || (cs & 7) || c > cs ||
         c > cpad || cr < 1 || cr > 128 || nblk < 1 || h < 2 || w < 2) return SN_EINVAL;
-    if ((border_rows == nullptr) != (border_cols == nullptr) || (!mid && !border_rows)) return SN_EINVAL;
     hipLaunchKernelGGL(cab_ca_part_kernel, dim3(SN_CABCA_NS, T), dim3(256), 0, (hipStream_t)stream, partial, nblk, cpad,
-                       (const bf16_t*)mid, cs, h, w, scratch, (const bf16_t*)border_rows, (const bf16_t*)border_cols);
+                       (const bf16_t*)mid, cs, h, w, scratch);
     hipLaunchKernelGGL(cab_ca_kernel, dim3(T), dim3(1024), 0, (hipStream_t)stream, (const float*)scratch, cpad, (const bf16_t*)mid, cs,
-                       c, cr, h, w, w2, wa, wb, ca, (const bf16_t*)border_rows);
-    return sn_check_launch();
-}
-
-int sn_scale_residual(const void* res, const void* x, const float* ca, int cpad, void* out, int T, int hw, int cs, void* stream) {
-    sn_clear_error();
-    if (!res || !x || !ca || !out || (cs & 7) || cs > cpad) return SN_EINVAL;
-    const size_t n = (size_t)hw * (cs >> 3);
-    int gx = (int)((n + 255) / 256); if (gx > 2048) gx = 2048;
-    hipLaunchKernelGGL(scale_residual_kernel, dim3(gx, T), dim3(256), 0, (hipStream_t)stream,
-                       (const uint4*)res, (const uint4*)x, ca, cpad, (uint4*)out, hw, cs >> 3);
+                       c, cr, h, w, w2, wa, wb, ca);
     return sn_check_launch();
 }
 

@@ -5,10 +5,7 @@
 //                      One workgroup owns an 8x32 output tile; LN+GEMM run on the tile plus a 1-pixel ring (340 px,
 //                      1.33x recompute); `a` goes to LDS 32 channels at a time (gate-paired chunks), the normalised
 //                      operands stay in registers as MFMA B fragments for the whole chunk loop.
-//   sn_dw5_gemm_gate  (K3'): g2 = SimpleGate2(body[4](RepConv(g1))) for the depthwise variants (C = 64): the g1 tile
-//                      (+2 ring) is staged in LDS 32 channels at a time, the 5x5 stencil runs with lane = pixel column
-//                      and a wave-uniform channel block (weights are scalar loads), its output feeds the MFMA k-step
-//                      of those 32 channels straight from LDS; accumulators persist across the two passes.
+//   sn_grp5_gemm_gate (K3g): the grouped RepConv of the "+" variants as a block-diagonal MFMA GEMM + 1x1 + SimpleGate2 (below).
 #include "sn_common.h"
 #include "../../include/shiftnet_hip.h"
 
@@ -30,25 +27,12 @@ __device__ __forceinline__ Slabs2 unit_slabs2(const UnitK2& U, int t) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-#ifndef SN_K12_TH
 #define SN_K12_TH 8
 #define SN_K12_NWV 8
-#endif
-#ifndef SN_K12_WSTREAM
-#define SN_K12_WSTREAM 0
-#endif
-#ifndef SN_K12_LDS_PAD
-#define SN_K12_LDS_PAD 0
-#endif
 template <int C, bool WITH_HW>
 __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const UnitK2 U, const XcdTiles G, const bf16_t* __restrict__ hwb, const uint4* __restrict__ wfrag,
                                                          const float* __restrict__ bias, const uint32_t* __restrict__ wdw,
-                                                         bf16_t* g1, float* pool, const int blocked, const int dbg_, unsigned long long* prof_) {
-#ifdef SN_EXPERIMENTAL
-    const int dbg = dbg_; unsigned long long* const prof = prof_;                 // ablation / phase-clock hooks (tools/prof_k12.py)
-#else
-    constexpr int dbg = 0; constexpr unsigned long long* prof = nullptr;          // production: the hooks fold away
-#endif
+                                                         bf16_t* g1, float* pool, const int blocked) {
     constexpr int CH = C / 2, K = WITH_HW ? C + CH : C, KS = (K + 31) / 32, MT = C / 8, NCHK = MT / 2;
     constexpr int TH = SN_K12_TH, TW = 32, RH = TH + 2, RW = TW + 2, NPX = RH * RW;  // tile + 1-pixel ring (8x32: 340 px, 16x32: 612 px)
     constexpr int NWV = SN_K12_NWV;                                                // waves per workgroup
@@ -56,43 +40,24 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
     constexpr int PSA = 80;                                                        // LDS bytes per pixel of an a-chunk (64 + 16 pad)
     __shared__ __attribute__((aligned(16))) char lds_a2[2][NPX * PSA];           // double-buffered a-chunk: one barrier per chunk
     __shared__ __attribute__((aligned(16))) uint16_t lds_tr[NWV][8][64];          // per-wave transpose scratch of the planar epilogue
-#if SN_K12_LDS_PAD      // occupancy experiment: extra LDS per workgroup forces ONE workgroup per CU (see the WSTREAM note below)
-    __shared__ char lds_pad[SN_K12_LDS_PAD];
-    if (U.T < 0) lds_pad[threadIdx.x] = 1;
-#endif
     const int lane = threadIdx.x & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
     int t, tyi, txi;
     if (!sn_xcd_tile(G, t, tyi, txi)) return;     // XCD-aware walk (sn_common.h): ring rows / columns of neighbouring tiles meet in one L2
     const int oy0 = tyi * TH, ox0 = txi * TW;
     const int hw = U.h * U.w;
     const Slabs2 sl = unit_slabs2(U, t);
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-    auto tick = [&](int slot) {
-        if (prof) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tacc[slot] += now - tlast; tlast = now; }
-    };
 
-    // weight fragments and bias of one chunk, fetched one chunk AHEAD (they come from L2: ~1 us when loaded at the point of use).
-    // WSTREAM (-DSN_K12_WSTREAM=1, C = 80 only): the fragments are streamed one k-step ahead inside the chunk's MFMA loop (16 instead of
-    // 32 registers) and the LayerNorm sweeps re-derive the fp32 values from the raw words: the C = 80 CAB2 instance drops from 152 to
-    // 116 VGPRs, i.e. from ONE to TWO 8-wave workgroups per CU, bit-identical output (tools/ab_k12.py).  MEASURED at 20 x 360 x 640:
-    // 1284-1309 us vs 985-1117 us for CAB2 (slower), 745-768 vs 751-780 us for CAB1 (same occupancy either way: neutral).  The
-    // converse experiment (-DSN_K12_LDS_PAD=24576: one workgroup per CU for C = 64) is neutral as well (591 vs 585 us): K12's
-    // throughput does not come from co-resident workgroups, one 8-wave workgroup already saturates whatever bounds it.
-    constexpr bool WSTREAM = SN_K12_WSTREAM && C == 80;
-    bf16x8_t Wf[2][WSTREAM ? 1 : KS];
+    // weight fragments and bias of one chunk, fetched one chunk AHEAD (they come from L2: ~1 us when loaded at the point of use)
+    bf16x8_t Wf[2][KS];
     float4 Wb[2];
     auto load_w = [&](int q) {
-        if constexpr (!WSTREAM) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                Wf[0][s] = as_frag(wfrag[((2 * q) * KS + s) * 64 + lane]);
-                Wf[1][s] = as_frag(wfrag[((2 * q + 1) * KS + s) * 64 + lane]);
-            }
+        for (int s = 0; s < KS; ++s) {
+            Wf[0][s] = as_frag(wfrag[((2 * q) * KS + s) * 64 + lane]);
+            Wf[1][s] = as_frag(wfrag[((2 * q + 1) * KS + s) * 64 + lane]);
         }
-        if constexpr (!WSTREAM) {
-            Wb[0] = *(const float4*)(bias + g * 4 * MT + (2 * q) * 4);
-            Wb[1] = *(const float4*)(bias + g * 4 * MT + (2 * q + 1) * 4);
-        }
+        Wb[0] = *(const float4*)(bias + g * 4 * MT + (2 * q) * 4);
+        Wb[1] = *(const float4*)(bias + g * 4 * MT + (2 * q + 1) * 4);
     };
     load_w(0);
 
@@ -130,55 +95,7 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
         // branch-free: ALWAYS load (a load inside a divergent branch is waited for on the spot, one memory round trip per slab)
         uint4 raw[KS];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) raw[s] = *(const uint4*)(slab[s] + (dbg & 8 ? 0 : ii * sstride[s]));
-        if constexpr (WSTREAM) {
-            // register-lean form: the fp32 values are re-derived from the raw words in each of the three sweeps instead of being
-            // kept (32 registers less at the kernel's register peak, 16 more unpack instructions per k-step)
-            const bool lastpad = (KS - 1) * 32 + 24 >= K;
-            auto up = [&](int s, int j) -> f32x2_t {
-                const uint32_t wd = j == 0 ? raw[s].x : j == 1 ? raw[s].y : j == 2 ? raw[s].z : raw[s].w;
-                return (f32x2_t){bf_lo(wd), bf_hi(wd)};
-            };
-            if (lastpad) {
-                const bool has = (KS - 1) * 32 + g * 8 < K;
-                raw[KS - 1].x = has ? raw[KS - 1].x : 0u; raw[KS - 1].y = has ? raw[KS - 1].y : 0u;
-                raw[KS - 1].z = has ? raw[KS - 1].z : 0u; raw[KS - 1].w = has ? raw[KS - 1].w : 0u;
-            }
-            f32x2_t sum2 = {0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) sum2 += up(s, j);
-            const float mean = sum_rows4(sum2[0] + sum2[1]) * (1.0f / K);
-            const f32x2_t mean2 = {mean, mean};
-            f32x2_t sq2 = {0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const bool pad = lastpad && s == KS - 1 && !(s * 32 + g * 8 < K);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x2_t d = up(s, j) - mean2;
-                    if (lastpad && s == KS - 1) d = pad ? (f32x2_t){0.f, 0.f} : d;
-                    sq2 = __builtin_elementwise_fma(d, d, sq2);
-                }
-            }
-            const float sq = sum_rows4(sq2[0] + sq2[1]);
-            const float rstd = 1.0f / sqrtf(sq * (1.0f / K) + 1e-6f);
-            const f32x2_t rstd2 = {rstd, rstd};
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const bool pad = lastpad && s == KS - 1 && !(s * 32 + g * 8 < K);
-                uint32_t o[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x2_t d = (up(s, j) - mean2) * rstd2;
-                    if (lastpad && s == KS - 1) d = pad ? (f32x2_t){0.f, 0.f} : d;
-                    o[j] = pack_bf2(d[0], d[1]);
-                }
-                B[n][s] = as_frag(make_uint4(o[0], o[1], o[2], o[3]));
-            }
-            continue;
-        }
+        for (int s = 0; s < KS; ++s) raw[s] = *(const uint4*)(slab[s] + ii * sstride[s]);
         f32x2_t xv[KS][4];
         f32x2_t sum2 = {0.f, 0.f};
 #pragma unroll
@@ -188,7 +105,6 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
                 const bool has = s * 32 + g * 8 < K;
                 q.x = has ? q.x : 0u; q.y = has ? q.y : 0u; q.z = has ? q.z : 0u; q.w = has ? q.w : 0u;
             }
-            if (dbg & 8) q = make_uint4(0, 0, 0, 0);
             xv[s][0] = (f32x2_t){bf_lo(q.x), bf_hi(q.x)}; xv[s][1] = (f32x2_t){bf_lo(q.y), bf_hi(q.y)};
             xv[s][2] = (f32x2_t){bf_lo(q.z), bf_hi(q.z)}; xv[s][3] = (f32x2_t){bf_lo(q.w), bf_hi(q.w)};
 #pragma unroll
@@ -224,28 +140,13 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
     auto gemm_chunk = [&](int q) {
         char* lds_a = lds_a2[q & 1];
         f32x4_t acc0[NTW], acc1[NTW];
-        float4 b0, b1;
-        if constexpr (WSTREAM) {      // bias fetched here, not a chunk ahead: 8 registers less across the stencil phase
-            b0 = *(const float4*)(bias + g * 4 * MT + (2 * q) * 4); b1 = *(const float4*)(bias + g * 4 * MT + (2 * q + 1) * 4);
-        } else { b0 = Wb[0]; b1 = Wb[1]; }
+        const float4 b0 = Wb[0], b1 = Wb[1];
 #pragma unroll
         for (int n = 0; n < NTW; ++n) { acc0[n] = (f32x4_t){b0.x, b0.y, b0.z, b0.w}; acc1[n] = (f32x4_t){b1.x, b1.y, b1.z, b1.w}; }
-        if constexpr (WSTREAM) {
-            bf16x8_t w0 = as_frag(wfrag[((2 * q) * KS) * 64 + lane]), w1 = as_frag(wfrag[((2 * q + 1) * KS) * 64 + lane]);
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int sn = s + 1 < KS ? s + 1 : s;
-                const bf16x8_t n0 = as_frag(wfrag[((2 * q) * KS + sn) * 64 + lane]), n1 = as_frag(wfrag[((2 * q + 1) * KS + sn) * 64 + lane]);
+        for (int s = 0; s < KS; ++s) {
 #pragma unroll
-                for (int n = 0; n < NTW; ++n) { acc0[n] = mfma16(w0, B[n][s], acc0[n]); acc1[n] = mfma16(w1, B[n][s], acc1[n]); }
-                w0 = n0; w1 = n1;
-            }
-        } else {
-#pragma unroll
-            for (int s = (dbg & 16) ? KS : 0; s < KS; ++s) {
-#pragma unroll
-                for (int n = 0; n < NTW; ++n) { acc0[n] = mfma16(Wf[0][s], B[n][s], acc0[n]); acc1[n] = mfma16(Wf[1][s], B[n][s], acc1[n]); }
-            }
+            for (int n = 0; n < NTW; ++n) { acc0[n] = mfma16(Wf[0][s], B[n][s], acc0[n]); acc1[n] = mfma16(Wf[1][s], B[n][s], acc1[n]); }
         }
 #pragma unroll
         for (int n = 0; n < NTW; ++n) {
@@ -260,18 +161,14 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
             }
         }
     };
-    tick(0);
     gemm_chunk(0);
     load_w(1);
-    tick(1);
 #pragma unroll 1
     for (int q = 0; q < NCHK; ++q) {
         // one barrier per chunk: chunk q is complete in buffer q&1, and every wave is done reading buffer (q+1)&1 (chunk q-1)
         __syncthreads();
-        tick(2);
         if (q + 1 < NCHK) gemm_chunk(q + 1);            // MFMA work of the next chunk overlaps this chunk's stencil
         load_w(q + 2 < NCHK ? q + 2 : NCHK - 1);        // unconditional (clamped): consumed one iteration later
-        tick(1);
         const char* lds_a = lds_a2[q & 1];
         // ---- depthwise 3x3 (+identity) and gate.  Wave = (64-pixel group pg, lane-group-slot pair gp): it handles slots
         //      2gp and 2gp+1 one after the other (the slot's weights are wave-uniform scalar loads), lanes are pixels, so a
@@ -299,7 +196,7 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
                 h2_t o2[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o2[k] = (h2_t){(_Float16)0.f, (_Float16)0.f};
-                if (!(dbg & 32)) {
+                {
 #pragma unroll
                     for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
@@ -330,7 +227,6 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
                     }
                 }
             }
-            tick(3);
             if (blocked == 2) {
                 // channel-planar g1 [T][h][C][wr] for the matrix-core stencil (sn_gsts3.hip): the wave's 64 pixels x 8 channels
                 // go through a wave-private LDS transpose (LDS operations of one wave execute in order: no barrier), then every
@@ -351,198 +247,14 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
                 if (py < U.h && pxx < wr) *(uint4*)(g1 + (((size_t)t * U.h + py) * C + ch) * wr + pxx) = v;
             } else if (inside) {
                 const size_t pix = (size_t)gy * U.w + gx;
-                if (blocked) {   // chunk-blocked [T][NCHK][h][w][16]: block q, position gs*4 + r  <->  channel gs*2*MT + q*4 + r
-                    *(uint4*)(g1 + (((size_t)t * NCHK + q) * hw + pix) * 16 + gp * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-                } else {         // natural NHWC
-                    bf16_t* dst = g1 + ((size_t)t * hw + pix) * C + q * 4;
-                    *(uint2*)(dst + (gp * 2) * 2 * MT) = make_uint2(ow[0], ow[1]);
-                    *(uint2*)(dst + (gp * 2 + 1) * 2 * MT) = make_uint2(ow[2], ow[3]);
-                }
+                bf16_t* dst = g1 + ((size_t)t * hw + pix) * C + q * 4;          // natural NHWC
+                *(uint2*)(dst + (gp * 2) * 2 * MT) = make_uint2(ow[0], ow[1]);
+                *(uint2*)(dst + (gp * 2 + 1) * 2 * MT) = make_uint2(ow[2], ow[3]);
             }
-            tick(4);
         }
-    }
-    if (prof && lane == 0 && t == 0 && tyi * G.ntx + txi < 256) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) prof[((size_t)(tyi * G.ntx + txi) * 8 + wv) * 8 + k] = tacc[k];
     }
 }
 
-#ifdef SN_EXPERIMENTAL   // K3': VALU 5x5 stencil, superseded by the matrix-core stencil kernel in sn_gsts3.hip
-// ------------------------------------------------------------------------------------------------------------
-// K3' (C = 64, depthwise RepConv): tile 64 x 4 pixels.  Four passes of 16 channels: stage the g1 region (+2 ring),
-// run the 5x5 stencil (wave = 4-channel block, lane = pixel column, 4 output rows with full vertical reuse, one kernel
-// column of weights (20 SGPRs) live at a time), write r[px][64ch] to LDS; then one MFMA sweep over the finished r tile.
-// Nothing persists in registers across passes, so the kernel fits 2-3 waves per SIMD.
-template <int TY>
-__global__ __launch_bounds__(256) void dw5_gemm_gate_kernel(const bf16_t* __restrict__ g1, const float* __restrict__ ca_in,
-                                                          const uint32_t* __restrict__ w5, const uint4* __restrict__ wfrag,
-                                                          bf16_t* g2, float* pool, int T, int h, int w, const int dbg) {
-    // PERSISTENT: gridDim.x workgroups walk the (frame, tile) list; the stencil weight words (6.4 KB) and the MFMA A
-    // fragments (64 VGPRs) are loaded once, and the staging loads of the NEXT pass / NEXT tile are always in flight
-    // while the current stencil or GEMM runs, so no global-memory latency is exposed inside the loop.
-    constexpr int C = 64, TXW = 64, RH = TY + 4, RW = TXW + 4, PSG = 40, PSR = 144, MT = 8, NT = TY, KS = 2;
-    __shared__ __attribute__((aligned(16))) char lds_g[RH * RW * PSG];      // 21760 B: g1 region, 16 channels (32 B + 8 pad)
-    __shared__ __attribute__((aligned(16))) char lds_r[TY * TXW * PSR];     // 36864 B: stencil output, all 64 channels
-    __shared__ float red[4 * C];
-    __shared__ __attribute__((aligned(16))) uint32_t lds_w[25 * C];         // stencil weight words [tap][64 ch]
-    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
-    const size_t hwp = (size_t)h * w;
-    const int tiles_x = (w + TXW - 1) / TXW, tiles_y = (h + TY - 1) / TY, tpf = tiles_x * tiles_y, ntiles = T * tpf;
-
-    for (int e = tid; e < 25 * C; e += 256) lds_w[e] = w5[e];
-    bf16x8_t A[MT][KS];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int s = 0; s < KS; ++s) A[m][s] = as_frag(wfrag[(m * KS + s) * 64 + lane]);
-
-    // staging plan: the same (region pixel, 16-byte piece) items for every tile and pass
-    constexpr int NITEM = (RH * RW * 2 + 255) / 256;
-    int iry[NITEM], irx[NITEM], lofs[NITEM];
-#pragma unroll
-    for (int k = 0; k < NITEM; ++k) {
-        const int idx = tid + k * 256, pix = idx >> 1, pc = idx & 1;
-        iry[k] = pix / RW; irx[k] = pix - iry[k] * RW;
-        lofs[k] = idx < RH * RW * 2 ? pix * PSG + pc * 16 : -1;
-    }
-    uint4 stg[NITEM];
-    int gofs[NITEM];                                   // element offset of each item inside one channel block, or -1
-    auto plan_tile = [&](int tile) {                    // once per tile: validity and offsets are the same for all 4 passes
-        const int t = tile / tpf, rem = tile - t * tpf, ty = rem / tiles_x, tx = rem - ty * tiles_x;
-        const int y0 = ty * TY, x0 = tx * TXW;
-#pragma unroll
-        for (int k = 0; k < NITEM; ++k) {
-            const int gy = y0 - 2 + iry[k], gx = x0 - 2 + irx[k];
-            const bool ok = lofs[k] >= 0 && gy >= 0 && gy < h && gx >= 0 && gx < w && !(dbg & 1);
-            gofs[k] = ok ? (gy * w + gx) * 16 + (tid & 1) * 8 : -1;
-        }
-        return t;
-    };
-    auto issue_loads = [&](int t, int pass) {          // g1 is channel-blocked [T][4][h][w][16]: one pass = one block
-        const bf16_t* gt = g1 + ((size_t)t * 4 + pass) * hwp * 16;
-        // UNCONDITIONAL loads (offset clamped to 0, masked when written to LDS): a branch around a load makes the compiler
-        // wait for it right away (phi copies behind s_waitcnt vmcnt(0)) and the prefetch would not be asynchronous
-#pragma unroll
-        for (int k = 0; k < NITEM; ++k) stg[k] = *(const uint4*)(gt + (gofs[k] < 0 ? 0 : gofs[k]));
-    };
-
-    int gofs_cur[NITEM];                                // plan of the tile whose data currently sits in stg
-    int tile = blockIdx.x;
-    issue_loads(plan_tile(tile < ntiles ? tile : 0), 0);
-    __syncthreads();                                    // lds_w ready
-    for (; tile < ntiles; tile += gridDim.x) {
-        const int t = tile / tpf, rem = tile - t * tpf, tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
-        const int y0 = tyi * TY, x0 = txi * TXW;
-#pragma unroll 1
-        for (int pass = 0; pass < 4; ++pass) {
-#pragma unroll
-            for (int k = 0; k < NITEM; ++k) gofs_cur[k] = gofs[k];
-#pragma unroll
-            for (int k = 0; k < NITEM; ++k)
-                if (lofs[k] >= 0) {
-                    const bool z = gofs_cur[k] < 0;
-                    uint2* d = (uint2*)(lds_g + lofs[k]);
-                    d[0] = z ? make_uint2(0, 0) : make_uint2(stg[k].x, stg[k].y);
-                    d[1] = z ? make_uint2(0, 0) : make_uint2(stg[k].z, stg[k].w);
-                }
-            __syncthreads();
-            {   // prefetch the next (tile, pass) in STRAIGHT-LINE code: no branch around the loads, otherwise the
-                // compiler joins the paths behind an s_waitcnt vmcnt(0) and the loads stop being asynchronous.
-                // Past the last tile the current tile is re-read (harmless).
-                const int ntile = pass == 3 ? tile + (int)gridDim.x : tile;
-                issue_loads(plan_tile(ntile < ntiles ? ntile : tile), (pass + 1) & 3);
-            }
-            const int cb = pass * 4 + wv;              // 4-channel block: channels [cb*4, cb*4+4)
-            float r[TY][4];
-#pragma unroll
-            for (int oy = 0; oy < TY; ++oy)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) r[oy][j] = 0.f;
-#pragma unroll 1
-            for (int dx = (dbg & 2) ? 5 : 0; dx < 5; ++dx) {
-                uint32_t wcol[5][4];                   // bf16 weight of channel j in half (j & 1) of its word, other half zero
-#pragma unroll
-                for (int dy = 0; dy < 5; ++dy) {
-                    const uint4 ww = *(const uint4*)(lds_w + (dy * 5 + dx) * C + cb * 4);     // broadcast read
-                    wcol[dy][0] = ww.x; wcol[dy][1] = ww.y; wcol[dy][2] = ww.z; wcol[dy][3] = ww.w;
-                }
-#pragma unroll
-                for (int iy = 0; iy < RH; ++iy) {
-                    const uint2 q = *(const uint2*)(lds_g + (iy * RW + lane + dx) * PSG + wv * 8);
-#pragma unroll
-                    for (int oy = 0; oy < TY; ++oy) {
-                        const int dy = iy - oy;
-                        if (dy >= 0 && dy < 5) {
-                            r[oy][0] = dot2bf(q.x, wcol[dy][0], r[oy][0]); r[oy][1] = dot2bf(q.x, wcol[dy][1], r[oy][1]);
-                            r[oy][2] = dot2bf(q.y, wcol[dy][2], r[oy][2]); r[oy][3] = dot2bf(q.y, wcol[dy][3], r[oy][3]);
-                        }
-                    }
-                }
-            }
-            float sc[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sc[j] = ca_in ? ca_in[(size_t)t * C + wv * 16 + pass * 4 + j] : 1.f;   // channel of (pass, wv, j)
-#pragma unroll
-            for (int oy = 0; oy < TY; ++oy) {
-                uint2 o;
-                o.x = pack_bf2(r[oy][0] * sc[0], r[oy][1] * sc[1]); o.y = pack_bf2(r[oy][2] * sc[2], r[oy][3] * sc[3]);
-                *(uint2*)(lds_r + (oy * TXW + lane) * PSR + cb * 8) = o;
-            }
-            __syncthreads();                           // lds_g free for the next pass, lds_r complete after pass 3
-        }
-
-        // ---- GEMM over the finished r tile: wave wv owns NT N-tiles (16 pixels each); per N-tile all 8 M-tiles are
-        // accumulated, so a lane ends up with its pixel's 16 consecutive g2 channels = one 32-byte store.
-        float ps[MT / 2][4];
-#pragma unroll
-        for (int mp = 0; mp < MT / 2; ++mp)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) ps[mp][rr] = 0.f;
-#pragma unroll 1
-        for (int n = (dbg & 4) ? NT : 0; n < NT; ++n) {
-            const int tp = (wv * NT + n) * 16 + p;
-            bf16x8_t Bf[KS];
-#pragma unroll
-            for (int s = 0; s < KS; ++s) Bf[s] = as_frag(*(const uint4*)(lds_r + tp * PSR + (s * 32 + g * 8) * 2));
-            f32x4_t acc[MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < KS; ++s) acc[m] = mfma16(A[m][s], Bf[s], acc[m]);
-            }
-            const int oy = y0 + tp / TXW, ox = x0 + (tp % TXW);
-            if (oy < h && ox < w) {
-                uint32_t o[MT];
-#pragma unroll
-                for (int mp = 0; mp < MT / 2; ++mp) {
-                    float v[4];
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) { v[rr] = acc[2 * mp][rr] * sigmoidf_(acc[2 * mp + 1][rr]); ps[mp][rr] += v[rr]; }
-                    o[2 * mp] = pack_bf2(v[0], v[1]); o[2 * mp + 1] = pack_bf2(v[2], v[3]);
-                }
-                uint4* dst = (uint4*)(g2 + (((size_t)t * h + oy) * w + ox) * C + g * 2 * MT);
-                dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
-                dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
-            }
-        }
-#pragma unroll
-        for (int mp = 0; mp < MT / 2; ++mp)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                float sm = ps[mp][rr];
-                sm = row_sum16(sm);
-                if (p == 0) red[wv * C + g * 2 * MT + mp * 4 + rr] = sm;
-            }
-        __syncthreads();
-        if (pool && tid < C)
-            pool[((size_t)t * tpf + rem) * C + tid] = red[tid] + red[C + tid] + red[2 * C + tid] + red[3 * C + tid];
-        // red / lds_r are rewritten only after the next tile's first __syncthreads()
-    }
-}
-
-#endif  // SN_EXPERIMENTAL
 
 // ------------------------------------------------------------------------------------------------------------
 // K3g ("+" variants, RepConv with groups = C/8): grouped 5x5 (+3x3 +identity folded) as a block-diagonal MFMA GEMM
@@ -562,16 +274,7 @@ __global__ __launch_bounds__(256) void dw5_gemm_gate_kernel(const bf16_t* __rest
 template <int C, int NH>
 __global__ __launch_bounds__(64 * NH * (C / 16), 3) void grp5p_gemm_gate_kernel(const bf16_t* __restrict__ g1, const float* __restrict__ ca_in,
                                                             const uint4* __restrict__ wgrp, const uint4* __restrict__ wfrag,
-                                                            bf16_t* g2, float* pool, int T, int h, int w, unsigned long long* prof_) {
-#ifdef SN_EXPERIMENTAL
-    unsigned long long* const prof = prof_;                 // in-kernel phase clocks (tools/prof_k3g.py)
-#else
-    constexpr unsigned long long* prof = nullptr;
-#endif
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-    auto tick = [&](int slot) {
-        if (prof) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tacc[slot] += now - tlast; tlast = now; }
-    };
+                                                            bf16_t* g2, float* pool, int T, int h, int w) {
     // PS = LDS bytes per pixel = 10 slots of 16 B, NO padding: ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27}, ...
     // (MI355X_MICROARCH.md), i.e. half a group reads chunk g&1 = 0 of 8 pixels and the other half chunk 1 of 8 OTHER pixels; with
     // slot = 10 p + (g&1) the 16 lanes of every group hit 16 distinct slots, while the "odd number of slots" padding (11) that suits
@@ -625,7 +328,6 @@ __global__ __launch_bounds__(64 * NH * (C / 16), 3) void grp5p_gemm_gate_kernel(
     for (; tile < seg1; tile += wpx) {
         const int t = tile / tpf, rem = tile - t * tpf, tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
         const int y0 = tyi * TY, x0 = txi * TXW;
-        tick(7);
         // ---- registers -> LDS (optional CALayer2 scale of the denoise variants), then prefetch the next tile ----
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
@@ -641,9 +343,7 @@ __global__ __launch_bounds__(64 * NH * (C / 16), 3) void grp5p_gemm_gate_kernel(
             }
             *(uint4*)(lds_g + pix * PS + pc * 16) = q;
         }
-        tick(0);
         __syncthreads();
-        tick(1);
         // gate-pair fragments of this tile (L1/L2 hits) FIRST, then the next tile's staging loads: vmcnt retires in order, so
         // waiting for the fragments before phase 2 must not also wait for the HBM loads issued behind them
         bf16x8_t A2[2][KS];
@@ -704,9 +404,7 @@ __global__ __launch_bounds__(64 * NH * (C / 16), 3) void grp5p_gemm_gate_kernel(
                 *(uint2*)(lds_r + ((NTWV * nh + n0 + n) * 16 + p) * PS + (m * 16 + g * 4) * 2) = o;
             }
         }
-        tick(2);
         __syncthreads();                                   // r complete; every wave is done reading the g1 region
-        tick(3);
         // ---- 1x1 C -> 2C, gate pair m: channels 2*MT*g + 4m + rr of the gate-paired order (MT = C/8), SimpleGate2 ----
         float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -749,9 +447,7 @@ __global__ __launch_bounds__(64 * NH * (C / 16), 3) void grp5p_gemm_gate_kernel(
             const float sm = row_sum16(ps[rr]);
             if (p == 0) red[nh * C + g * (C / 4) + 4 * m + rr] = sm;
         }
-        tick(4);
         __syncthreads();                                   // output tile and red complete
-        tick(5);
         // ---- coalesced NHWC stores: 16-byte pieces, consecutive lanes = consecutive addresses of a pixel's C channels ----
         for (int it = tid; it < TY * TXW * NPC; it += NTHR) {
             const int px = it / NPC, pc = it - px * NPC;
@@ -759,12 +455,7 @@ __global__ __launch_bounds__(64 * NH * (C / 16), 3) void grp5p_gemm_gate_kernel(
             if (oy < h && ox < w) *(uint4*)(g2 + (((size_t)t * h + oy) * w + ox) * C + pc * 8) = *(const uint4*)(lds_g + px * PS + pc * 16);
         }
         if (pool && tid < C) pool[((size_t)t * tpf + rem) * C + tid] = NH == 2 ? red[tid] + red[C + tid] : red[tid];
-        tick(6);
         __syncthreads();                                   // the output tile (g1 region) and red are rewritten by the next tile
-    }
-    if (prof && lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) prof[((size_t)blockIdx.x * 16 + wv) * 8 + k] = tacc[k];
     }
 }
 
@@ -772,57 +463,25 @@ __global__ __launch_bounds__(64 * NH * (C / 16), 3) void grp5p_gemm_gate_kernel(
 
 extern "C" {
 
-#ifdef SN_EXPERIMENTAL
-static int g_sn_debug = 0;                      /* process-global profiling switches: experimental build only */
-int sn_debug_set(int v) { g_sn_debug = v; return 0; }
-int sn_debug_get(void) { return g_sn_debug; }
-static void* g_sn_debug_buf = nullptr;          /* optional device buffer for in-kernel cycle counters (tools/) */
-int sn_debug_buf_set(void* p) { g_sn_debug_buf = p; return 0; }
-void* sn_debug_buf_get(void) { return g_sn_debug_buf; }
-#define SN_DBG_MASK g_sn_debug
-#define SN_DBG_BUF(bit) ((unsigned long long*)((g_sn_debug & (bit)) ? g_sn_debug_buf : nullptr))
-
-#ifndef SN_DW5_TY
-#define SN_DW5_TY 4
-#endif
-int sn_dw5_blocks(int h, int w) { return ((h + SN_DW5_TY - 1) / SN_DW5_TY) * ((w + 63) / 64); }
-#else
-#define SN_DBG_MASK 0
-#define SN_DBG_BUF(bit) ((unsigned long long*)nullptr)
-#endif
-
 int sn_lngate_blocks(int h, int w) { return (SN_K12_TH * 32 / 64) * ((h + SN_K12_TH - 1) / SN_K12_TH) * ((w + 31) / 32); }
 
 int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, const float* bias, const uint32_t* wdw,
                     void* g1, float* pool, int g1_blocked, void* stream) {
     sn_clear_error();
     if (!s || !s->x || (s->C != 64 && s->C != 80) || s->mode < 0 || s->mode > 2 || !wfrag || !bias || !wdw || !g1 ||
-        (s->mode != 0 && !hw) || (g1_blocked && s->C != 64) || g1_blocked < 0 || g1_blocked > 2) return SN_EINVAL;
+        (s->mode != 0 && !hw) || (g1_blocked && s->C != 64) || (g1_blocked != 0 && g1_blocked != 2)) return SN_EINVAL;
     UnitK2 u; u.x = (const bf16_t*)s->x; u.T = s->T; u.h = s->h; u.w = s->w; u.C = s->C; u.mode = s->mode; u.wrap = s->wrap;
     const XcdTiles G = sn_xcd_tiles((s->w + 31) / 32, (s->h + SN_K12_TH - 1) / SN_K12_TH, s->T);
     const dim3 grid = sn_xcd_grid(G);
     hipStream_t st = (hipStream_t)stream;
 #define SN_LAUNCH_K12(CC, HW_) hipLaunchKernelGGL((ln_gemm_gate_kernel<CC, HW_>), grid, dim3(SN_K12_NWV * 64), 0, st, u, G, (const bf16_t*)hw, \
-        (const uint4*)wfrag, bias, wdw, (bf16_t*)g1, pool, g1_blocked, SN_DBG_MASK, SN_DBG_BUF(256))
+        (const uint4*)wfrag, bias, wdw, (bf16_t*)g1, pool, g1_blocked)
     if (s->C == 64) { if (s->mode) SN_LAUNCH_K12(64, true); else SN_LAUNCH_K12(64, false); }
     else { if (s->mode) SN_LAUNCH_K12(80, true); else SN_LAUNCH_K12(80, false); }
 #undef SN_LAUNCH_K12
     return sn_check_launch();
 }
 
-#ifdef SN_EXPERIMENTAL
-int sn_dw5_gemm_gate(const void* g1, const float* ca_in, const uint32_t* w5, const void* wfrag, void* g2, float* pool,
-                     int T, int h, int w, int C, void* stream) {
-    sn_clear_error();
-    if (!g1 || !w5 || !wfrag || !g2 || C != 64) return SN_EINVAL;
-    const int ntiles = T * ((w + 63) / 64) * ((h + SN_DW5_TY - 1) / SN_DW5_TY);
-    const int nwg = ntiles < 512 ? ntiles : 512;            // 2 resident workgroups per CU x 256 CUs, persistent
-    hipLaunchKernelGGL(dw5_gemm_gate_kernel<SN_DW5_TY>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g1, ca_in, w5,
-                       (const uint4*)wfrag, (bf16_t*)g2, pool, T, h, w, g_sn_debug);
-    return sn_check_launch();
-}
-
-#endif  // SN_EXPERIMENTAL
 
 int sn_grp5_blocks(int h, int w) { return ((h + 3) / 4) * ((w + 31) / 32); }
 
@@ -834,17 +493,14 @@ int sn_grp5_gemm_gate(const void* g1, const float* ca_in, const void* wgrp, cons
     int dev = 0, ncu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1)
         return SN_ELAUNCH;
-#ifndef SN_GRP5_NH
-#define SN_GRP5_NH 2       /* measured on config 3: NH = 2 (one 10-wave workgroup per CU) 123.6 ms, NH = 1 (two 5-wave workgroups) 180.1 ms */
-#endif
-    constexpr int NH = SN_GRP5_NH;
+    constexpr int NH = 2;      /* measured on config 3: NH = 2 (one 10-wave workgroup per CU) 123.6 ms, NH = 1 (two 5-wave workgroups) 180.1 ms */
     if (hipFuncSetAttribute((const void*)grp5p_gemm_gate_kernel<80, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return SN_ELAUNCH;
     const int ntiles = T * ((h + 3) / 4) * ((w + 31) / 32);
     const int maxwg = (NH == 1 ? 2 : 1) * ncu, nwg = ntiles < maxwg ? ntiles : maxwg;            // persistent, all workgroups resident
     sn_clear_error();
     hipLaunchKernelGGL((grp5p_gemm_gate_kernel<80, NH>), nwg, dim3(64 * NH * 5), lds, (hipStream_t)stream, (const bf16_t*)g1, ca_in,
-                       (const uint4*)wgrp, (const uint4*)wfrag, (bf16_t*)g2, pool, T, h, w, SN_DBG_BUF(1024));
+                       (const uint4*)wgrp, (const uint4*)wfrag, (bf16_t*)g2, pool, T, h, w);
     return sn_check_launch();
 }
 

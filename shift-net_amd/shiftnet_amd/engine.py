@@ -53,9 +53,9 @@ class Plan:
     def _dev(self, t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
         return None if t is None else t.contiguous().to(self.device)
 
-    def add_conv(self, name: str, key: str, cins: Sequence[int], weight: Optional[torch.Tensor] = None) -> None:
-        w = self.sd[key + "weight"] if weight is None else weight
-        b = self.sd.get(key + "bias") if weight is None else None
+    def add_conv(self, name: str, key: str, cins: Sequence[int]) -> None:
+        w = self.sd[key + "weight"]
+        b = self.sd.get(key + "bias")
         cs_in = prep.ceil8(max(cins))
         p = prep.pack_conv(w, b, cins, cs_in)
         p["wfrag"] = self._dev(p["wfrag"])
@@ -91,30 +91,17 @@ class Plan:
         g = prep.pack_ln_gemm(sd[f"{pre}body.{i}.weight"], sd[pre + "norm.weight"], sd[pre + "norm.bias"], c); i += 1
         u["w_ln"], u["b_ln"] = self._dev(g["wfrag"]), self._dev(g["bias"])
         w3 = prep.pack_dw3_gate(sd[f"{pre}body.{i}.conv_2.weight"], c); i += 1
-        u["w_dw3"] = self._dev(w3)
-        u["w_dw3_d2"] = self._dev(prep.dot2_words(w3))          # experimental chains (v_dot2c operands)
         u["w_dw3_h2"] = self._dev(prep.pk_f16_words(w3))        # K12: packed-fp16 stencil, [9][C] words = positions (2k, 2k+1)
-        if c == 64:
-            u["w_toep3"] = self._dev(prep.pack_toeplitz_dw3_chunks(sd[f"{pre}body.{i - 1}.conv_2.weight"], c))   # K12m band records
         i += 1
         if V.denoise:
             self.add_ca(f"{pre}ca1", f"{pre}body.{i}."); i += 1
         if V.grouped_rep:
-            dense = prep.pack_grouped_rep(sd[f"{pre}body.{i}.conv_1.weight"], sd[f"{pre}body.{i}.conv_2.weight"])
-            self.add_conv(pre + "rep", "", [c], weight=dense)           # SN_GSTS_V=0 path only
-            u["w_dw5"] = self._dev(prep.identity_dw5(c))
             u["w_grp"] = self._dev(prep.pack_grouped_frag(sd[f"{pre}body.{i}.conv_1.weight"], sd[f"{pre}body.{i}.conv_2.weight"]))
         else:
             w5 = prep.pack_dw5(sd[f"{pre}body.{i}.conv_1.weight"], sd[f"{pre}body.{i}.conv_2.weight"])
-            u["w_dw5"] = self._dev(w5)
-            if c == 64:      # v1 path: g1 / r travel in chunk-block position order (prep.chunk_block_perm)
-                perm = torch.from_numpy(prep.chunk_block_perm(c))
-                u["w_dw5_d2"] = self._dev(prep.dot2_words(w5[:, perm]))
-                u["w_toep5"] = self._dev(prep.pack_toeplitz(w5, 5))       # v2 path: 5x5 on the matrix cores
+            u["w_toep5"] = self._dev(prep.pack_toeplitz(w5, 5))           # K3m: 5x5 on the matrix cores
         i += 1
         u["w_gate"] = self._dev(prep.pack_gate_gemm(sd[f"{pre}body.{i}.weight"], c))
-        if c == 64 and not V.grouped_rep:
-            u["w_gate_blk"] = self._dev(prep.pack_gate_gemm_blocked(sd[f"{pre}body.{i}.weight"], c))
         i += 1
         i += 1
         self.add_ca(f"{pre}ca2", f"{pre}body.{i}."); i += 1
@@ -194,11 +181,6 @@ class Engine:
         self.V = plan.V
         self.lib = L.load()
         self.dev = plan.device
-        # 1: two convs, CALayer scale + residual in conv2's epilogue (product path); 0: + a separate scale pass; 2: fused CAB with mid
-        # in LDS -- experimental library only, measured slower (csrc/sn_conv.hip: sn_cab_fused)
-        self.cab_v = int(os.environ.get("SN_CAB_V", "1"))
-        if self.cab_v >= 2 and not L.EXPERIMENTAL:
-            raise L.ShiftNetLibError("SN_CAB_V=2 (fused CAB) needs the experimental library: SN_EXPERIMENTAL=1")
         self.prof: Optional[list] = None      # bench.py attaches a list to collect (fn, label, meta, ev0, ev1)
         self._meta: Tuple = ()
         self.split = None                     # temporal_split.TemporalSplit: this engine holds a frame range of a longer window
@@ -234,8 +216,7 @@ class Engine:
 
     def conv(self, name: str, ins: Sequence[Act], *, stride: int = 1, pad: Optional[int] = None, prelu: Optional[float] = None,
              res: Optional[Act] = None, out_mode: int = 0, pool: bool = False, in_mode: int = 0, oscale: Optional[torch.Tensor] = None,
-             nchw_out: Optional[torch.Tensor] = None, nchw_sc: Optional[torch.Tensor] = None, res2: Optional[Act] = None,
-             sums_only: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+             nchw_out: Optional[torch.Tensor] = None, nchw_sc: Optional[torch.Tensor] = None, res2: Optional[Act] = None):
         p = self.P.convs[name]
         k, cout = int(p["k"]), int(p["cout"])
         T, hs, ws, cs_in = ins[0].dims
@@ -259,10 +240,6 @@ class Engine:
             assert nchw_out is not None and nchw_sc is not None
             d.out, d.sc, d.cs_out = nchw_out.data_ptr(), nchw_sc.data_ptr(), 8
             d.c_out, d.nchw_dtype = cout, _dtype_code(nchw_out.dtype)
-        elif sums_only is not None:     # pass A of the fused CAB: channel sums + border lines, the result itself is not stored
-            assert out_mode == 0 and pool
-            d.out, d.cs_out, d.c_out = None, prep.ceil8(cout), cout
-            d.border_rows, d.border_cols = sums_only[0].data_ptr(), sums_only[1].data_ptr()
         else:
             c_log = cout // 4 if out_mode == 1 else cout
             cs_out = prep.ceil8(c_log)
@@ -282,7 +259,7 @@ class Engine:
             nblk = self.lib.sn_conv_pool_blocks(C.byref(d))
             pool_buf = torch.empty((T, nblk, 16 * d.mt), dtype=torch.float32, device=self.dev)
             d.pool = pool_buf.data_ptr()
-        self._meta = ("conv", T, h_out, w_out, len(ins) * cs_in, int(d.cs_out), k, stride, in_mode, 9 if sums_only is not None else out_mode)
+        self._meta = ("conv", T, h_out, w_out, len(ins) * cs_in, int(d.cs_out), k, stride, in_mode, out_mode)
         self._call("sn_conv2d", f"sn_conv2d[{name}]", C.byref(d), self._stream())
         if pool:
             return out_act, pool_buf, h_out * w_out
@@ -297,71 +274,31 @@ class Engine:
         return ca
 
     def scale_residual(self, r: Act, x: Act, ca: torch.Tensor, extra: Optional[Act] = None) -> Act:
-        assert extra is None, "the bf16 CAB tail with a second residual goes through the conv epilogue (cab_v >= 1)"
-        T, h, w, cs = r.dims
-        o = self._new(T, h, w, cs)
-        self._meta = ("ew", T, h, w, cs)
-        self._call("sn_scale_residual", "sn_scale_residual", r.t.data_ptr(), x.t.data_ptr(), ca.data_ptr(), ca.shape[1], o.data_ptr(),
-                                           T, h * w, cs, self._stream())
-        return Act(o, r.c)
+        raise NotImplementedError("bf16 CABs apply the CALayer scale and the residual in conv2's epilogue (fused_cab_tail)")
 
     # ---- blocks (oracle/shiftnet_oracle.py has the same names) ----------------------------------------------
+    fused_cab_tail = True      # Engine32 (one kernel per reference module) runs conv, conv, pool, MLP, scale + residual instead
+
     def cab(self, pre: str, x: Act, extra: Optional[Act] = None) -> Act:
         """CAB: 3x3 -> PReLU -> 3x3 -> CALayer -> +x (gshift_deblur1.py:141-156).
 
         The CALayer scale is known BEFORE the second conv (its pooled input is linear in `mid`, sn_cab_ca), so scale and residual
-        are applied in conv2's epilogue.  cab_v 1 (product path): two sn_conv2d launches, 5 tensor passes.  cab_v 2 (experimental
-        library, storage widths 16..48): FUSED -- pass A = conv1 + PReLU as a sums-only launch (channel sums + the border lines of
-        mid; mid itself never reaches HBM), pass B = sn_cab_fused recomputes conv1 on the tile's ring, keeps mid in LDS and runs conv2
-        with the scale / residual epilogue: 3 tensor passes, parity green, but measured slower (latency-bound).
-        cab_v 0: two convs plus a separate scale pass (A/B only)."""
-        if self.cab_v >= 1:
+        (and the optional second residual `extra`) are applied in conv2's epilogue: two sn_conv2d launches, 5 tensor passes.
+        (A fused CAB with `mid` in LDS -- 3 passes -- was built and measured slower in round 2)"""
+        if self.fused_cab_tail:
             p = self.P.cas[pre + "CA"]
-            c1, c2 = self.P.convs[pre + "body.0"], self.P.convs[pre + "body.2"]
             T, h, w, cs = x.dims
             slope = self.P.scalar(pre + "body.1.weight")
-            fused = self.cab_v >= 2 and cs in (16, 24, 40, 48) and c1["bias"] is None and c2["bias"] is None and h >= 2 and w >= 2
             scratch = torch.empty((self.lib.sn_cab_ca_scratch_floats(T),), dtype=torch.float32, device=self.dev)
-            if fused:
-                brow = torch.empty((T, 2, w, cs), dtype=torch.bfloat16, device=self.dev)
-                bcol = torch.empty((T, 2, h, cs), dtype=torch.bfloat16, device=self.dev)
-                _, pool, _ = self.conv(pre + "body.0", [x], prelu=slope, pool=True, sums_only=(brow, bcol))
-                _, nblk, cpad = pool.shape
-                ca = torch.empty((T, cpad), dtype=torch.float32, device=self.dev)
-                self._call("sn_cab_ca", f"sn_cab_ca[{pre}]", pool.data_ptr(), nblk, cpad, None, cs, p["c"], p["cr"], h, w,
-                           p["w2"].data_ptr(), p["wa"].data_ptr(), p["wb"].data_ptr(), scratch.data_ptr(), ca.data_ptr(), T, self._stream(),
-                           brow.data_ptr(), bcol.data_ptr())
-                return self.cab_fused(pre, x, slope, ca, extra)
             mid, pool, _ = self.conv(pre + "body.0", [x], prelu=slope, pool=True)
             _, nblk, cpad = pool.shape
             ca = torch.empty((T, cpad), dtype=torch.float32, device=self.dev)
             self._call("sn_cab_ca", f"sn_cab_ca[{pre}]", pool.data_ptr(), nblk, cpad, mid.t.data_ptr(), cs, p["c"], p["cr"], h, w,
-                       p["w2"].data_ptr(), p["wa"].data_ptr(), p["wb"].data_ptr(), scratch.data_ptr(), ca.data_ptr(), T, self._stream(), None, None)
+                       p["w2"].data_ptr(), p["wa"].data_ptr(), p["wb"].data_ptr(), scratch.data_ptr(), ca.data_ptr(), T, self._stream())
             return self.conv(pre + "body.2", [mid], res=x, oscale=ca, res2=extra)
         r = self.conv(pre + "body.0", [x], prelu=self.P.scalar(pre + "body.1.weight"))
         r, pool, npix = self.conv(pre + "body.2", [r], pool=True)
         return self.scale_residual(r, x, self.ca_mlp(pre + "CA", pool, npix), extra)
-
-    def cab_fused(self, pre: str, x: Act, slope: float, ca: torch.Tensor, extra: Optional[Act]) -> Act:
-        """Pass B of the fused CAB (sn_cab_fused)."""
-        c1, c2 = self.P.convs[pre + "body.0"], self.P.convs[pre + "body.2"]
-        T, h, w, cs = x.dims
-        assert c1["mt"] == c2["mt"] and c1["ks"] == c2["ks"] and c1["cs_in"] == cs
-        o = self._new(T, h, w, cs)
-        d = L.ConvDesc()
-        d.inp[0] = x.t.data_ptr()
-        d.n_in, d.cs_in, d.T, d.h_in, d.w_in, d.in_mode = 1, cs, T, h, w, 0
-        d.k, d.stride, d.pad, d.h_out, d.w_out = 3, 1, 1, h, w
-        d.wfrag, d.mt, d.ks = c1["wfrag"].data_ptr(), int(c1["mt"]), int(c1["ks"])
-        d.act, d.prelu = 1, slope
-        d.out, d.cs_out, d.c_out, d.out_mode = o.data_ptr(), cs, int(c2["cout"]), 0
-        d.oscale, d.oscale_stride = ca.data_ptr(), ca.shape[1]
-        if extra is not None:
-            assert extra.dims == x.dims
-            d.res2 = extra.t.data_ptr()
-        self._meta = ("cab", T, h, w, cs)
-        self._call("sn_cab_fused", f"sn_cab_fused[{pre}]", C.byref(d), c2["wfrag"].data_ptr(), self._stream())
-        return Act(o, x.c)
 
     def _wrap_flag(self, mode: int, circular: bool) -> int:
         """sn_unit_src.wrap: 0 keep the boundary frame, 1 circular, 2 neighbour frame in the halo slot (temporal split)."""

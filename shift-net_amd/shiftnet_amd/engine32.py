@@ -39,9 +39,8 @@ class Plan32(Plan):
         self.offs = prep.shift_offsets_i8(shift_table(V.c1)).to(device)
         self._build()
 
-    def add_conv(self, name: str, key: str, cins: Sequence[int], weight: Optional[torch.Tensor] = None) -> None:
-        if weight is None:                       # (the packed block-diagonal copy of the grouped RepConv is a bf16-path artefact)
-            self.convs[name] = {"key": key, "cins": list(cins)}
+    def add_conv(self, name: str, key: str, cins: Sequence[int]) -> None:
+        self.convs[name] = {"key": key, "cins": list(cins)}
 
     def add_cab(self, pre: str, c: int) -> None:
         self.add_conv(pre + "body.0", pre + "body.0.", [c])
@@ -68,9 +67,9 @@ class Plan32(Plan):
 class Engine32(Engine):
     def __init__(self, plan: Plan32) -> None:
         super().__init__(plan, torch.float32)
-        self.cab_v = 0
 
     act_dtype = torch.float32
+    fused_cab_tail = False
 
     # ---- leaf operators ------------------------------------------------------------------------------------
     def _conv32(self, wkey: str, bkey: Optional[str], ins: Sequence[torch.Tensor], cins: Sequence[int], *, k: int, stride: int = 1,
@@ -116,8 +115,7 @@ class Engine32(Engine):
 
     def conv(self, name: str, ins: Sequence[Act], *, stride: int = 1, pad: Optional[int] = None, prelu: Optional[float] = None,
              res: Optional[Act] = None, out_mode: int = 0, pool: bool = False, in_mode: int = 0, oscale: Optional[torch.Tensor] = None,
-             nchw_out: Optional[torch.Tensor] = None, nchw_sc: Optional[torch.Tensor] = None, res2: Optional[Act] = None,
-             sums_only=None):
+             nchw_out: Optional[torch.Tensor] = None, nchw_sc: Optional[torch.Tensor] = None, res2: Optional[Act] = None):
         p = self.P.convs[name]
         key = p["key"]
         k = int(self.P.sd[key + "weight"].shape[-1])

@@ -15,21 +15,15 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libshiftnet_hip.so")
 
 SN_F32, SN_F16, SN_BF16 = 0, 1, 2
 
-EXPERIMENTAL = os.environ.get("SN_EXPERIMENTAL", "0") == "1"      # load the -DSN_EXPERIMENTAL build (tools/, A/B tests only)
-if EXPERIMENTAL:
-    LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libshiftnet_hip_exp.so")
+ABI_VERSION = 3      # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so from before a struct / signature change fails the check in load()
 
 SYMBOLS = [          # include/shiftnet_hip.h, production ABI
     "sn_abi_version", "sn_selftest_mfma", "sn_ingest", "sn_conv2d", "sn_conv_pool_blocks", "sn_ca_mlp",
-    "sn_scale_residual", "sn_cab_ca", "sn_cab_ca_scratch_floats", "sn_planar_pitch", "sn_nhwc_to_planar", "sn_dw5m_blocks",
+    "sn_cab_ca", "sn_cab_ca_scratch_floats", "sn_planar_pitch", "sn_nhwc_to_planar", "sn_dw5m_blocks",
     "sn_dw5m_gemm_gate", "sn_gsts_gather", "sn_temporal_roll", "sn_gsts_shiftconv", "sn_scale_gemm_res",
     "sn_ingest_u8", "sn_egress_blocks", "sn_egress_u8", "sn_ssim_blocks", "sn_ssim_u8",
     "sn32_conv2d", "sn32_gsts_gather", "sn32_layernorm", "sn32_gate", "sn32_chan_sum", "sn32_scale_residual", "sn32_ingest",
     "sn_ln_gemm_gate", "sn_lngate_blocks", "sn_grp5_gemm_gate", "sn_grp5_blocks",
-]
-EXPERIMENTAL_SYMBOLS = [     # include/shiftnet_hip_experimental.h, only in libshiftnet_hip_exp.so
-    "sn_ln_gemm", "sn_dw_gate", "sn_dwgate_blocks", "sn_dw_gemm_gate", "sn_dwgemm_blocks", "sn_dw5_gemm_gate", "sn_dw5_blocks",
-    "sn_debug_set", "sn_debug_get", "sn_debug_buf_set", "sn_debug_buf_get", "sn_lngatem_blocks", "sn_ln_gemm_gate_m", "sn_cab_fused",
 ]
 
 
@@ -42,7 +36,6 @@ class ConvDesc(C.Structure):
         ("act", C.c_int), ("prelu", C.c_float), ("res", C.c_void_p), ("out", C.c_void_p),
         ("cs_out", C.c_int), ("out_mode", C.c_int), ("c_out", C.c_int), ("nchw_dtype", C.c_int),
         ("sc", C.c_void_p), ("pool", C.c_void_p), ("oscale", C.c_void_p), ("oscale_stride", C.c_int), ("res2", C.c_void_p),
-        ("border_rows", C.c_void_p), ("border_cols", C.c_void_p),
     ]
 
 
@@ -83,7 +76,7 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: build it with `python shift-net_amd/build.py` (hipcc, gfx950). "
             "There is no CPU fallback for the Shift-Net HIP path.")
     lib = C.CDLL(LIB_PATH)
-    missing = [s for s in SYMBOLS + (EXPERIMENTAL_SYMBOLS if EXPERIMENTAL else []) if not hasattr(lib, s)]
+    missing = [s for s in SYMBOLS if not hasattr(lib, s)]
     if missing:
         raise ShiftNetLibError(f"{LIB_PATH} lacks symbols {missing}")
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
@@ -97,9 +90,8 @@ def load() -> C.CDLL:
     lib.sn_nhwc_to_planar.argtypes = [vp, vp, ci, ci, ci, ci, vp]
     lib.sn_dw5m_blocks.argtypes = [ci, ci]
     lib.sn_dw5m_gemm_gate.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
-    lib.sn_cab_ca.argtypes = [vp, ci, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp]
+    lib.sn_cab_ca.argtypes = [vp, ci, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp]
     lib.sn_cab_ca_scratch_floats.argtypes = [ci]
-    lib.sn_scale_residual.argtypes = [vp, vp, vp, ci, vp, ci, ci, ci, vp]
     lib.sn_gsts_gather.argtypes = [C.POINTER(UnitSrc), vp, vp, vp]
     lib.sn_temporal_roll.argtypes = [C.POINTER(UnitSrc), vp, vp]
     lib.sn_gsts_shiftconv.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp]
@@ -123,26 +115,9 @@ def load() -> C.CDLL:
     lib.sn32_ingest.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, vp]
     for s in SYMBOLS:
         getattr(lib, s).restype = ci
-    if EXPERIMENTAL:
-        lib.sn_cab_fused.argtypes = [C.POINTER(ConvDesc), vp, vp]
-        lib.sn_lngatem_blocks.argtypes = [ci, ci]
-        lib.sn_ln_gemm_gate_m.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp, vp, vp]
-        lib.sn_ln_gemm.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp]
-        lib.sn_dw_gate.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
-        lib.sn_dwgate_blocks.argtypes = [ci, ci]
-        lib.sn_dw_gemm_gate.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
-        lib.sn_dwgemm_blocks.argtypes = [ci, ci]
-        lib.sn_dw5_blocks.argtypes = [ci, ci]
-        lib.sn_debug_set.argtypes = [ci]
-        lib.sn_debug_get.argtypes = []
-        lib.sn_debug_buf_set.argtypes = [vp]
-        lib.sn_debug_buf_get.argtypes = []
-        lib.sn_dw5_gemm_gate.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
-        for s in EXPERIMENTAL_SYMBOLS:
-            getattr(lib, s).restype = ci
-        lib.sn_debug_buf_get.restype = vp
-    if lib.sn_abi_version() != 1:
-        raise ShiftNetLibError("ABI version mismatch between shiftnet_amd/lib.py and libshiftnet_hip.so")
+    if lib.sn_abi_version() != ABI_VERSION:
+        raise ShiftNetLibError(f"ABI version mismatch: {LIB_PATH} reports {lib.sn_abi_version()}, shiftnet_amd/lib.py expects {ABI_VERSION} "
+                               "(stale build: run `python shift-net_amd/build.py`)")
     _lib = lib
     return lib
 

@@ -124,25 +124,6 @@ def pack_dw5(w5: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(a.reshape(a.shape[0], 25).T))
 
 
-def pack_grouped_rep(w5: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
-    """grouped RepConv ("+", groups = C/8): fold 3x3 + identity, expand to a block-diagonal dense [C, C, 5, 5]."""
-    a = w5.detach().float().cpu().numpy().copy()          # [C, 8, 5, 5]
-    c = a.shape[0]
-    a[:, :, 1:4, 1:4] += w3.detach().float().cpu().numpy()
-    dense = np.zeros((c, c, 5, 5), np.float32)
-    for o in range(c):
-        g0 = (o // 8) * 8
-        dense[o, g0:g0 + 8] = a[o]
-        dense[o, o, 2, 2] += 1.0
-    return torch.from_numpy(dense)
-
-
-def identity_dw5(c: int) -> torch.Tensor:
-    w = np.zeros((25, c), np.float32)
-    w[12] = 1.0
-    return torch.from_numpy(w)
-
-
 def pack_gate_gemm(w2: torch.Tensor, c: int) -> torch.Tensor:
     """body 1x1 C -> 2C before SimpleGate2; rows gate-paired, K natural."""
     w = w2.detach().float().cpu().numpy().reshape(2 * c, c)
@@ -170,37 +151,11 @@ def shift_offsets_i8(table: List[Tuple[int, int]]) -> torch.Tensor:
     return torch.tensor(table, dtype=torch.int8).reshape(-1, 2).contiguous()
 
 
-def dot2_words(w: torch.Tensor) -> torch.Tensor:
-    """fp32 [..., N] -> int32 words for v_dot2c_f32_bf16: bf16(w[..., j]) in half (j & 1) of word j, other half zero."""
-    bits = w.to(torch.bfloat16).view(torch.int16).to(torch.int32) & 0xFFFF
-    n = w.shape[-1]
-    shift = (torch.arange(n) & 1) * 16
-    return (bits << shift).to(torch.int32).contiguous()
-
-
 def pk_f16_words(w: torch.Tensor) -> torch.Tensor:
     """fp32 [..., N] (N even) -> int32 [..., N/2] words for v_pk_fma_f16: fp16(w[..., 2k]) in the low half, fp16(w[..., 2k+1]) in the
     high half of word k (round to nearest)."""
     h = w.to(torch.float16).contiguous().view(torch.int16).to(torch.int32) & 0xFFFF
     return (h[..., 0::2] | (h[..., 1::2] << 16)).to(torch.int32).contiguous()
-
-
-def chunk_block_perm(c: int = 64) -> np.ndarray:
-    """position -> channel of the chunk-blocked g1 / r layout used between sn_ln_gemm_gate and sn_dw5_gemm_gate (C = 64):
-    position pos = q*16 + gs*4 + r (block q written by chunk q of K12)  <->  channel gs*16 + q*4 + r."""
-    assert c == 64
-    pos = np.arange(c)
-    q, gs, r = pos // 16, (pos % 16) // 4, pos % 4
-    return gs * 16 + q * 4 + r
-
-
-def pack_gate_gemm_blocked(w2: torch.Tensor, c: int) -> torch.Tensor:
-    """pack_gate_gemm with the K axis in chunk-block position order."""
-    w = w2.detach().float().cpu().numpy().reshape(2 * c, c)[:, chunk_block_perm(c)]
-    ks = (c + 31) // 32
-    wp = np.zeros((16 * (c // 8), 32 * ks), np.float32)
-    wp[rows_gate(c), :c] = w
-    return pack_frag(wp)
 
 
 def pack_grouped_frag(w5: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
@@ -240,21 +195,3 @@ def pack_toeplitz(wk: torch.Tensor, k: int) -> torch.Tensor:
     tab[:, :, 0, 7:7 + k] = w
     tab[:, :, 1, 6:6 + k] = w
     return torch.from_numpy(tab).to(torch.bfloat16)
-
-
-def pack_toeplitz_dw3_chunks(w: torch.Tensor, c: int) -> torch.Tensor:
-    """RepConv2 depthwise 3x3 [2C,1,3,3] (+identity) -> band records for sn_ln_gemm_gate_m: bf16 [C/16][32][3][2][20].
-
-    Chunk q, plane = half*16 + n holds channel half*C + (n>>2)*(C/4) + 4q + (n&3): the channel that row n of the gate-paired
-    16-row weight blocks 2q (half 0) / 2q+1 (half 1) produces (rows_gate)."""
-    wn = w.detach().float().cpu().reshape(2 * c, 9).clone()
-    wn[:, 4] += 1.0
-    rec = pack_toeplitz(wn.T.contiguous(), 3)                      # [2C][3][2][20]
-    nchk = c // 16
-    out = torch.zeros((nchk, 32, 3, 2, 20), dtype=torch.bfloat16)
-    for q in range(nchk):
-        for half in range(2):
-            for n in range(16):
-                ch = half * c + (n >> 2) * (c // 4) + 4 * q + (n & 3)
-                out[q, half * 16 + n] = rec[ch]
-    return out

@@ -211,24 +211,17 @@ def test_conv_epilogues(engines):
 @pytest.mark.parametrize("hw", [(20, 44), (13, 70), (2, 3)])
 def test_cab(name, pre, c, hw, engines):
     """CAB (two convs, closed-form CALayer, scale / residual epilogue) incl. ragged tiles, a map smaller than one tile and the second
-    residual of the last orb / rorb.  With the experimental library loaded (tests/test_gpu_experimental.py) the fused path
-    (pass A sums + sn_cab_fused, widths 14..48) is checked as well and must agree with the oracle to the same bound."""
-    from shiftnet_amd import lib as L
+    residual of the last orb / rorb."""
     eng, sd = engines(name)
     x = bf(torch.from_numpy(synth.unit_noise((3, c, hw[0], hw[1]), seed=71)))
     e = bf(torch.from_numpy(synth.unit_noise((3, c, hw[0], hw[1]), seed=72)))
     ref = O.cab(sd, pre, x)
-    for v in ((1, 2) if L.EXPERIMENTAL else (1,)):
-        eng.cab_v = v
-        try:
-            out = eng.cab(pre, act(to_dev(x), c))
-            check(f"cab_v{v}_{name}_{pre}_{hw[0]}x{hw[1]}", to_cpu(out.t, c), ref, 8e-3)
-            if out.t.shape[-1] > c:
-                assert out.t[..., c:].float().abs().max().item() == 0.0
-            out2 = eng.cab(pre, act(to_dev(x), c), act(to_dev(e), c))
-            check(f"cab_v{v}_extra_{name}_{pre}_{hw[0]}x{hw[1]}", to_cpu(out2.t, c), ref + e, 8e-3)
-        finally:
-            eng.cab_v = 1
+    out = eng.cab(pre, act(to_dev(x), c))
+    check(f"cab_{name}_{pre}_{hw[0]}x{hw[1]}", to_cpu(out.t, c), ref, 8e-3)
+    if out.t.shape[-1] > c:
+        assert out.t[..., c:].float().abs().max().item() == 0.0
+    out2 = eng.cab(pre, act(to_dev(x), c), act(to_dev(e), c))
+    check(f"cab_extra_{name}_{pre}_{hw[0]}x{hw[1]}", to_cpu(out2.t, c), ref + e, 8e-3)
 
 
 @pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_denoise2", "gshift_deblur1", "gshift_denoise1"])

@@ -25,17 +25,19 @@ def test_library_exports_every_declared_symbol():
     assert declared == sorted(L.SYMBOLS), (declared, sorted(L.SYMBOLS))
     for s in declared:
         assert hasattr(lib, s)
-    assert lib.sn_abi_version() == 1
-    # the experimental header's symbols live ONLY in the -DSN_EXPERIMENTAL build; the production library must not export them
-    out_exp = mod.build(experimental=True)
-    exp_hdr = open(os.path.join(ROOT, "include", "shiftnet_hip_experimental.h")).read()
-    exp_decl = sorted(set(re.findall(r"^(?:int|void\*) (sn\d*_\w+)\(", exp_hdr, flags=re.M)))
-    assert exp_decl == sorted(L.EXPERIMENTAL_SYMBOLS)
-    libx = ctypes.CDLL(out_exp)
-    for s in exp_decl:
-        assert hasattr(libx, s) and not hasattr(lib, s), s
-    for s in declared:
-        assert hasattr(libx, s), s
+    assert lib.sn_abi_version() == L.ABI_VERSION
+    m = re.search(r"#define SN_ABI_VERSION (\d+)", header)
+    assert m and int(m.group(1)) == L.ABI_VERSION          # header, library and binding agree (a stale .so fails load())
+    # the ctypes mirrors of the ABI structs have the size the C compiler gives the header's structs
+    import subprocess, tempfile
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "sz.c")
+        open(src, "w").write('#include <stdio.h>\n#include "shiftnet_hip.h"\nint main(void){printf("%zu %zu %zu\\n", sizeof(sn_conv_desc), '
+                             'sizeof(sn32_conv_desc), sizeof(sn_unit_src));return 0;}\n')
+        exe = os.path.join(td, "sz")
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
+        sizes = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    assert sizes == [ctypes.sizeof(L.ConvDesc), ctypes.sizeof(L.Conv32Desc), ctypes.sizeof(L.UnitSrc)], sizes
     # argument validation is host side and must not need a GPU
     assert lib.sn_conv2d(None, None) == -22
     d = L.ConvDesc(); d.stride, d.mt, d.n_in, d.cs_in, d.h_out, d.w_out = 1, 1, 1, 16, 720, 1280

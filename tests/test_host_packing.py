@@ -57,11 +57,13 @@ def test_unit_emulation_matches_oracle(name):
                 wa, wb = sd[f"{q}body.3.conv_du.0.weight"].flatten(1), sd[f"{q}body.3.conv_du.2.weight"].flatten(1)
                 ca1 = torch.sigmoid(torch.relu(mean @ wa.T) @ wb.T).numpy()
                 i = 4
-            if V.grouped_rep:
-                dense = prep.pack_grouped_rep(sd[f"{q}body.{i}.conv_1.weight"], sd[f"{q}body.{i}.conv_2.weight"])
-                pc = prep.pack_conv(dense, None, [C], C)
-                g1 = emu.conv2d([g1 if ca1 is None else g1 * ca1[:, None, None, :]], pc, bias=False)[..., :C]
-                w5 = prep.identity_dw5(C).numpy(); ca1 = None
+            if V.grouped_rep:     # the grouped RepConv itself (pack_grouped_frag) is checked in test_grouped_frag_table; here: plain conv
+                F = torch.nn.functional
+                gin = torch.from_numpy(g1 if ca1 is None else g1 * ca1[:, None, None, :]).permute(0, 3, 1, 2)
+                rr = (F.conv2d(gin, sd[f"{q}body.{i}.conv_1.weight"], padding=2, groups=C // 8)
+                      + F.conv2d(gin, sd[f"{q}body.{i}.conv_2.weight"], padding=1, groups=C // 8) + gin)
+                g1 = rr.permute(0, 2, 3, 1).contiguous().numpy()
+                w5 = np.zeros((25, C), np.float32); w5[12] = 1.0; ca1 = None
             else:
                 w5 = prep.pack_dw5(sd[f"{q}body.{i}.conv_1.weight"], sd[f"{q}body.{i}.conv_2.weight"]).numpy()
             g2, sums = emu.dw_gemm_gate(g1, w5, prep.pack_gate_gemm(sd[f"{q}body.{i + 1}.weight"], C), ca1)
@@ -106,9 +108,9 @@ def test_conv_emulation_matches_oracle(case):
         assert np.abs(out[..., w.shape[0]:]).max() == 0.0       # pad channels stay zero
 
 
-def test_grouped_frag_and_chunk_block_tables():
-    """pack_grouped_frag (block-diagonal MFMA layout of the '+' RepConv) and the chunk-block permutation of the
-    depthwise path reproduce the oracle's RepConv / 1x1 when pushed through the kernels' documented slot conventions."""
+def test_grouped_frag_table():
+    """pack_grouped_frag (block-diagonal MFMA layout of the '+' RepConv) reproduces the oracle's RepConv when pushed through the
+    kernel's documented slot conventions."""
     F = torch.nn.functional
     sd = synth_state_dict("gshift_deblur1")
     pre = "stage1.decoder_level1.encoder_level1.0.body.3."
@@ -138,17 +140,6 @@ def test_grouped_frag_and_chunk_block_tables():
                         out[oy, ox0 + p, 16 * mt + g * 4: 16 * mt + g * 4 + 4] = regs[lane]
     got = torch.from_numpy(out).permute(2, 0, 1)[None]
     assert (got - ref).abs().max().item() < 0.03 * max(1.0, ref.abs().max().item())
-    # chunk-block permutation is a bijection and matches the K12 store rule position q*16 + gs*4 + r <-> channel gs*16 + q*4 + r
-    perm = prep.chunk_block_perm(64)
-    assert sorted(perm.tolist()) == list(range(64))
-    assert perm[1 * 16 + 2 * 4 + 3] == 2 * 16 + 1 * 4 + 3
-    w2 = sd["stage1.decoder_level1.encoder_level1.0.body.4.weight"][:128, :64] if False else torch.randn(128, 64, 1, 1)
-    a = emu.frag_to_np(prep.pack_gate_gemm(w2, 64)); b = emu.frag_to_np(prep.pack_gate_gemm_blocked(w2, 64))
-    A = a.reshape(8, 2, 4, 16, 8).transpose(0, 3, 1, 2, 4).reshape(128, 64)        # rows x K (natural)
-    Bm = b.reshape(8, 2, 4, 16, 8).transpose(0, 3, 1, 2, 4).reshape(128, 64)       # rows x K (block positions)
-    assert np.array_equal(Bm, A[:, perm])
-    words = prep.dot2_words(torch.tensor([[1.0, -2.0, 0.5, 3.0]]))
-    assert [x & 0xFFFFFFFF for x in words[0].tolist()] == [0x3F80, 0xC0000000, 0x3F00, 0x40400000]
 
 
 @pytest.mark.parametrize("k", [3, 5])
@@ -178,28 +169,6 @@ def test_toeplitz_band_table(k):
             ref = np.array([sum(w[ch, dy, dx] * x[ch, oy + dy, 8 + m + dx - k // 2] for dy in range(k) for dx in range(k))
                             for m in range(16)])
             np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
-
-
-def test_toeplitz_dw3_chunk_records():
-    """prep.pack_toeplitz_dw3_chunks: plane (half, n) of chunk q must carry the band of the channel that row n of the
-    gate-paired weight blocks 2q / 2q+1 produces (prep.rows_gate), with the RepConv2 identity folded into the centre tap."""
-    c = 64
-    rng = np.random.default_rng(11)
-    w = torch.from_numpy(rng.standard_normal((2 * c, 1, 3, 3)).astype(np.float32))
-    rec = prep.pack_toeplitz_dw3_chunks(w, c).float().numpy()          # [4][32][3][2][20]
-    assert rec.shape == (c // 16, 32, 3, 2, 20)
-    rows = prep.rows_gate(c)                                           # channel o -> row index in the 16*MT padded matrix
-    wn = w.bfloat16().float().numpy().reshape(2 * c, 3, 3).copy()
-    for o in range(2 * c):
-        row = rows[o]
-        mt, n = row // 16, row % 16
-        q, half = mt // 2, mt % 2
-        band = rec[q, half * 16 + n]                                   # [3][2][20]
-        ref = wn[o].copy()
-        ref[1, 1] = (w[o, 0, 1, 1] + 1.0).bfloat16().float().item()
-        np.testing.assert_array_equal(band[:, 0, 7:10], ref)           # copy 0: taps at elements 7..9
-        np.testing.assert_array_equal(band[:, 1, 6:9], ref)            # copy 1: shifted left by one
-        assert np.count_nonzero(band[:, 0, :7]) == 0 and np.count_nonzero(band[:, 0, 10:]) == 0
 
 
 def test_matrix_core_stencil_emulation_matches_valu_path():
@@ -243,9 +212,8 @@ def test_cab_pooled_mean_closed_form():
     np.testing.assert_allclose(got / (h * w), ref, rtol=1e-4, atol=1e-5)
 
 
-def test_packed_fp16_and_dot2_weight_words():
-    """Operand words of the packed stencils: pk_f16_words (K12: v_pk_fma_f16, word k = fp16 of elements 2k | 2k+1 << 16, round to
-    nearest) and dot2_words (K0: v_dot2c_f32_bf16, element j in half j & 1 of its own word, other half zero)."""
+def test_packed_fp16_weight_words():
+    """Operand words of the packed stencil: pk_f16_words (K12: v_pk_fma_f16, word k = fp16 of elements 2k | 2k+1 << 16, round to nearest)."""
     import numpy as np
     import torch
     from shiftnet_amd import prep
@@ -260,6 +228,3 @@ def test_packed_fp16_and_dot2_weight_words():
     ref = w.to(torch.float16).numpy()
     assert np.array_equal(lo, ref[:, 0::2]) and np.array_equal(hi, ref[:, 1::2])
     assert lo[0, 0] == np.float16(1.0) and hi[0, 0] == np.float16(-65504.0)
-    d2 = prep.dot2_words(w).numpy().astype(np.int64) & 0xFFFFFFFF
-    bf = (w.to(torch.bfloat16).view(torch.int16).to(torch.int32) & 0xFFFF).numpy()
-    assert np.array_equal(d2[:, 0::2], bf[:, 0::2]) and np.array_equal(d2[:, 1::2], bf[:, 1::2].astype(np.int64) << 16)

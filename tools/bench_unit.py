@@ -17,21 +17,13 @@ def main():
     ap.add_argument("--h", type=int, default=360)
     ap.add_argument("--w", type=int, default=640)
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--gsts-v", type=int, default=2)
-    ap.add_argument("--dbg", type=int, default=0)
     args = ap.parse_args()
-    if args.gsts_v != 2 or args.dbg:
-        os.environ["SN_EXPERIMENTAL"] = "1"      # superseded chains / ablation switches live in the -DSN_EXPERIMENTAL library
     from shiftnet_amd.engine import Act, Engine, Plan
-    from shiftnet_amd.engine_experimental import ExperimentalEngine
     from shiftnet_amd.spec import VARIANTS
     from shiftnet_amd.weights import synth_state_dict
     dev = torch.device("cuda:0")
     V = VARIANTS[args.variant]
-    eng = (ExperimentalEngine if os.environ.get("SN_EXPERIMENTAL") == "1" else Engine)(Plan(V, synth_state_dict(args.variant), dev))
-    if os.environ.get("SN_EXPERIMENTAL") == "1":
-        eng.gsts_v = args.gsts_v
-        eng.lib.sn_debug_set(args.dbg)
+    eng = Engine(Plan(V, synth_state_dict(args.variant), dev))
     x = Act(torch.randn(args.t, args.h, args.w, V.c1, device=dev).to(torch.bfloat16), V.c1)
     pre = "stage1.decoder_level1."
     for _ in range(2):
