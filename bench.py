@@ -25,7 +25,7 @@ for p in (ROOT, os.path.join(ROOT, "shift-net_amd")):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PMC_FILE = "r02_pmc_hbm_traffic_bench_window.json"    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very command (tools/make_profiles_r02.sh)
+PMC_FILE = "r03_pmc_hbm_traffic_bench_window.json"    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command with --no-parity --no-cpu-baseline (tools/make_profiles_r03.sh)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 VARIANT = "gshift_deblur2"
 H, W, ONE_LEN = 720, 1280, 16
@@ -44,6 +44,8 @@ CONFIGS = {
     4: dict(variant="gshift_denoise1", height=480, width=852, one_len=32, dtype="bf16", quadrants=True),
     # config 5's per-GPU window: 1920x1080, 96 restored frames over 8 GPUs = one_len 12 each (weak scaling with --gpus N)
     5: dict(variant="gshift_deblur1", height=1080, width=1920, one_len=12, dtype="bf16", quadrants=False),
+    # north_star's scaling workload: Shift-Net+ on 1080p windows of one_len 16, one per GPU, at --gpus 1 / 2 / 4 / 8
+    6: dict(variant="gshift_deblur1", height=1080, width=1920, one_len=16, dtype="bf16", quadrants=False),
 }
 DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
 
@@ -58,22 +60,13 @@ def kernel_alg_bytes(fn, meta):
     if meta and meta[0] == "naf":
         _, T, h, w, c, mode = meta
         px = T * h * w * 2
-        return {"sn_gsts_shiftconv": px * c, "sn_ln_gemm": px * (3.5 * c if mode else 3 * c), "sn_dw_gate": px * 3 * c,
-                "sn_dw_gemm_gate": px * 2 * c, "sn_scale_gemm_res": px * 3 * c,
-                "sn_ln_gemm_gate": px * (2.5 * c if mode else 2 * c), "sn_ln_gemm_gate_m": px * (2.5 * c if mode else 2 * c),
-                "sn_dw5_gemm_gate": px * 2 * c, "sn_dw5m_gemm_gate": px * 2 * c, "sn_grp5_gemm_gate": px * 2 * c}.get(fn, 0)
+        return {"sn_gsts_shiftconv": px * c, "sn_scale_gemm_res": px * 3 * c, "sn_ln_gemm_gate": px * (2.5 * c if mode else 2 * c),
+                "sn_dw5m_gemm_gate": px * 2 * c, "sn_grp5_gemm_gate": px * 2 * c,
+                "sn_cab_phase1": px * (2.5 * c if mode else 2 * c)}.get(fn, 0)       # phase 1: read x (+ hw), write g2
     if meta and meta[0] == "conv":
         _, T, ho, wo, cin, cs_out, k, stride, in_mode, out_mode = meta
         pin = T * ho * wo * stride * stride / (4 if in_mode == 1 else 1)
-        if out_mode == 9:                           # sums-only launch (pass A of the fused CAB): reads x, writes nothing
-            return 2 * pin * cin
         return 2 * (pin * cin + T * ho * wo * cs_out)
-    if meta and meta[0] == "cab":                   # sn_cab_fused: read x, write out
-        _, T, h, w, cs = meta
-        return 2 * 2 * T * h * w * cs
-    if meta and meta[0] == "ew":
-        _, T, h, w, cs = meta
-        return 2 * 3 * T * h * w * cs
     return 0
 
 
@@ -148,6 +141,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the small parity sample (rocprofv3 / PMC runs: only full windows in the trace)")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
@@ -241,9 +235,19 @@ def main():
         hh, ww, quads = h, w, [(0, h, 0, w)]
     sigma_map = torch.full((1, L + 4, 1, hh, ww), 30.0 / 255.0, dtype=dt, device=dev) if denoise else None
 
-    def step(local_only=False):
+    gather_ms = []          # per step: host-visible time of the halo all-gather (N > 1), measured with events on the launch stream
+
+    def step(local_only=False, timed=False):
         # local_only: rank 0's extra per-kernel profiling step must not enter a collective the other ranks are not in
-        win = fr if local_only else assemble_window(own, first_edge, last_edge, rank, world)
+        if local_only or world == 1:
+            win = fr if local_only else assemble_window(own, first_edge, last_edge, rank, world)
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            win = assemble_window(own, first_edge, last_edge, rank, world)
+            e1.record()
+            if timed:
+                gather_ms.append((e0, e1))
         outs = []
         for a, b, c, d in quads:
             xq = win if len(quads) == 1 else win[:, :, a:b, c:d].contiguous()
@@ -263,15 +267,23 @@ def main():
         log("warm-up done, timing")
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = step()
+            out = step(timed=True)
+        torch.cuda.synchronize()
+        own_elapsed = time.perf_counter() - t0          # this rank alone, before it waits for the others
         barrier()
         elapsed = time.perf_counter() - t0
     for o in (out if isinstance(out, list) else [out]):
         assert o.shape == (L, 3, hh, ww) and torch.isfinite(o.float()).all()
+    per_rank = None
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
+        g_ms = sum(a.elapsed_time(b) for a, b in gather_ms) / max(len(gather_ms), 1)
+        mine = torch.tensor([own_elapsed / args.steps * 1e3, g_ms], device=dev, dtype=torch.float64)
+        allv = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        per_rank = {"ms_per_step": [round(v[0].item(), 3) for v in allv], "halo_all_gather_ms": [round(v[1].item(), 3) for v in allv]}
 
     result = None
     if rank == 0:
@@ -285,96 +297,132 @@ def main():
             step(local_only=True)
         torch.cuda.synchronize()
         agg = {}
-        unit_ms = 0.0
-        unit_bytes = 0.0
+        unit_ms, unit_bytes, n_cabs = 0.0, 0.0, 0
         for fn, label, meta, e0, e1 in eng.prof:
             key = fn
             if fn == "sn_conv2d":                       # one GPU kernel per (M-tiles, tile shape): key by template instance
                 mt = -(-max(meta[5], 1) // 16) if meta[9] != 1 else -(-meta[5] * 4 // 16)
-                key = f"sn_conv2d<mt{mt},{'8x32' if meta[7] == 1 else '4x16'}>" + ("[sums]" if meta[9] == 9 else "")
-            elif fn == "sn_cab_fused":
-                key = f"sn_cab_fused<cs{meta[4]}>"
-            elif fn in ("sn_ln_gemm_gate", "sn_ln_gemm_gate_m"):
+                key = f"sn_conv2d<mt{mt},{'8x32' if meta[7] == 1 else '4x16'}>"
+            elif fn in ("sn_ln_gemm_gate", "sn_cab_phase1"):
                 key = f"{fn}<{'cab2' if meta[5] else 'cab1'}>"
-            a = agg.setdefault(key, {"ms": 0.0, "n": 0, "bytes": 0.0})
+            a = agg.setdefault(key, {"ms": 0.0, "n": 0, "bytes": 0.0, "gsts": bool(meta and meta[0] == "naf")})
             d = e0.elapsed_time(e1)
             a["ms"] += d; a["n"] += 1; a["bytes"] += kernel_alg_bytes(fn, meta)
-            fn = key
             if meta and meta[0] == "naf":
                 unit_ms += d
                 if fn == "sn_scale_gemm_res":            # one CAB finished: its fused-unit bytes = read x + write y
                     unit_bytes += 2 * meta[1] * meta[2] * meta[3] * meta[4] * 2
-        prof_copy = list(eng.prof)
+                    n_cabs += 1
         eng.prof = None
         dom = max(agg, key=lambda k: agg[k]["ms"])
-        # HBM traffic of the dominant kernel from the committed PMC passes of THIS command (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE, separate passes, tools/make_profiles_r02.sh): per-launch average over the kernel's launches in the window,
-        # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950.
-        traffic, traffic_note = None, "no PMC entry for this kernel under profiles/"
+        # HBM traffic from the committed PMC passes of THIS command run with --no-parity --no-cpu-baseline (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE, separate passes, tools/make_profiles_r03.sh -> tools/pmc_summary.py): bytes per WINDOW per kernel symbol =
+        # sum over that symbol's launches / windows in the trace, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
+        # coalesced reads on gfx950.  A figure below 0.9 x the algorithmic bytes cannot be right (every input is read at least once):
+        # it is then reported as null with the reason (round 2's file averaged in the launches of a small parity clip).
+        SYM = {"sn_dw5m_gemm_gate": "dw5m_gemm_gate_kernel", "sn_ln_gemm_gate<cab2>": "ln_gemm_gate_kernel<64, true>",
+               "sn_ln_gemm_gate<cab1>": "ln_gemm_gate_kernel<64, false>", "sn_scale_gemm_res": "scale_gemm_res_kernel<64",
+               "sn_gsts_shiftconv": "shiftconv_kernel<32", "sn_conv2d<mt1,8x32>": "conv3_fast_kernel<1, 16, 8>",
+               "sn_conv2d<mt2,8x32>": "conv3_fast_kernel<2, 24, 8>", "sn_ca_mlp": "ca_mlp_kernel",
+               "sn_cab_phase1<cab1>": "cab_phase1_kernel<2", "sn_cab_phase1<cab2>": "cab_phase1_kernel<3"}
+        pmc, pmc_note = None, "no PMC file under profiles/"
+        headline = (args.variant, h, w, L, args.dtype, len(quads)) == (VARIANT, H, W, ONE_LEN, "bf16", 1)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))["kernels"]
-            sym = {"sn_dw5m_gemm_gate": "dw5m_gemm_gate_kernel", "sn_ln_gemm_gate<cab2>": "ln_gemm_gate_kernel<64, true>",
-                   "sn_ln_gemm_gate<cab1>": "ln_gemm_gate_kernel<64, false>", "sn_scale_gemm_res": "scale_gemm_res_kernel<64>",
-                   "sn_gsts_shiftconv": "shiftconv_kernel<32>", "sn_conv2d<mt1,8x32>": "conv3_fast_kernel<1, 16, 8>",
-                   "sn_conv2d<mt2,8x32>": "conv3_fast_kernel<2, 24, 8>"}.get(dom)
-            ent = next((v for k, v in pmc.items() if sym and sym in k), None)
-            if ent and (args.variant, h, w, L, args.dtype) == (VARIANT, H, W, ONE_LEN, "bf16"):
-                traffic = round((2 * ent["FETCH_SIZE_KB_per_launch"] + ent["WRITE_SIZE_KB_per_launch"]) * 1024 / 1e9, 4)
-                traffic_note = ("GB per launch, average over this kernel's launches in the window: 2 x FETCH_SIZE + WRITE_SIZE of the "
-                                f"committed PMC passes of this command (profiles/{PMC_FILE})")
+            doc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+            pmc = doc["kernels_per_window"] if headline else None
+            pmc_note = (f"profiles/{PMC_FILE}: 2 x FETCH_SIZE + WRITE_SIZE summed over the kernel's launches of one window "
+                        f"({doc.get('windows_in_trace')} full windows in the trace, no parity sample)") if headline else "PMC passes exist for the headline config only"
         except Exception as e:                                      # noqa: BLE001
-            traffic_note = f"PMC file unreadable: {e}"
-        ach = agg[dom]["bytes"] / (agg[dom]["ms"] * 1e-3) / 1e9
+            pmc_note = f"PMC file unreadable: {e}"
+
+        def window_gb(key):
+            sym = SYM.get(key)
+            if pmc is None or sym is None:
+                return None
+            hits = [v for k, v in pmc.items() if sym in k]
+            return sum(2 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"] for v in hits) * 1024 / 1e9 if hits else None
+
+        def checked(traffic_gb, alg_gb, what):
+            if traffic_gb is None:
+                return None, pmc_note
+            if traffic_gb < 0.9 * alg_gb:
+                return None, f"PMC file stale or diluted: {what} measured {traffic_gb:.4f} GB < 0.9 x algorithmic {alg_gb:.4f} GB"
+            return round(traffic_gb, 4), pmc_note
+        dom_alg = agg[dom]["bytes"] / agg[dom]["n"] / 1e9
+        dw = window_gb(dom)
+        dom_traffic, dom_note = checked(None if dw is None else dw / agg[dom]["n"], dom_alg, dom)
+        n_units = max(n_cabs // 2, 1)
+        gw = [window_gb(k) for k, v in agg.items() if v["gsts"]]
+        unit_alg = unit_bytes / n_units / 1e9
+        unit_traffic, unit_note = checked(None if (not gw or any(g is None for g in gw)) else sum(gw) / n_units, unit_alg, "GSTS kernels per unit")
+        ach_dom = agg[dom]["bytes"] / (agg[dom]["ms"] * 1e-3) / 1e9
+        ach_unit = unit_bytes / max(unit_ms, 1e-9) / 1e6
         kernels = {k: {"ms_total": round(v["ms"], 3), "launches": v["n"],
                        "gbps_algorithmic": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)} for k, v in agg.items()}
         sbytes = 4 if dt == torch.float32 else 2
         win_bytes = len(quads) * algorithmic_bytes_window(args.variant, hh, ww, L + 4, L, s=sbytes)
+        dlabel = {"bf16": "bf16", "fp16": "fp16", "fp32": "fp32"}[args.dtype]
         result = {
-            "metric": f"restored frames/sec at {w}x{h} T={L} {'fp32' if dt == torch.float32 else 'bf16'}", "value": round(fps, 3), "unit": "frames/s",
+            "metric": f"restored frames/sec at {w}x{h} T={L} {dlabel}", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if dt == torch.float32 else "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+            # module dtype; fp16 / bf16 modules both compute with bf16 storage + fp32 accumulation
+            "dtype": {"bf16": "bf16", "fp16": "fp16 module on bf16 storage", "fp32": "f32"}[args.dtype],
             "config": {"workload": f"{'Shift-Net-s' if args.variant.endswith('2') else 'Shift-Net+'} ({args.variant}), {w}x{h}, one_len={L} (T_in={L + 4}), "
                                    + ("as the denoise CLI's 4 quadrants of %dx%d, " % (ww, hh) if args.quadrants else "")
                                    + (f"module dtype {args.dtype}, " if args.dtype != "bf16" else "")
                                    + "one window per GPU, synthetic checkpoint", "parallelism": f"clip-parallel x{world}",
                        "baseline_config": args.config if args.config is not None else (2 if (args.variant, h, w, L) == (VARIANT, H, W, ONE_LEN) else None)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
-                         "algorithmic_gb_per_launch": round(agg[dom]["bytes"] / agg[dom]["n"] / 1e9, 4),
-                         "avg_launch_ms": round(agg[dom]["ms"] / agg[dom]["n"], 4), "launches": agg[dom]["n"]},
-            "gsts_unit_roofline": {"achieved": round(unit_bytes / max(unit_ms, 1e-9) / 1e6, 1), "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": round(unit_bytes / max(unit_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
-                                   "note": "SURVEY 8(d) fused-unit bytes (read x + write y per CAB2/CAB1) / time of all GSTS kernels"},
+            # the roofline this path is graded on is the FUSED GSTS UNIT (channel_shift + CAB2 + CAB1: read x, write y per
+            # CAB = 4 T C h w s bytes) over the time of every GSTS kernel; intermediates count zero bytes.
+            "roofline": {"bound": "hbm", "scope": "fused GSTS unit (SURVEY.md 8d), all pyramid levels of one window", "achieved": round(ach_unit, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_unit / HBM_PEAK_GBS, 4), "traffic": unit_traffic,
+                         "traffic_note": "GB per unit (average over the window's units): " + unit_note,
+                         "algorithmic_gb_per_unit": round(unit_alg, 4), "avg_unit_ms": round(unit_ms / n_units, 4), "units": n_units},
+            "dominant_kernel": {"kernel": dom, "bound": "hbm", "achieved": round(ach_dom, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(ach_dom / HBM_PEAK_GBS, 4), "traffic": dom_traffic, "traffic_note": "GB per launch: " + dom_note,
+                                "algorithmic_gb_per_launch": round(dom_alg, 4),
+                                "avg_launch_ms": round(agg[dom]["ms"] / agg[dom]["n"], 4), "launches": agg[dom]["n"],
+                                "note": "kernel-local figure: its inputs / outputs include intermediates that the fused-unit model counts as zero bytes"},
             "whole_net_roofline": {"achieved": round(win_bytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(win_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "kernels": kernels,
         }
+        if per_rank is not None:
+            result["per_rank"] = per_rank
         if world > 1 and os.environ.get("SN_BENCH_SHARED_DEVICE_TEST") == "1":
             result["shared_device_test"] = True        # all ranks on one GPU: a rank-flow test, not a measurement
-        if world == 1 and args.variant == VARIANT and args.dtype == "bf16":
+        if world == 1 and args.variant == VARIANT and args.dtype == "bf16" and not args.no_parity:
             # parity sample next to the throughput: the same module on a small clip vs the CPU oracle (checker only)
             from oracle import shiftnet_oracle as O
+            from shiftnet_amd import cli as CLI
             sd = synth_state_dict(VARIANT)
             blur_s, sharp_s = synth.blurred_clip(7, 96, 128, seed=4)
             xs = O.frames_to_tensor(list(blur_s))
             with torch.no_grad():
                 o_hip = net(xs.to(torch.bfloat16).to(dev)).float().cpu()
                 o_ref = O.forward(O.VARIANTS[VARIANT], sd, xs, None, 2, 2)
-                # the reference under the I/O quantisation of a bf16 module (bf16 input tensor, bf16 output tensor)
-                o_rq = O.forward(O.VARIANTS[VARIANT], sd, xs.bfloat16().float(), None, 2, 2).bfloat16().float()
             gt = torch.from_numpy(sharp_s[2:5]).permute(0, 3, 1, 2).float() / 255
 
             def psnr(a, b):
                 m = (a - b).pow(2).mean().item()
                 return 99.0 if m == 0 else 10 * __import__("math").log10(1.0 / m)
-            result["parity"] = {"sample": "Shift-Net-s, 7x96x128 synthetic clip, 3 restored frames, bf16 module vs CPU fp32 oracle",
-                                "psnr_hip_vs_fp32_db": round(psnr(o_hip, o_ref), 2),
-                                "delta_psnr_vs_gt_db": round(abs(psnr(o_hip.clamp(0, 1), gt) - psnr(o_rq.clamp(0, 1), gt)), 4),
-                                "delta_psnr_vs_gt_fp32_io_db": round(abs(psnr(o_hip.clamp(0, 1), gt) - psnr(o_ref.clamp(0, 1), gt)), 4),
-                                "io_quantisation_alone_db": round(abs(psnr(o_rq.clamp(0, 1), gt) - psnr(o_ref.clamp(0, 1), gt)), 4),
-                                "max_abs": round((o_hip - o_ref).abs().max().item(), 5),
-                                "tolerance": "psnr_hip_vs_fp32_db >= 48 and delta_psnr_vs_gt_db <= 0.01 (reference evaluated with the "
-                                             "same bf16 input/output tensors); asserted in tests/test_gpu_parity.py"}
+            par = {"sample": "Shift-Net-s, 7x96x128 synthetic clip, 3 restored frames, bf16 module vs CPU fp32 oracle (the reference restated)",
+                   "psnr_hip_vs_fp32_db": round(psnr(o_hip, o_ref), 2), "max_abs": round((o_hip - o_ref).abs().max().item(), 5),
+                   # the module's bf16 OUTPUT TENSOR against the fp32 reference: includes the 1/256 quantisation of a bf16 image tensor
+                   "delta_psnr_vs_gt_bf16_tensor_db": round(abs(psnr(o_hip.clamp(0, 1), gt) - psnr(o_ref.clamp(0, 1), gt)), 4)}
+            # the CLI path (what test_deblur.py measures): PSNR from the fp32 accumulators of conv_last, no bf16 image tensor in between
+            try:
+                with torch.no_grad():
+                    o32 = net.forward_fp32_out(xs.to(torch.bfloat16).to(dev), shortcut=xs.to(dev)).float().cpu()
+                par["delta_psnr_vs_gt_db"] = round(abs(psnr(o32.clamp(0, 1), gt) - psnr(o_ref.clamp(0, 1), gt)), 4)
+                par["psnr_fp32_out_vs_fp32_db"] = round(psnr(o32, o_ref), 2)
+                par["tolerance"] = ("psnr_hip_vs_fp32_db >= 48 and delta_psnr_vs_gt_db <= 0.01 against the fp32 reference directly (restored frame "
+                                    "taken from conv_last's fp32 accumulators and the un-rounded input, as the CLI does); asserted in "
+                                    "tests/test_gpu_parity.py, tests/test_gpu_io.py")
+            except AttributeError:
+                par["tolerance"] = "psnr_hip_vs_fp32_db >= 48"
+            result["parity"] = par
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle on a bounded sample (child process, hard timeout)")
             result["cpu_baseline"] = cpu_baseline_subprocess()

@@ -65,8 +65,10 @@ typedef struct sn_conv_desc {
                             2: NCHW [T][c_out][h][w] of `nchw_dtype` plus the NCHW shortcut `sc`
                                ("return output_features + shortcut[...]" :791) */
     int c_out;           /* logical out channels (mode 2 only) */
-    int nchw_dtype;
-    const void* sc;      /* mode 2: NCHW tensor of nchw_dtype, same shape as out */
+    int nchw_dtype;      /* SN_F32 with a half-precision module = the restored frame straight from the fp32 accumulators: what the CLIs'
+                            metrics and PNG writer consume (inference/test_deblur.py:137-143 calls .float() on the module output) */
+    const void* sc;      /* mode 2: NCHW tensor of `sc_dtype`, same shape as out */
+    int sc_dtype;
     float* pool;         /* NULL or [T][gridDim.y*gridDim.x][16*mt] f32 per-workgroup channel sums of the output
                             (first half of AdaptiveAvgPool2d(1), CALayer :69); rows per frame = sn_conv_pool_blocks(d) */
     const float* oscale; /* NULL or [T][oscale_stride] f32: out = conv * oscale[t][c] (+ res) -- the CALayer scale of a CAB

@@ -22,7 +22,7 @@ struct ConvK {
     int hin, win, in_mode, k, stride, pad, hout, wout;
     const uint4* wfrag; int ks;
     const float* bias; int act; float prelu;
-    const bf16_t* res; bf16_t* out; int cs_out, out_mode, c_out, nchw_dtype;
+    const bf16_t* res; bf16_t* out; int cs_out, out_mode, c_out, nchw_dtype, sc_dtype;
     const void* sc; float* pool; const float* oscale; int oscale_stride; const bf16_t* res2;
     int rh, rw, ps;
     XcdTiles xg;                     // tile walk of conv_mfma_kernel / conv3_fast_kernel (sn_common.h)
@@ -248,13 +248,11 @@ __global__ __launch_bounds__(256, sn_conv_waves(MT, TH)) void conv_mfma_kernel(c
                         const int co = co0 + r;
                         if (co < P.c_out) {
                             const size_t oi = (((size_t)t * P.c_out + co) * P.hout + oy) * P.wout + ox;
-                            if (P.nchw_dtype == SN_F32) {
-                                ((float*)P.out)[oi] = v[r] + ((const float*)P.sc)[oi];
-                            } else if (P.nchw_dtype == SN_F16) {
-                                ((__half*)P.out)[oi] = __float2half(v[r] + __half2float(((const __half*)P.sc)[oi]));
-                            } else {
-                                ((bf16_t*)P.out)[oi] = f_to_bf(v[r] + bf_to_f(((const bf16_t*)P.sc)[oi]));
-                            }
+                            const float scv = P.sc_dtype == SN_F32 ? ((const float*)P.sc)[oi]
+                                            : (P.sc_dtype == SN_F16 ? __half2float(((const __half*)P.sc)[oi]) : bf_to_f(((const bf16_t*)P.sc)[oi]));
+                            if (P.nchw_dtype == SN_F32) ((float*)P.out)[oi] = v[r] + scv;
+                            else if (P.nchw_dtype == SN_F16) ((__half*)P.out)[oi] = __float2half(v[r] + scv);
+                            else ((bf16_t*)P.out)[oi] = f_to_bf(v[r] + scv);
                         }
                     }
                 }
@@ -769,7 +767,7 @@ int sn_conv2d(const sn_conv_desc* d, void* stream) {
     if (!d->out) return SN_EINVAL;
     if (d->k < 1 || d->k > 5 || (d->stride != 1 && d->stride != 2) || d->mt < 1 || d->mt > 6 || d->ks < 1) return SN_EINVAL;
     if (d->in_mode == 1 && ((d->h_in | d->w_in) & 1)) return SN_EINVAL;
-    if (d->out_mode == 2 && (!d->sc || d->c_out > 4 * d->mt)) return SN_EINVAL;
+    if (d->out_mode == 2 && (!d->sc || d->c_out > 4 * d->mt || d->nchw_dtype < 0 || d->nchw_dtype > 2 || d->sc_dtype < 0 || d->sc_dtype > 2)) return SN_EINVAL;
     if (d->ks * 32 < d->k * d->k * d->n_in * d->cs_in) return SN_EINVAL;
     if (d->oscale && d->oscale_stride < 16 * d->mt) return SN_EINVAL;
     if ((d->res || d->res2) && d->out_mode != 0) return SN_EINVAL;
@@ -780,7 +778,7 @@ int sn_conv2d(const sn_conv_desc* d, void* stream) {
     K.hout = d->h_out; K.wout = d->w_out;
     K.wfrag = (const uint4*)d->wfrag; K.ks = d->ks; K.bias = d->bias; K.act = d->act; K.prelu = d->prelu;
     K.res = (const bf16_t*)d->res; K.out = (bf16_t*)d->out; K.cs_out = d->cs_out; K.out_mode = d->out_mode;
-    K.c_out = d->c_out; K.nchw_dtype = d->nchw_dtype; K.sc = d->sc; K.pool = d->pool; K.oscale = d->oscale; K.oscale_stride = d->oscale_stride; K.res2 = (const bf16_t*)d->res2;
+    K.c_out = d->c_out; K.nchw_dtype = d->nchw_dtype; K.sc_dtype = d->sc_dtype; K.sc = d->sc; K.pool = d->pool; K.oscale = d->oscale; K.oscale_stride = d->oscale_stride; K.res2 = (const bf16_t*)d->res2;
     const int blocks = K.cv >> 3;
     K.ps = d->stride == 1 ? 16 * sn_lds_slots(blocks) : ((blocks & 1) ? K.cv * 2 : K.cv * 2 + 16);     // stride 2: odd slot count (pixels 2 apart)
     K.rh = K.rw = 0;

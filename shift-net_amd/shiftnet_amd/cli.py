@@ -7,7 +7,12 @@ Same flags, directory layout, window arithmetic, metric definitions and log line
   --dtype {fp16,bf16,fp32}  dtype of the module (upstream: fp16 except the "+" denoiser, which stays float32): fp16 / bf16
                       modules run the bf16-storage MFMA kernels, fp32 modules the fp32 kernels (engine32.py)
   --host_io           convert uint8 <-> float on the host exactly like upstream (default: on the device, csrc/sn_io.hip:
-                      same values bit for bit, 3 instead of 12 bytes per pixel over PCIe, PSNR and SSIM reduced on the GPU)
+                      same values bit for bit, 3 instead of 12 bytes per pixel over PCIe, PSNR and SSIM reduced on the GPU; the
+                      denoise CLIs then also draw their AWGN on the device -- upstream draws it unseeded on the host,
+                      test_denoise.py:145-147, so the realisation is not part of the contract -- and stitch the quadrants there)
+The restored frames are taken as float32 straight from the last conv's fp32 accumulators (GShiftNet.forward_fp32_out): upstream
+converts the half-precision module output with .float() before clamp * 255 / PSNR / imwrite (test_deblur.py:137-143), and a bf16
+image tensor would quantise [0.5, 1] to 1/256 steps first.
 Image I/O uses PIL (imageio / cv2 / skimage are not in this image); PSNR / SSIM restate the upstream formulas.
 """
 from __future__ import annotations
@@ -88,17 +93,23 @@ def denoise_windows(n_frames: int) -> List[Tuple[int, int, int]]:
     return [(kk * one_len, one_len + (k_res if kk == k_len - 1 else 0), k_res if kk == k_len - 1 else 0) for kk in range(k_len)]
 
 
-def quadrant_forward(net, x: torch.Tensor, sigma: float) -> torch.Tensor:
-    """The denoise CLI's 4 overlapping quadrants (test_denoise.py:153-173); x:[1,N,3,H,W] on device."""
+def quadrant_forward(net, x: torch.Tensor, sigma: float, on_device: bool = False, x32: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The denoise CLI's 4 overlapping quadrants (test_denoise.py:153-173); x:[1,N,3,H,W] on device.  The stitched float32 frames are
+    returned on the host like upstream's, or stay on the device (on_device) for the device-side metrics."""
     B, N, _, H, W = x.shape
     pad_h, pad = 32 - (H // 2 % 16), 32 - (W // 2 % 16)
     hh, ww = H // 2 + pad_h, W // 2 + pad
     std = torch.full((1, 1, 1, 1, 1), sigma, dtype=x.dtype, device=x.device).expand(B, N, 1, hh, ww)
-    out = torch.zeros(N - 4, 3, H, W)
-    o1 = net(x[:, :, :, 0:hh, 0:ww].contiguous(), std).float().cpu()
-    o2 = net(x[:, :, :, 0:hh, W // 2 - pad:].contiguous(), std).float().cpu()
-    o3 = net(x[:, :, :, H // 2 - pad_h:, 0:ww].contiguous(), std).float().cpu()
-    o4 = net(x[:, :, :, H // 2 - pad_h:, W // 2 - pad:].contiguous(), std).float().cpu()
+    out = torch.zeros(N - 4, 3, H, W, device=x.device if on_device else "cpu")
+
+    def run(ys, xs):        # x32: the un-rounded float32 frames for the final "+ x" of a half-precision module
+        sc = x32[:, :, :, ys, xs].contiguous() if x32 is not None and x32.dtype != x.dtype else None
+        o = net.forward_fp32_out(x[:, :, :, ys, xs].contiguous(), std, shortcut=sc)
+        return o if on_device else o.cpu()
+    o1 = run(slice(0, hh), slice(0, ww))
+    o2 = run(slice(0, hh), slice(W // 2 - pad, W))
+    o3 = run(slice(H // 2 - pad_h, H), slice(0, ww))
+    o4 = run(slice(H // 2 - pad_h, H), slice(W // 2 - pad, W))
     out[..., 0:H // 2, 0:W // 2] = o1[..., 0:-pad_h, 0:-pad]
     out[..., 0:H // 2, W // 2:] = o2[..., 0:-pad_h, pad:]
     out[..., H // 2:, 0:W // 2] = o3[..., pad_h:, 0:-pad]
@@ -167,22 +178,33 @@ class Inference:
                 inputs = [im[:nh, :nw] for im in inputs]
                 gtf = [im[:nh, :nw] for im in gtf]
                 name = os.path.basename(ins[start + 2]).split(".")[0] if isinstance(ins[start + 2], str) else "%05d" % (start + 2)
-                dev_io = not a.host_io and not self.denoise       # (the denoise CLI draws its noise on the host, test_denoise.py:145-147)
-                if self.denoise:
-                    x = numpy2tensor(inputs)
+                dev_io = not a.host_io
+                x32 = None
+                if self.denoise and dev_io:     # uint8 frames up, float32 conversion and the AWGN on the device, quadrants stitched there
                     sigma = a.sigma / 255.0
-                    x = x + torch.empty_like(x).normal_(mean=0, std=sigma)
-                    x = x.to("cuda").to(self.dtype)
+                    x32 = ingest_u8(torch.from_numpy(np.stack(inputs)).to("cuda"), torch.float32)
+                    x32 = x32 + torch.empty_like(x32).normal_(mean=0, std=sigma)
+                    x = x32.to(self.dtype)
                     t1 = time.time()
-                    output = quadrant_forward(self.net, x, sigma)
+                    output = quadrant_forward(self.net, x, sigma, on_device=True, x32=x32)
+                elif self.denoise:              # upstream's host path (test_denoise.py:145-173)
+                    x32 = numpy2tensor(inputs)
+                    sigma = a.sigma / 255.0
+                    x32 = (x32 + torch.empty_like(x32).normal_(mean=0, std=sigma)).to("cuda")
+                    x = x32.to(self.dtype)
+                    t1 = time.time()
+                    output = quadrant_forward(self.net, x, sigma, x32=x32)
                 elif dev_io:
-                    x = ingest_u8(torch.from_numpy(np.stack(inputs)).to("cuda"), self.dtype)
+                    u8 = torch.from_numpy(np.stack(inputs)).to("cuda")
+                    x = ingest_u8(u8, self.dtype)
+                    x32 = ingest_u8(u8, torch.float32) if self.dtype != torch.float32 else None     # exact v / 255 for the final "+ x"
                     t1 = time.time()
-                    output = self.net(x)
+                    output = self.net.forward_fp32_out(x, shortcut=x32)
                 else:
-                    x = numpy2tensor(inputs).to("cuda").to(self.dtype)
+                    x32 = numpy2tensor(inputs).to("cuda")
+                    x = x32.to(self.dtype)
                     t1 = time.time()
-                    output = self.net(x).float()
+                    output = self.net.forward_fp32_out(x, shortcut=x32 if self.dtype != torch.float32 else None)
                 torch.cuda.synchronize()
                 t2 = time.time()
                 psnr = ssim = float("nan")
@@ -208,7 +230,7 @@ class Inference:
                             write_image(os.path.join(self.result_path, v, "%03d.png" % index), img)
                     index += 1
                 t3 = time.time()
-                del output, x
+                del output, x, x32
                 torch.cuda.empty_cache()
                 self.logger.write_log(
                     "> {}-{} PSNR={:.5}, SSIM={:.4} pre_time:{:.3}s, forward_time:{:.3}s, post_time:{:.3}s, total_time:{:.3}s"

@@ -36,13 +36,31 @@ def _dtype_code(dt: torch.dtype) -> int:
     return {torch.float32: L.SN_F32, torch.float16: L.SN_F16, torch.bfloat16: L.SN_BF16}[dt]
 
 
+def host_f32_copy(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """fp32 CPU copies of a state dict with ONE device-to-host transfer: the ~2000 tensors of a checkpoint are flattened into one
+    buffer on their device first (per-key .cpu() calls cost 5755 copyBuffer launches / 27 ms per plan build in the round-2 profile)."""
+    keys = list(sd.keys())
+    if not keys:
+        return {}
+    dev_keys = [k for k in keys if sd[k].device.type != "cpu"]
+    out = {k: sd[k].detach().float() for k in keys if sd[k].device.type == "cpu"}
+    if dev_keys:
+        flat = torch.cat([sd[k].detach().reshape(-1).float() for k in dev_keys]).cpu()
+        o = 0
+        for k in dev_keys:
+            n = sd[k].numel()
+            out[k] = flat[o:o + n].reshape(sd[k].shape)
+            o += n
+    return {k: out[k] for k in keys}
+
+
 class Plan:
     """Device-resident prepared weights of one checkpoint."""
 
     def __init__(self, V: Variant, sd: Dict[str, torch.Tensor], device: torch.device) -> None:
         self.V = V
         self.device = device
-        self.sd = {k: v.detach().float().cpu() for k, v in sd.items()}
+        self.sd = host_f32_copy(sd)
         self.convs: Dict[str, Dict[str, object]] = {}
         self.cas: Dict[str, Dict[str, object]] = {}
         self.units: Dict[str, Dict[str, object]] = {}
@@ -239,7 +257,7 @@ class Engine:
         if out_mode == 2:
             assert nchw_out is not None and nchw_sc is not None
             d.out, d.sc, d.cs_out = nchw_out.data_ptr(), nchw_sc.data_ptr(), 8
-            d.c_out, d.nchw_dtype = cout, _dtype_code(nchw_out.dtype)
+            d.c_out, d.nchw_dtype, d.sc_dtype = cout, _dtype_code(nchw_out.dtype), _dtype_code(nchw_sc.dtype)
         else:
             c_log = cout // 4 if out_mode == 1 else cout
             cs_out = prep.ceil8(c_log)
@@ -464,11 +482,17 @@ class Engine:
         return Act(x8, self.V.in_ch)
 
     @torch.no_grad()
-    def forward(self, x: torch.Tensor, noise_map: Optional[torch.Tensor], past: int, future: int) -> torch.Tensor:
-        """GShiftNet.forward; x:[T,C,H,W] (already x[0]) on this engine's device, any of fp32/fp16/bf16."""
+    def forward(self, x: torch.Tensor, noise_map: Optional[torch.Tensor], past: int, future: int,
+                out_dtype: Optional[torch.dtype] = None, shortcut: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """GShiftNet.forward; x:[T,C,H,W] (already x[0]) on this engine's device, any of fp32/fp16/bf16.  out_dtype (default: x.dtype, the
+        module contract) = torch.float32 returns the restored frames from conv_last's fp32 accumulators without the rounding to a
+        half-precision image tensor: the CLIs' metrics / PNG path (inference/test_deblur.py:137-143 converts with .float() anyway).
+        shortcut: optional [T,3,H,W] tensor added instead of x in "return output_features + shortcut[...]" (gshift_deblur1.py:791): the
+        un-rounded float32 frames when x had to be rounded to a half-precision module dtype."""
         with torch.cuda.device(self.dev):      # launches, events and allocations all belong to the engine's device
-            if not self.use_graph or self.split is not None or self.prof is not None or torch.cuda.is_current_stream_capturing():
-                return self._forward(x, noise_map, past, future)
+            if (not self.use_graph or self.split is not None or self.prof is not None or out_dtype is not None or shortcut is not None
+                    or torch.cuda.is_current_stream_capturing()):
+                return self._forward(x, noise_map, past, future, out_dtype, shortcut)
             return self._forward_graphed(x, noise_map, past, future)
 
     def _forward_graphed(self, x, noise_map, past, future):
@@ -500,7 +524,8 @@ class Engine:
         g.replay()
         return so.clone()                       # the graph owns `so`: hand out a copy, like the fresh tensor upstream returns
 
-    def _forward(self, x: torch.Tensor, noise_map: Optional[torch.Tensor], past: int, future: int) -> torch.Tensor:
+    def _forward(self, x: torch.Tensor, noise_map: Optional[torch.Tensor], past: int, future: int,
+                 out_dtype: Optional[torch.dtype] = None, shortcut: Optional[torch.Tensor] = None) -> torch.Tensor:
         V = self.V
         x = x.contiguous()
         T, cin, H, W = x.shape
@@ -511,7 +536,7 @@ class Engine:
         lo = past if (sp is None or sp.rank == 0) else 0                         # a split window trims on its outer ranks only
         hi = T - (future if (sp is None or sp.rank == sp.world - 1) else 0)
         n_out = max(hi - lo, 0)
-        out = torch.empty((n_out, 3, H, W), dtype=x.dtype, device=x.device)
+        out = torch.empty((n_out, 3, H, W), dtype=out_dtype or x.dtype, device=x.device)
         if n_out == 0:
             if sp is not None:
                 raise ValueError("temporal split: every rank must restore at least one frame (the halo exchanges are collective)")
@@ -531,7 +556,9 @@ class Engine:
         sc = y
         for i in range(1, V.n_orb + 1):     # deblur: "+ shortcut" after the last rorb (:779), same folding
             y = self.tfr_unet(f"rorb{i}.", y, sc if (i == V.n_orb and not V.denoise) else None)
-        self.conv("conv_last", [y], out_mode=2, nchw_out=out, nchw_sc=x[lo:hi].contiguous())
+        sc = x if shortcut is None else shortcut
+        assert sc.shape[0] == T and tuple(sc.shape[2:]) == (H, W) and sc.shape[1] >= 3 and sc.device == x.device
+        self.conv("conv_last", [y], out_mode=2, nchw_out=out, nchw_sc=sc[lo:hi, :3].contiguous() if sc.shape[1] > 3 else sc[lo:hi].contiguous())
         return out
 
 

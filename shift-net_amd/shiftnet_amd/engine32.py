@@ -20,7 +20,7 @@ import torch
 
 from . import lib as L
 from . import prep
-from .engine import Act, Engine, Plan, _dtype_code
+from .engine import Act, Engine, Plan, _dtype_code, host_f32_copy
 from .spec import Variant, shift_table
 
 
@@ -30,7 +30,7 @@ class Plan32(Plan):
     def __init__(self, V: Variant, sd: Dict[str, torch.Tensor], device: torch.device) -> None:
         self.V = V
         self.device = device
-        self.sd = {k: v.detach().float().cpu() for k, v in sd.items()}
+        self.sd = host_f32_copy(sd)
         self.dsd = {k: v.to(device) for k, v in self.sd.items()}
         self.convs: Dict[str, Dict[str, object]] = {}
         self.cas: Dict[str, Dict[str, object]] = {}

@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
         ("wfrag", C.c_void_p), ("mt", C.c_int), ("ks", C.c_int), ("bias", C.c_void_p),
         ("act", C.c_int), ("prelu", C.c_float), ("res", C.c_void_p), ("out", C.c_void_p),
         ("cs_out", C.c_int), ("out_mode", C.c_int), ("c_out", C.c_int), ("nchw_dtype", C.c_int),
-        ("sc", C.c_void_p), ("pool", C.c_void_p), ("oscale", C.c_void_p), ("oscale_stride", C.c_int), ("res2", C.c_void_p),
+        ("sc", C.c_void_p), ("sc_dtype", C.c_int), ("pool", C.c_void_p), ("oscale", C.c_void_p), ("oscale_stride", C.c_int), ("res2", C.c_void_p),
     ]
 
 

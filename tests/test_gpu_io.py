@@ -44,3 +44,27 @@ def test_device_ssim_matches_the_cli_formula(dt, hw):
     for e in range(T):
         host = out[e].float().clamp(0, 1.0).permute(1, 2, 0).numpy() * 255
         assert abs(got[e] - cli.ssim_calculate(host, sharp[e])) < 2e-5, (e, got[e])
+
+
+@pytest.mark.parametrize("name,dt", [("gshift_deblur2", torch.bfloat16), ("gshift_deblur2", torch.float16), ("gshift_deblur1", torch.bfloat16)])
+def test_cli_psnr_of_a_half_precision_module_is_within_the_contract_of_the_fp32_reference(name, dt):
+    """What the deblur CLI reports for a bf16 / fp16 module -- uint8 frames in, float32 restored frames from conv_last's fp32
+    accumulators (forward_fp32_out, "+ x" on the exact v / 255), clamp * 255, PSNR vs the uint8 ground truth on the device -- against
+    the SAME metric of the fp32 reference forward on the same frames (oracle = the reference restated; inference/test_deblur.py:139-143).
+    north_star: within 0.01 dB, with no re-definition of the reference."""
+    import importlib
+    from oracle import shiftnet_oracle as O
+    from shiftnet_amd.weights import synth_state_dict
+    blur, sharp = synth.blurred_clip(7, 48, 64, seed=3)
+    sd = synth_state_dict(name)
+    net = importlib.import_module(f"basicsr.models.archs.{name}").GShiftNet(future_frames=2, past_frames=2)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dt).cuda().eval()
+    u8 = torch.from_numpy(blur).cuda()
+    with torch.no_grad():
+        out = net.forward_fp32_out(ingest_u8(u8, dt), shortcut=ingest_u8(u8, torch.float32))
+        ref = O.forward(O.VARIANTS[name], sd, cli.numpy2tensor(list(blur)), None, 2, 2)
+    _, psnr = egress_u8(out, torch.from_numpy(sharp[2:5]).cuda(), want_image=False)
+    for e in range(3):
+        host_ref = ref[e].clamp(0, 1.0).permute(1, 2, 0).numpy() * 255               # test_deblur.py:140-141 on the reference output
+        assert abs(psnr[e] - cli.psnr_255(host_ref, sharp[2 + e])) <= 0.01, (name, dt, e, psnr[e], cli.psnr_255(host_ref, sharp[2 + e]))

@@ -282,7 +282,7 @@ def test_unit_parity_at_production_tile_counts(name, T, h, w, engines):
         check(f"unit_{'rev' if rev else 'fwd'}_{name}_{T}x{h}x{w}", to_cpu(out.t, V.c1), O.gsts_unit(sd, blk + unit, x, rev, V), 1.2e-2)
 
 
-@pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_deblur1", "gshift_denoise1"])
+@pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_deblur1", "gshift_denoise1", "gshift_denoise2"])
 def test_unet_and_stage1(name, engines):
     eng, sd = engines(name)
     V = O.VARIANTS[name]
@@ -298,6 +298,11 @@ def test_unet_and_stage1(name, engines):
 def _psnr(a, b):
     mse = (a.float() - b.float()).pow(2).mean().item()
     return 99.0 if mse == 0 else 10 * np.log10(1.0 / mse)
+
+
+# relative RMS error of the network's correction (out - input) against the reference's: <= 2x the largest value measured on MI355X
+# for the four variants (fp16 / bf16 modules, gpurun_out/parity_report.json); a wrong tap or gate half is O(1) here
+CORR_TOL = 0.08
 
 
 @pytest.mark.parametrize("name", list(VARIANTS))
@@ -321,20 +326,26 @@ def test_whole_net_vs_golden(name, dt, golden_dir):
     assert tuple(out.shape) == tuple(ref.shape) and out.dtype == dt
     out = out.float().cpu()
     gt = torch.from_numpy(sharp[2:5]).permute(0, 3, 1, 2).float() / 255
-    p_oo = _psnr(out, ref)
-    dpsnr_raw = abs(_psnr(out.clamp(0, 1), gt) - _psnr(ref.clamp(0, 1), gt))
-    if dt == torch.float16:
-        dpsnr = dpsnr_raw                                  # upstream's CLI dtype: compared with the fp32 reference output directly
-    else:
-        # a bf16 module's input and output TENSORS are bf16: compare with the reference evaluated under the same I/O
-        # quantisation (fp32 oracle on the bf16-rounded clip, output rounded to bf16) -- see the module docstring
-        with torch.no_grad():
-            sd = synth_state_dict(name)
-            ref_q = O.forward(V, sd, x.bfloat16().float(), nm.bfloat16().float() if V.denoise else None, 2, 2).bfloat16().float()
-        dpsnr = abs(_psnr(out.clamp(0, 1), gt) - _psnr(ref_q.clamp(0, 1), gt))
-    REPORT.append({"name": f"net_{name}_{dt}", "psnr_vs_ref": p_oo, "ref_own_bf16_psnr": float(g["p2f2_ref_bf16_psnr"]),
-                   "delta_psnr_gt": dpsnr, "delta_psnr_gt_vs_fp32_ref": dpsnr_raw, "max_abs": (out - ref).abs().max().item()})
-    assert p_oo >= 48.0 and dpsnr <= 0.01, (name, dt, p_oo, dpsnr, dpsnr_raw)
+    p_oo = _psnr(out, ref)                                    # the module contract: a tensor of the module dtype
+    # The CLI path: restored frames as float32 from conv_last's accumulators, the final "+ x" on the un-rounded frames
+    # (GShiftNet.forward_fp32_out).  Compared with the REFERENCE's fp32 output directly, no re-definition of the reference.
+    with torch.no_grad():
+        kw = {"shortcut": x.cuda()}
+        out32 = (net.forward_fp32_out(x.to(dt).cuda(), nm.to(dt).cuda(), **kw) if V.denoise else net.forward_fp32_out(x.to(dt).cuda(), **kw))
+    assert out32.dtype == torch.float32 and tuple(out32.shape) == tuple(ref.shape)
+    out32 = out32.cpu()
+    p_32 = _psnr(out32, ref)
+    dpsnr = abs(_psnr(out32.clamp(0, 1), gt) - _psnr(ref.clamp(0, 1), gt))
+    dpsnr_tensor = abs(_psnr(out.clamp(0, 1), gt) - _psnr(ref.clamp(0, 1), gt))
+    # The synthetic checkpoint makes the restored frame "input + small correction" (conv_last gain 0.01), so a PSNR against the
+    # reference output alone would tolerate a badly wrong correction: bound the CORRECTION itself, relative to the reference's.
+    xin = x[0, 2:5]
+    corr_err = ((out32 - xin) - (ref - xin)).pow(2).mean().sqrt().item() / (ref - xin).pow(2).mean().sqrt().item()
+    REPORT.append({"name": f"net_{name}_{dt}", "psnr_vs_ref": p_oo, "psnr_fp32_out_vs_ref": p_32, "ref_own_bf16_psnr": float(g["p2f2_ref_bf16_psnr"]),
+                   "delta_psnr_gt": dpsnr, "delta_psnr_gt_module_dtype_tensor": dpsnr_tensor, "correction_rel_rms_err": corr_err,
+                   "max_abs": (out32 - ref).abs().max().item()})
+    assert p_oo >= 48.0 and p_32 >= 48.0 and dpsnr <= 0.01, (name, dt, p_oo, p_32, dpsnr, dpsnr_tensor)
+    assert corr_err <= CORR_TOL, (name, dt, corr_err)
     # default past/future of the ctor
     net2 = mod.GShiftNet()
     net2.load_state_dict(synth_state_dict(name), strict=True)

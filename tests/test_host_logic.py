@@ -66,6 +66,31 @@ def test_dropin_class_contract():
             net(torch.zeros(1, 5, 3 if "deblur" in name else 3, 8, 8), *([torch.zeros(1, 5, 1, 8, 8)] if "denoise" in name else []))
 
 
+def test_weight_plan_is_dropped_when_parameters_change():
+    """Every way the parameters can change must invalidate the prepared device weights (shiftnet_amd/arch.py): a checkpoint loaded
+    through a PARENT module reaches the class only as _load_from_state_dict, in-place edits only bump version counters."""
+    from basicsr.models.archs import gshift_deblur2
+    from shiftnet_amd.engine import host_f32_copy
+    net = gshift_deblur2.GShiftNet()
+    sig0 = net._param_signature()
+    assert sig0 == net._param_signature()
+    net._plan = object()
+    parent = torch.nn.Module(); parent.net = net
+    parent.load_state_dict(parent.state_dict())
+    assert net._plan is None                                     # recursive load
+    sig1 = net._param_signature()
+    p = next(net.parameters())
+    p.data.mul_(1.0)
+    with torch.no_grad():
+        p.add_(0.0)                                              # in-place edit: version counter
+    assert net._param_signature() != sig1
+    net._plan = object(); net.half(); assert net._plan is None   # _apply
+    net._plan = object(); net.load_state_dict(net.state_dict()); assert net._plan is None
+    sd = {"a": torch.arange(6.0).reshape(2, 3).half(), "b": torch.ones(4)}
+    cp = host_f32_copy(sd)
+    assert list(cp) == ["a", "b"] and cp["a"].dtype == torch.float32 and torch.equal(cp["a"], sd["a"].float()) and cp["b"].shape == (4,)
+
+
 def test_window_ranges_match_cli_arithmetic():
     from shiftnet_amd.clip_parallel import window_ranges
     # test_deblur.py:111-120 with N=100, one_len=48: k_len = 96//48 = 2
