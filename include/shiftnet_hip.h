@@ -159,6 +159,18 @@ int sn_dw5m_blocks(int h, int w);
 int sn_dw5m_gemm_gate(const void* g1p, const float* ca_in, const void* ttab, const void* wfrag, void* g2, float* pool,
                       int T, int h, int w, int C, void* stream);
 
+/* ---- fused phase 1 of CAB1 / CAB2, depthwise variants without the inner CALayer2 (C = 64: Shift-Net-s deblur), csrc/sn_phase1.hip ----
+ * g2 = SimpleGate2(body[4](RepConv(SimpleGate(RepConv2(body[0](norm(u)))))))  (gshift_deblur2.py:186-214 CAB1, :215-258 CAB2) in ONE kernel:
+ * u is read once, g2 written once; `a`, g1 and r never reach HBM (what sn_ln_gemm_gate + sn_dw5m_gemm_gate do in two kernels with g1 in
+ * HBM).  s / hw: as for sn_ln_gemm_gate (hw = sn_gsts_shiftconv's output for mode 1 / 2, NULL for mode 0).
+ * wfrag1, bias, wsum, w3, w5, wfrag2: prep.pack_phase1 (LayerNorm folded and applied after the 1x1: wsum = row sums of the bf16 weights;
+ * w3 / w5: packed-fp16 stencil tables in accumulator-lane order; wfrag2: fp16 fragments of body[4]).
+ * g2: [T][h][w][C] NHWC bf16.  pool: NULL or [T][sn_cab_phase1_blocks(T,h,w)][C] f32 partial channel sums of g2 (CALayer2, finished by
+ * sn_ca_mlp).  sn_cab_phase1_blocks queries the current device (the work split depends on its CU count); < 0 on error. */
+int sn_cab_phase1_blocks(int T, int h, int w);
+int sn_cab_phase1(const sn_unit_src* s, const void* hw, const void* wfrag1, const float* bias, const float* wsum, const uint32_t* w3,
+                  const uint32_t* w5, const void* wfrag2, void* g2, float* pool, void* stream);
+
 /* y = shortcut + beta * body[7](ca * g2) (gshift_deblur1.py:201,210,254): beta and the optional bias are folded
  * into wfrag/bias; the shortcut is the ROLLED tensor for CAB2 (mode 1/2) and x for CAB1 (mode 0). */
 int sn_scale_gemm_res(const sn_unit_src* s, const void* g2, const float* ca, const void* wfrag, const float* bias,

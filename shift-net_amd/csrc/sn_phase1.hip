@@ -38,7 +38,7 @@ struct P1Args {
     const bf16_t* x; const bf16_t* hwb;
     int T, h, w, mode, wrap;
     const uint4* wfrag1; const float* bias; const float* wsum;
-    const uint4* w3; const uint2* w5;
+    const uint32_t* w3; const uint32_t* w5;
     const uint4* wfrag2;
     bf16_t* g2; float* pool;
     int nsx, nsy, seg, vw;
@@ -59,13 +59,13 @@ __device__ __forceinline__ uint32_t as_u(h2_t h) { return __builtin_bit_cast(uin
 // edge there is no neighbour: zeros (those columns are halo, their results are never used).
 template <int N> __device__ __forceinline__ uint32_t from_left(uint32_t prev, uint32_t cur, bool has_prev) {
     if (!has_prev) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur, 0x110 + N, 0xf, 0xf, true);
-    const int t = __builtin_amdgcn_update_dpp(0, (int)prev, 0x120 + N, 0xf, 0xf, false);
+    const int t = __builtin_amdgcn_mov_dpp((int)prev, 0x120 + N, 0xf, 0xf, false);      // every lane has a source in a rotate: no `old` value needed
     return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)cur, 0x110 + N, 0xf, 0xf, false);
 }
 // ... N columns to the RIGHT (x + N): lanes p < 16 - N take cur[p + N] (row_shl:N), the others the right neighbour's first N lanes (row_ror:16-N)
 template <int N> __device__ __forceinline__ uint32_t from_right(uint32_t next, uint32_t cur, bool has_next) {
     if (!has_next) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur, 0x100 + N, 0xf, 0xf, true);
-    const int t = __builtin_amdgcn_update_dpp(0, (int)next, 0x120 + 16 - N, 0xf, 0xf, false);
+    const int t = __builtin_amdgcn_mov_dpp((int)next, 0x120 + 16 - N, 0xf, 0xf, false);
     return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)cur, 0x100 + N, 0xf, 0xf, false);
 }
 
@@ -76,9 +76,12 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
     constexpr int C = 64, CH = 32, K = 32 * KS, MT = 8, RWD = 16 * NX;
     constexpr int PSX = KS == 2 ? 160 : 224;                                  // LDS bytes per pixel of a staged input row (10 / 14 slots: 2 mod 4)
     static_assert(KS == 2 || KS == 3, "K = C (CAB1) or C + C/2 (CAB2)");
-    static_assert(RWD * 4 == 256, "staging: one thread per (region pixel, 8-channel piece of a k-step)");
-    __shared__ __attribute__((aligned(16))) uint4 lds_w3[4][9][4];           // [wave][tap][g] -> 4 words: (a-ch r0|r1), (r2|r3), partners (r0|r1), (r2|r3)
-    __shared__ __attribute__((aligned(16))) uint2 lds_w5[4][25][4];          // [wave][tap][g] -> 2 words: (g1-ch r0|r1), (r2|r3)
+    static_assert(RWD * 4 <= 256, "staging: one thread per (region pixel, 8-channel piece of a k-step)");
+    // stencil weights, packed fp16 pairs, one 32-byte record per (pass, kernel row): [wave][g][pass][row][8 words]
+    //   3x3 pass kp: words 2 tx + kk = tap (row, tx) of a-register k = kp + 2 kk (kk = 0: channels (4g+.. r = 2kp, 2kp+1), kk = 1: their gate partners)
+    //   5x5 pass k : words tx = tap (row, tx) of g1-register k (channels r = 2k, 2k+1)
+    __shared__ __attribute__((aligned(16))) uint32_t lds_w3[4][4][2][3][8];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_w5[4][4][2][5][8];
     __shared__ __attribute__((aligned(16))) uint4 lds_w2[4][2][2][64];       // [wave][M-tile of the pair][k-step][lane]: second 1x1, fp16 fragments
     __shared__ __attribute__((aligned(16))) char lds_x[2][RWD * PSX];        // staged raw input rows (ring of 2)
     __shared__ __attribute__((aligned(8))) float2 lds_st[2][RWD];            // (rstd, -rstd * mean) per pixel of the staged row
@@ -90,8 +93,8 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
     const int h = A.h, w = A.w, hw = h * w;
 
     // ---- per-wave constants -> LDS (wave-private slices: no barrier needed, the LDS operations of one wave execute in order) ----
-    for (int e = lane; e < 36; e += 64) lds_w3[q][e >> 2][e & 3] = A.w3[q * 36 + e];
-    for (int e = lane; e < 100; e += 64) lds_w5[q][e >> 2][e & 3] = A.w5[q * 100 + e];
+    for (int e = lane; e < 4 * 2 * 3 * 8; e += 64) (&lds_w3[q][0][0][0][0])[e] = A.w3[q * (4 * 2 * 3 * 8) + e];
+    for (int e = lane; e < 4 * 2 * 5 * 8; e += 64) (&lds_w5[q][0][0][0][0])[e] = A.w5[q * (4 * 2 * 5 * 8) + e];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
     //       of its pixel, s = 0..KS-1 -- exactly the B fragments of lane group g = c4 -- HBM -> registers -> LDS, one row
     //      AHEAD, and derives the LayerNorm statistics of the pixel (each input row is read and reduced once per team, not once per wave)
     const int spx = tid >> 2, c4 = tid & 3;
+    const bool stager = tid < RWD * 4;                                        // (NX = 3: the last wave has no staging work)
     int f0 = t, o0 = 0, f1 = t, o1 = CH;
     if (A.mode == 1) { if (t > 0 || A.wrap) { f0 = sn_prev_frame(t, A.T, A.wrap); o0 = CH; f1 = t; o1 = 0; } }
     else if (A.mode == 2) { if (t < A.T - 1 || A.wrap) { f0 = t; o0 = CH; f1 = sn_next_frame(t, A.T, A.wrap); o1 = 0; } }
@@ -124,11 +128,12 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
     uint4 Xr[KS];
     auto issue_row = [&](int y) {
         const int yc = (y >= 0 && y < h) ? y : 0;
-        const int ii = yc * w + sgxc;
+        const int ii = stager ? yc * w + sgxc : 0;
 #pragma unroll
         for (int s = 0; s < KS; ++s) Xr[s] = *(const uint4*)(slab[s] + (size_t)ii * sstride[s]);
     };
     auto stage_row = [&](int slot) {                                          // registers -> LDS + statistics of the pixel
+        if (!stager) return;                                                  // wave-uniform
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -172,6 +177,21 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
         const int yin = Y0 - 3 + j;                                           // input row of this iteration (staged in slot j & 1)
         const bool rowin = yin >= 0 && yin < h;
         issue_row(yin + 1);                                                   // next row: in flight during everything below (rows past the end re-read a valid row)
+        // Weight records are fetched ONE GROUP AHEAD (group = one kernel row of one pass: 4 NX .. 6 NX packed FMAs) into two alternating
+        // register sets, with scheduling fences between the groups: left alone, the scheduler hoists all 34 LDS reads of an iteration to
+        // its top (86 more live registers, spills at two waves per SIMD).
+        uint32_t wb[2][6];
+        const uint32_t* w3p = &lds_w3[q][g][0][0][0];
+        const uint32_t* w5p = &lds_w5[q][g][0][0][0];
+        auto ld3 = [&](int kp, int ty, uint32_t* d) {
+            const uint4 a4 = *(const uint4*)(w3p + (kp * 3 + ty) * 8); const uint2 b2 = *(const uint2*)(w3p + (kp * 3 + ty) * 8 + 4);
+            d[0] = a4.x; d[1] = a4.y; d[2] = a4.z; d[3] = a4.w; d[4] = b2.x; d[5] = b2.y;
+        };
+        auto ld5 = [&](int k, int ty, uint32_t* d) {
+            const uint4 a4 = *(const uint4*)(w5p + (k * 5 + ty) * 8);
+            d[0] = a4.x; d[1] = a4.y; d[2] = a4.z; d[3] = a4.w; d[4] = w5p[(k * 5 + ty) * 8 + 4];
+        };
+        ld3(0, 2, wb[0]);
         // ---- first 1x1 on the RAW operands + LayerNorm epilogue -> a (packed fp16, zero outside the image) ----
         uint32_t ah[NX][4];
         {
@@ -193,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
                 const float a12 = fmaf(rstd, acc1[2], fmaf(tm, ws1.z, bs1.z)), a13 = fmaf(rstd, acc1[3], fmaf(tm, ws1.w, bs1.w));
                 ah[n][0] = in ? cvt_pk_h2(a00, a01) : 0u; ah[n][1] = in ? cvt_pk_h2(a02, a03) : 0u;
                 ah[n][2] = in ? cvt_pk_h2(a10, a11) : 0u; ah[n][3] = in ? cvt_pk_h2(a12, a13) : 0u;
+                if (n & 1) __builtin_amdgcn_sched_barrier(0);                 // two N-tiles' operand reads in flight at a time, not all NX
             }
         }
         // ---- depthwise 3x3 (+identity), scatter form: row yin completes output row yin-1; then SimpleGate.  Two passes: registers
@@ -213,24 +234,25 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
                     }
                 h2_t F[NX][2];
 #pragma unroll
-                for (int ty = 2; ty >= 0; --ty)                               // ty = 2 first: it reads P1 before ty = 1 overwrites it (from P0), then ty = 0 reopens P0
+                for (int ti = 0; ti < 3; ++ti) {                              // ty = 2 first: it reads P1 before ty = 1 overwrites it (from P0), then ty = 0 reopens P0
+                    const int ty = 2 - ti, cur = (kp * 3 + ti) & 1;
+                    if (ti < 2) ld3(kp, ty - 1, wb[cur ^ 1]); else if (kp == 0) ld3(1, 2, wb[cur ^ 1]); else ld5(0, 4, wb[cur ^ 1]);
 #pragma unroll
-                    for (int tx = 0; tx < 3; ++tx) {
-                        const uint4 wq = lds_w3[q][ty * 3 + tx][g];
-                        const uint32_t wv[4] = {wq.x, wq.y, wq.z, wq.w};
+                    for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
                         for (int n = 0; n < NX; ++n)
 #pragma unroll
                             for (int kk = 0; kk < 2; ++kk) {
                                 const int k = kp + 2 * kk;
                                 const h2_t v = as_h2(tx == 0 ? L[n][kk] : (tx == 1 ? ah[n][k] : R[n][kk]));
-                                const h2_t wk = as_h2(wv[k]);
+                                const h2_t wk = as_h2(wb[cur][2 * tx + kk]);
                                 // input row yin is row (y + ty - 1) of output row y = yin + 1 - ty: ty = 2 completes yin-1, 1 feeds yin, 0 opens yin+1
                                 if (ty == 2) F[n][kk] = __builtin_elementwise_fma(v, wk, tx == 0 ? P1[n][k] : F[n][kk]);
                                 else if (ty == 1) P1[n][k] = __builtin_elementwise_fma(v, wk, tx == 0 ? P0[n][k] : P1[n][k]);
                                 else P0[n][k] = tx == 0 ? v * wk : __builtin_elementwise_fma(v, wk, P0[n][k]);
                             }
-                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int n = 0; n < NX; ++n) {                                // SimpleGate; zero padding of the 5x5: g1 is zero outside the image
                     const h2_t m = F[n][0] * F[n][1];
@@ -251,11 +273,12 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
                 S[3][n] = from_right<1>(nx, cur, n + 1 < NX); S[4][n] = from_right<2>(nx, cur, n + 1 < NX);
             }
 #pragma unroll
-            for (int ty = 4; ty >= 0; --ty)                                   // ty = 4 first: it reads Q3 before ty = 3 overwrites it, and so on down to Q0
+            for (int ti = 0; ti < 5; ++ti) {                                  // ty = 4 first: it reads Q3 before ty = 3 overwrites it, and so on down to Q0
+                const int ty = 4 - ti, cur = (6 + k * 5 + ti) & 1;
+                if (ti < 4) ld5(k, ty - 1, wb[cur ^ 1]); else if (k == 0) ld5(1, 4, wb[cur ^ 1]);
 #pragma unroll
                 for (int tx = 0; tx < 5; ++tx) {
-                    const uint2 wq = lds_w5[q][ty * 5 + tx][g];
-                    const h2_t wk = as_h2(k == 0 ? wq.x : wq.y);
+                    const h2_t wk = as_h2(wb[cur][tx]);
 #pragma unroll
                     for (int n = 0; n < NX; ++n) {
                         const h2_t v = as_h2(S[tx][n]);
@@ -267,6 +290,8 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
                         else Q0[n][k] = tx == 0 ? v * wk : __builtin_elementwise_fma(v, wk, Q0[n][k]);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         // ---- hand-over: r row yo = yin - 3 -> ring slot j & 1; next input row + its statistics -> slot (j + 1) & 1; ONE barrier ----
         const int yo = yin - 3;
@@ -302,6 +327,7 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
                     for (int r = 0; r < 4; ++r) psum[r] += v[r];
                     *(uint2*)(A.g2 + (((size_t)t * h + yo) * w + gx) * C + 16 * g + 4 * q) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                 }
+                if (n & 1) __builtin_amdgcn_sched_barrier(0);                 // two N-tiles at a time (operands + accumulators of all NX at once spill)
             }
         }
     }
@@ -317,8 +343,9 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
 }
 
 // row segments per column strip: as few rounds of resident workgroups (2 per CU) as possible, each (segment + 6 warm-up rows) long
-void p1_partition(int T, int h, int w, int ncu, int vw, int& nsx, int& nsy, int& seg) {
-    nsx = (w + vw - 1) / vw;
+void p1_partition(int T, int h, int w, int ncu, int vwmax, int& nsx, int& vw, int& nsy, int& seg) {
+    nsx = (w + vwmax - 1) / vwmax;
+    vw = (w + nsx - 1) / nsx;                                                 // equal strips instead of a nearly empty last one
     long best = -1;
     nsy = 1;
     for (int cand = 1; cand <= (h + 7) / 8; ++cand) {
@@ -337,7 +364,7 @@ int p1_ncu() {
     return ncu;
 }
 
-constexpr int P1_NX = 4, P1_VW = 16 * P1_NX - 6;
+constexpr int P1_NX = 3, P1_VWMAX = 16 * P1_NX - 6;      // NX = 4 needs ~300 registers per lane (spills at two waves per SIMD); 3: 254
 
 }  // namespace
 
@@ -346,8 +373,8 @@ extern "C" {
 int sn_cab_phase1_blocks(int T, int h, int w) {
     const int ncu = p1_ncu();
     if (ncu < 1 || T < 1 || h < 1 || w < 1) return SN_EINVAL;
-    int nsx, nsy, seg;
-    p1_partition(T, h, w, ncu, P1_VW, nsx, nsy, seg);
+    int nsx, vw, nsy, seg;
+    p1_partition(T, h, w, ncu, P1_VWMAX, nsx, vw, nsy, seg);
     return nsx * nsy;
 }
 
@@ -360,9 +387,9 @@ int sn_cab_phase1(const sn_unit_src* s, const void* hw, const void* wfrag1, cons
     if (ncu < 1) return SN_ELAUNCH;
     P1Args A;
     A.x = (const bf16_t*)s->x; A.hwb = (const bf16_t*)hw; A.T = s->T; A.h = s->h; A.w = s->w; A.mode = s->mode; A.wrap = s->wrap;
-    A.wfrag1 = (const uint4*)wfrag1; A.bias = bias; A.wsum = wsum; A.w3 = (const uint4*)w3; A.w5 = (const uint2*)w5; A.wfrag2 = (const uint4*)wfrag2;
-    A.g2 = (bf16_t*)g2; A.pool = pool; A.vw = P1_VW;
-    p1_partition(s->T, s->h, s->w, ncu, P1_VW, A.nsx, A.nsy, A.seg);
+    A.wfrag1 = (const uint4*)wfrag1; A.bias = bias; A.wsum = wsum; A.w3 = w3; A.w5 = w5; A.wfrag2 = (const uint4*)wfrag2;
+    A.g2 = (bf16_t*)g2; A.pool = pool;
+    p1_partition(s->T, s->h, s->w, ncu, P1_VWMAX, A.nsx, A.vw, A.nsy, A.seg);
     const dim3 grid((unsigned)(s->T * A.nsx * A.nsy));
     sn_clear_error();
     if (s->mode) hipLaunchKernelGGL((cab_phase1_kernel<3, P1_NX>), grid, dim3(256), 0, (hipStream_t)stream, A);

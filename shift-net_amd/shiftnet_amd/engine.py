@@ -120,6 +120,10 @@ class Plan:
             u["w_toep5"] = self._dev(prep.pack_toeplitz(w5, 5))           # K3m: 5x5 on the matrix cores
         i += 1
         u["w_gate"] = self._dev(prep.pack_gate_gemm(sd[f"{pre}body.{i}.weight"], c))
+        if c == 64 and not V.grouped_rep and not V.denoise:      # fused phase 1 (sn_cab_phase1): Shift-Net-s deblur
+            p1 = prep.pack_phase1(sd[f"{pre}body.0.weight"], sd[pre + "norm.weight"], sd[pre + "norm.bias"], sd[f"{pre}body.1.conv_2.weight"],
+                                  sd[f"{pre}body.{i - 1}.conv_1.weight"], sd[f"{pre}body.{i - 1}.conv_2.weight"], sd[f"{pre}body.{i}.weight"], c)
+            u["p1"] = {k: self._dev(v) for k, v in p1.items()}
         i += 1
         i += 1
         self.add_ca(f"{pre}ca2", f"{pre}body.{i}."); i += 1
@@ -295,6 +299,7 @@ class Engine:
         raise NotImplementedError("bf16 CABs apply the CALayer scale and the residual in conv2's epilogue (fused_cab_tail)")
 
     # ---- blocks (oracle/shiftnet_oracle.py has the same names) ----------------------------------------------
+    fused_phase1 = True        # Shift-Net-s deblur: sn_cab_phase1 instead of sn_ln_gemm_gate + sn_dw5m_gemm_gate (tests switch it off for A/B)
     fused_cab_tail = True      # Engine32 (one kernel per reference module) runs conv, conv, pool, MLP, scale + residual instead
 
     def cab(self, pre: str, x: Act, extra: Optional[Act] = None) -> Act:
@@ -362,6 +367,20 @@ class Engine:
             hwb = self._new(T, h, w, c // 2)
             self._call("sn_gsts_shiftconv", "sn_gsts_shiftconv", C.byref(src), P.offs.data_ptr(), u["w1"].data_ptr(), hwb.data_ptr(), st)
             hw_ptr = hwb.data_ptr()
+        if "p1" in u and self.fused_phase1:             # phase 1 in ONE kernel: neither a, g1 nor r leave the CU (csrc/sn_phase1.hip)
+            p1 = u["p1"]
+            g2 = self._new(T, h, w, c)
+            nblk = lib.sn_cab_phase1_blocks(T, h, w)
+            if nblk < 1:
+                raise L.ShiftNetLibError(f"sn_cab_phase1_blocks failed with code {nblk}")
+            pool2 = torch.empty((T, nblk, c), dtype=torch.float32, device=self.dev)
+            self._call("sn_cab_phase1", "sn_cab_phase1", C.byref(src), hw_ptr, p1["wfrag1"].data_ptr(), p1["bias"].data_ptr(), p1["wsum"].data_ptr(),
+                       p1["w3"].data_ptr(), p1["w5"].data_ptr(), p1["wfrag2"].data_ptr(), g2.data_ptr(), pool2.data_ptr(), st)
+            ca2 = self.ca_mlp(pre + "ca2", pool2, h * w)
+            y = self._new(T, h, w, c)
+            self._call("sn_scale_gemm_res", "sn_scale_gemm_res", C.byref(src), g2.data_ptr(), ca2.data_ptr(), u["w_out"].data_ptr(), None,
+                       y.data_ptr(), st)
+            return Act(y, c)
         mstencil = not V.grouped_rep                    # depthwise RepConv (C = 64): Toeplitz-MFMA 5x5 on a channel-planar g1
         if mstencil:
             g1 = torch.empty((T, h, c, lib.sn_planar_pitch(w)), dtype=torch.bfloat16, device=self.dev)

@@ -23,7 +23,7 @@ SYMBOLS = [          # include/shiftnet_hip.h, production ABI
     "sn_dw5m_gemm_gate", "sn_gsts_gather", "sn_temporal_roll", "sn_gsts_shiftconv", "sn_scale_gemm_res",
     "sn_ingest_u8", "sn_egress_blocks", "sn_egress_u8", "sn_ssim_blocks", "sn_ssim_u8",
     "sn32_conv2d", "sn32_gsts_gather", "sn32_layernorm", "sn32_gate", "sn32_chan_sum", "sn32_scale_residual", "sn32_ingest",
-    "sn_ln_gemm_gate", "sn_lngate_blocks", "sn_grp5_gemm_gate", "sn_grp5_blocks",
+    "sn_ln_gemm_gate", "sn_lngate_blocks", "sn_grp5_gemm_gate", "sn_grp5_blocks", "sn_cab_phase1", "sn_cab_phase1_blocks",
 ]
 
 
@@ -99,6 +99,8 @@ def load() -> C.CDLL:
     lib.sn_lngate_blocks.argtypes = [ci, ci]
     lib.sn_grp5_gemm_gate.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.sn_grp5_blocks.argtypes = [ci, ci]
+    lib.sn_cab_phase1_blocks.argtypes = [ci, ci, ci]
+    lib.sn_cab_phase1.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.sn_scale_gemm_res.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp, vp]
     lib.sn_ingest_u8.argtypes = [vp, vp, ci, ci, ci, ci, vp]
     lib.sn_egress_blocks.argtypes = []

@@ -195,3 +195,74 @@ def pack_toeplitz(wk: torch.Tensor, k: int) -> torch.Tensor:
     tab[:, :, 0, 7:7 + k] = w
     tab[:, :, 1, 6:6 + k] = w
     return torch.from_numpy(tab).to(torch.bfloat16)
+
+
+# ---- fused phase 1 (csrc/sn_phase1.hip): LayerNorm after the GEMM, depthwise stencils on the MFMA accumulator layout -----------------
+P1_G1_SCALE = 2.0 ** -4      # g1 = a1' * a2' is carried in fp16: the first factor is scaled down, the second 1x1 scaled up (exact powers of two)
+
+
+def pack_frag_f16(wp: np.ndarray) -> torch.Tensor:
+    """pack_frag for v_mfma_f32_16x16x32_f16: the same A-fragment order, fp16 elements."""
+    m, k = wp.shape
+    assert m % 16 == 0 and k % 32 == 0
+    mt, ks = m // 16, k // 32
+    a = wp.reshape(mt, 16, ks, 4, 8).transpose(0, 2, 3, 1, 4).reshape(mt, ks, 64, 8)
+    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.float16)
+
+
+def _h2_words(lo: np.ndarray, hi: np.ndarray) -> np.ndarray:
+    """fp32 arrays -> uint32 words: fp16(lo) in bits 0..15, fp16(hi) in bits 16..31 (round to nearest)."""
+    l16 = lo.astype(np.float16).view(np.uint16).astype(np.uint32)
+    h16 = hi.astype(np.float16).view(np.uint16).astype(np.uint32)
+    return l16 | (h16 << 16)
+
+
+def pack_phase1(w1: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, w_dw3: torch.Tensor, w_dw5: torch.Tensor, w_dw5_3: torch.Tensor,
+                w2: torch.Tensor, c: int) -> Dict[str, torch.Tensor]:
+    """Operands of sn_cab_phase1 for one CAB1 / CAB2 (depthwise RepConv, C = 64).
+
+    w1: body[0] 1x1 [2C, K, 1, 1]; ln_w / ln_b: LayerNorm2d affine [K]; w_dw3: RepConv2.conv_2 [2C, 1, 3, 3]; w_dw5 / w_dw5_3: RepConv.conv_1
+    [C, 1, 5, 5] / conv_2 [C, 1, 3, 3]; w2: body[4] 1x1 [2C, C, 1, 1]  (gshift_deblur2.py:186-258).
+
+    * wfrag1 / bias: as pack_ln_gemm (LayerNorm affine folded, gate-paired rows).  The kernel feeds the RAW input to the MFMA and applies
+      the normalisation afterwards: W (v - mu) rstd = rstd (W v) - rstd mu (W 1), so it also needs wsum = W 1 -- the row sums of the
+      bf16-ROUNDED weights (what the MFMA multiplies by), same order as bias.
+    * Wave q, lane group g, accumulator register r of M-tiles (2q, 2q+1) = a-channels c and C + c with c = 16 g + 4 q + r (rows_gate).  Packed
+      fp16 register k of a lane: k = 0: (r0, r1), 1: (r2, r3) of the first half, 2 / 3: the same of the gate partners.
+      w3: uint32 [4 q][4 g][2 pass][3 ty][8]: pass kp handles registers (kp, kp + 2); word 2 tx + kk = taps (ty, tx) of register kp + 2 kk
+          (identity folded into the centre tap, first-half channels scaled by P1_G1_SCALE); words 6, 7 unused.
+      w5: uint32 [4 q][4 g][2 k][5 ty][8]: word tx = taps (ty, tx) of g1 register k = channels c(r = 2k), c(r = 2k + 1); 3x3 and identity folded.
+    * wfrag2: body[4] / P1_G1_SCALE as fp16 fragments, gate-paired rows, natural K (r is stored in natural channel order)."""
+    g = pack_ln_gemm(w1, ln_w, ln_b, c)
+    assert c == 64
+    mt = c // 8
+    # row sums of the bf16-rounded, LayerNorm-folded weights, in bias (= storage position) order
+    w = w1.detach().float().cpu().numpy().reshape(2 * c, -1)
+    wf = torch.from_numpy(w * ln_w.detach().float().cpu().numpy()[None, :]).to(torch.bfloat16).float().numpy()
+    wsum = np.zeros(2 * c, np.float32)
+    wsum[pos_gate(c)] = wf.sum(1)
+    # 3x3 on a (2C channels), identity folded
+    d3 = w_dw3.detach().float().cpu().numpy().reshape(2 * c, 9).copy()
+    d3[:, 4] += 1.0
+    d3[:c] *= P1_G1_SCALE
+    t3 = np.zeros((4, 4, 2, 3, 8), np.uint32)
+    d5 = pack_dw5(w_dw5, w_dw5_3).numpy()                       # [25][C], 3x3 + identity folded
+    t5 = np.zeros((4, 4, 2, 5, 8), np.uint32)
+    for q in range(4):
+        for gg in range(4):
+            c0 = 16 * gg + 4 * q
+            for kp in range(2):
+                for ty in range(3):
+                    for tx in range(3):
+                        for kk in range(2):
+                            o = kk * c + c0 + 2 * kp
+                            t3[q, gg, kp, ty, 2 * tx + kk] = _h2_words(d3[o, ty * 3 + tx], d3[o + 1, ty * 3 + tx])
+            for k in range(2):
+                for ty in range(5):
+                    for tx in range(5):
+                        t5[q, gg, k, ty, tx] = _h2_words(d5[ty * 5 + tx, c0 + 2 * k], d5[ty * 5 + tx, c0 + 2 * k + 1])
+    w2n = w2.detach().float().cpu().numpy().reshape(2 * c, c) / P1_G1_SCALE
+    wp = np.zeros((16 * mt, 32 * ((c + 31) // 32)), np.float32)
+    wp[rows_gate(c), :c] = w2n
+    return {"wfrag1": g["wfrag"], "bias": g["bias"], "wsum": torch.from_numpy(wsum),
+            "w3": torch.from_numpy(t3.view(np.int32).copy()), "w5": torch.from_numpy(t5.view(np.int32).copy()), "wfrag2": pack_frag_f16(wp)}
