@@ -69,6 +69,12 @@ template <int N> __device__ __forceinline__ uint32_t from_right(uint32_t next, u
     return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)cur, 0x100 + N, 0xf, 0xf, false);
 }
 
+#ifndef P1_ABLATE        // development only (tools/p1_variants.py): skip parts of the kernel to see what the time is made of; results are then wrong
+#define P1_ABLATE 0
+#endif
+#define P1_ON(bit) (!(P1_ABLATE & (bit)))
+#define P1_FENCE() do { if (!P1_ON(256)) __builtin_amdgcn_sched_barrier(0); } while (0)      // fences between the stencil groups measured 19 % SLOWER: off
+constexpr int P1_PSO = 144;          // LDS bytes per pixel of a finished g2 row
 constexpr int P1_PSR = 160;          // LDS bytes per pixel of an r row: 128 + 32 (10 slots of 16 B, 2 mod 4: conflict-free ds_read_b128 lane groups)
 
 template <int KS, int NX>
@@ -83,9 +89,12 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_w3[4][4][2][3][8];
     __shared__ __attribute__((aligned(16))) uint32_t lds_w5[4][4][2][5][8];
     __shared__ __attribute__((aligned(16))) uint4 lds_w2[4][2][2][64];       // [wave][M-tile of the pair][k-step][lane]: second 1x1, fp16 fragments
+    __shared__ __attribute__((aligned(16))) float4 lds_wb[4][4][4];          // [wave][g]{row sums, bias} x {M-tile 2q, 2q+1}: LayerNorm epilogue constants
     __shared__ __attribute__((aligned(16))) char lds_x[2][RWD * PSX];        // staged raw input rows (ring of 2)
     __shared__ __attribute__((aligned(8))) float2 lds_st[2][RWD];            // (rstd, -rstd * mean) per pixel of the staged row
     __shared__ __attribute__((aligned(16))) char lds_r[2][RWD * P1_PSR];     // r rows (ring of 2)
+    __shared__ __attribute__((aligned(16))) char lds_o[2][RWD * P1_PSO];     // finished g2 rows (ring of 2): every wave holds 4 of a pixel's 64 channels,
+                                                                              // the rows leave as 16-byte pieces of whole 128-byte pixels
     const int tid = threadIdx.x, lane = tid & 63, q = wave_id(), g = lane >> 4, p = lane & 15;
     const int b = blockIdx.x, sx = b % A.nsx, sy = (b / A.nsx) % A.nsy, t = b / (A.nsx * A.nsy);
     const int x0 = sx * A.vw, Y0 = sy * A.seg, Y1 = Y0 + A.seg < A.h ? Y0 + A.seg : A.h;
@@ -105,8 +114,10 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
         W1[0][s] = as_frag(A.wfrag1[((2 * q) * KS + s) * 64 + lane]);
         W1[1][s] = as_frag(A.wfrag1[((2 * q + 1) * KS + s) * 64 + lane]);
     }
-    const float4 bs0 = *(const float4*)(A.bias + g * 4 * MT + (2 * q) * 4), bs1 = *(const float4*)(A.bias + g * 4 * MT + (2 * q + 1) * 4);
-    const float4 ws0 = *(const float4*)(A.wsum + g * 4 * MT + (2 * q) * 4), ws1 = *(const float4*)(A.wsum + g * 4 * MT + (2 * q + 1) * 4);
+    if (lane < 16) {                                                          // lane = 4 g' + i: (row sums | bias) x (M-tile 2q | 2q+1) of lane group g'
+        const int gg = lane >> 2, i = lane & 3;
+        lds_wb[q][gg][i] = *(const float4*)((i < 2 ? A.wsum : A.bias) + gg * 4 * MT + (2 * q + (i & 1)) * 4);
+    }
 
     // ---- staging role: thread = (region pixel spx, piece c4): it moves the 8-channel pieces [32 s + 8 c4, +8) of the virtual input u
     //       of its pixel, s = 0..KS-1 -- exactly the B fragments of lane group g = c4 -- HBM -> registers -> LDS, one row
@@ -116,23 +127,28 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
     int f0 = t, o0 = 0, f1 = t, o1 = CH;
     if (A.mode == 1) { if (t > 0 || A.wrap) { f0 = sn_prev_frame(t, A.T, A.wrap); o0 = CH; f1 = t; o1 = 0; } }
     else if (A.mode == 2) { if (t < A.T - 1 || A.wrap) { f0 = t; o0 = CH; f1 = sn_next_frame(t, A.T, A.wrap); o1 = 0; } }
+    // wave-uniform 64-bit frame bases (scalar registers) + 32-bit per-lane element offsets (a frame has < 2^31 elements)
     const bf16_t* slab[KS];
-    int sstride[KS];
+    int sstride[KS], soff[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        if (s == 0) { slab[s] = A.x + (ptrdiff_t)f0 * hw * C + o0 + 8 * c4; sstride[s] = C; }
-        else if (s == 1) { slab[s] = A.x + (ptrdiff_t)f1 * hw * C + o1 + 8 * c4; sstride[s] = C; }
-        else { slab[s] = A.hwb + (size_t)t * hw * CH + 8 * c4; sstride[s] = CH; }
+        if (s == 0) { slab[s] = A.x + (ptrdiff_t)f0 * hw * C; soff[s] = o0 + 8 * c4; sstride[s] = C; }
+        else if (s == 1) { slab[s] = A.x + (ptrdiff_t)f1 * hw * C; soff[s] = o1 + 8 * c4; sstride[s] = C; }
+        else { slab[s] = A.hwb + (size_t)t * hw * CH; soff[s] = 8 * c4; sstride[s] = CH; }
     }
     const int sgx = x0 - 3 + spx, sgxc = (sgx >= 0 && sgx < w) ? sgx : 0;    // clamped column: loads are unconditional, masks come later
-    uint4 Xr[KS];
-    auto issue_row = [&](int y) {
+    // Input rows in flight: DIST = 2 rows ahead with two register sets that swap roles every iteration (loop unrolled by two) when the
+    // registers allow it (CAB1: 247 VGPRs); CAB2 (three k-steps per row) spills with two sets -- and a spill reload issued behind the
+    // prefetch waits for it (vmcnt retires in order) -- so it fetches one row ahead.
+    constexpr int DIST = KS == 2 ? 2 : 1;
+    uint4 XA[KS], XB[DIST == 2 ? KS : 1];
+    auto issue_row = [&](int y, uint4* X) {
         const int yc = (y >= 0 && y < h) ? y : 0;
         const int ii = stager ? yc * w + sgxc : 0;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) Xr[s] = *(const uint4*)(slab[s] + (size_t)ii * sstride[s]);
+        for (int s = 0; s < KS; ++s) X[s] = *(const uint4*)(slab[s] + ((P1_ON(512) ? ii : 0) * sstride[s] + soff[s]));
     };
-    auto stage_row = [&](int slot) {                                          // registers -> LDS + statistics of the pixel
+    auto stage_row = [&](int slot, const uint4* Xr) {                         // registers -> LDS + statistics of the pixel
         if (!stager) return;                                                  // wave-uniform
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -140,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
             *(uint4*)(lds_x[slot] + spx * PSX + (32 * s + 8 * c4) * 2) = Xr[s];
             const uint32_t wd[4] = {Xr[s].x, Xr[s].y, Xr[s].z, Xr[s].w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { s1 = dot2bf(wd[i], 0x3f803f80u, s1); s2 = dot2bf(wd[i], wd[i], s2); }
+            for (int i = 0; i < (P1_ON(1) ? 4 : 0); ++i) { s1 = dot2bf(wd[i], 0x3f803f80u, s1); s2 = dot2bf(wd[i], wd[i], s2); }
         }
         s1 += dpp_mov<0xB1>(s1); s1 += dpp_mov<0x4E>(s1);                     // sum over the 4 lanes of the pixel (quad_perm)
         s2 += dpp_mov<0xB1>(s2); s2 += dpp_mov<0x4E>(s2);
@@ -168,15 +184,85 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
     }
     float psum[4] = {0.f, 0.f, 0.f, 0.f};
     const int nit = (Y1 - Y0) + 6;
-    issue_row(Y0 - 3);
-    stage_row(0);
+    // development only (P1_ABLATE & 2048): s_memtime clocks per phase of the row loop, written over the pool entries at the end
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = P1_ON(2048) ? 0 : __builtin_amdgcn_s_memtime();
+    auto tick = [&](int slot) {
+        if (!P1_ON(4096)) __builtin_amdgcn_sched_barrier(0);                  // variant: scheduling fences at the phase boundaries only
+        if (!P1_ON(2048)) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tacc[slot] += now - tlast; tlast = now;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    issue_row(Y0 - 3, XA);
+    stage_row(0, XA);
+    if (DIST == 2) issue_row(Y0 - 2, XA);
+    // every load of the prologue (weight fragments, bias / row-sum vectors) has landed: without this the compiler keeps conservative
+    // s_waitcnt vmcnt(N) in front of their first uses INSIDE the loop, which in steady state wait for the previous row's stores
+    __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0), expcnt / lgkmcnt untouched
     __syncthreads();
 
-#pragma unroll 1
-    for (int j = 0; j < nit; ++j) {
+    // ---- second 1x1 on a finished r row, SimpleGate2, store, channel sums.  Row yo = Y0 - 6 + jj was written to ring slot jj & 1 at the
+    //      end of iteration jj; it is consumed at the TOP of iteration jj + 1, where its LDS -> MFMA -> exp / rcp -> store chain overlaps
+    //      with the first 1x1 and the stencils of the next row instead of standing alone between the barrier and the loop end ----
+    auto second_gemm = [&](int jj) {
+        const int yo = Y0 - 6 + jj;
+        if (yo < Y0) return;                                                  // workgroup-uniform; rows above the segment are warm-up
+        const char* rs = lds_r[jj & 1];
+        char* os = lds_o[jj & 1];
+        uint4 W2[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) W2[m][s] = lds_w2[q][m][s][lane];
+#pragma unroll
+        for (int n = 0; n < NX; ++n) {
+            const uint4 b0 = *(const uint4*)(rs + (16 * n + p) * P1_PSR + (g * 8) * 2);
+            const uint4 b1 = *(const uint4*)(rs + (16 * n + p) * P1_PSR + (32 + g * 8) * 2);
+            f32x4_t c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+            c0 = mfma16h(W2[0][0], b0, c0); c1 = mfma16h(W2[1][0], b0, c1);
+            c0 = mfma16h(W2[0][1], b1, c0); c1 = mfma16h(W2[1][1], b1, c1);
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = c0[r] * sigmoidf_(c1[r]);
+            const int rc = 16 * n + p, gx = x0 - 3 + rc;
+            const bool ok = rc >= 3 && rc < 3 + A.vw && gx < w;               // own columns of this strip
+#pragma unroll
+            for (int r = 0; r < 4; ++r) psum[r] += ok ? v[r] : 0.f;
+            *(uint2*)(os + rc * P1_PSO + (16 * g + 4 * q) * 2) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        }
+    };
+    // ---- a finished g2 row leaves the CU one barrier after second_gemm wrote it to lds_o: thread = (pixel, 16-byte piece), i.e. whole
+    //      128-byte pixels per 8 consecutive lanes (8-byte stores straight from the accumulator layout cost 170 us per launch) ----
+    auto store_row = [&](int jj) {
+        const int yo = Y0 - 6 + jj;
+        if (yo < Y0) return;                                                  // workgroup-uniform
+        const char* os = lds_o[jj & 1];
+        bf16_t* const g2row = A.g2 + ((size_t)t * h + yo) * w * C;            // wave-uniform row base of the output
+#pragma unroll
+        for (int k = 0; k < (RWD * 8 + 255) / 256; ++k) {
+            const int idx = tid + 256 * k, rc = idx >> 3, c8 = idx & 7, gx = x0 - 3 + rc;
+            const bool ok = idx < RWD * 8 && rc >= 3 && rc < 3 + A.vw && gx < w;
+            const uint4 v = *(const uint4*)(os + (ok ? rc : 0) * P1_PSO + c8 * 16);
+            if (ok && (P1_ON(1024) || A.vw == 12345)) *(uint4*)(g2row + (gx * C + c8 * 8)) = v;
+        }
+    };
+
+    // one row of the walk; Xs: registers holding row yin + 1 (loaded one iteration ago, staged at the end of this one), Xl: free set,
+    // receives row yin + 2
+    auto iteration = [&](const int j, uint4* Xs, uint4* Xl) {
         const int yin = Y0 - 3 + j;                                           // input row of this iteration (staged in slot j & 1)
         const bool rowin = yin >= 0 && yin < h;
-        issue_row(yin + 1);                                                   // next row: in flight during everything below (rows past the end re-read a valid row)
+        tick(7);
+        // Input rows are fetched TWO iterations ahead (HBM round trips under load outlast one iteration: the wait before stage_row was 28 %
+        // of the wave cycles with a distance of one), and BEFORE this iteration's stores in program order: vmcnt retires in order, a
+        // load behind a store would wait for the store's acknowledgement.
+        issue_row(yin + DIST, Xl);
+        __builtin_amdgcn_sched_barrier(0);                                    // ... and they stay HERE: the scheduler otherwise sinks the loads to their use
+        if (j > 1 && P1_ON(64)) store_row(j - 2);
+        if (j > 0 && P1_ON(64)) second_gemm(j - 1);
+        tick(0);
         // Weight records are fetched ONE GROUP AHEAD (group = one kernel row of one pass: 4 NX .. 6 NX packed FMAs) into two alternating
         // register sets, with scheduling fences between the groups: left alone, the scheduler hoists all 34 LDS reads of an iteration to
         // its top (86 more live registers, spills at two waves per SIMD).
@@ -196,13 +282,16 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
         uint32_t ah[NX][4];
         {
             const char* xs = lds_x[j & 1];
+            const float4 ws0 = lds_wb[q][g][0], ws1 = lds_wb[q][g][1], bs0 = lds_wb[q][g][2], bs1 = lds_wb[q][g][3];   // phase-local: 16 registers not held across the stencils
 #pragma unroll
             for (int n = 0; n < NX; ++n) {
                 f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    const bf16x8_t bq = as_frag(*(const uint4*)(xs + (16 * n + p) * PSX + (32 * s + 8 * g) * 2));
-                    acc0 = mfma16(W1[0][s], bq, acc0); acc1 = mfma16(W1[1][s], bq, acc1);
+                    const uint4 bqr = *(const uint4*)(xs + (16 * n + p) * PSX + (32 * s + 8 * g) * 2);
+                    const bf16x8_t bq = as_frag(bqr);
+                    if (P1_ON(2)) { acc0 = mfma16(W1[0][s], bq, acc0); acc1 = mfma16(W1[1][s], bq, acc1); }
+                    else { acc0[0] += __uint_as_float(bqr.x); acc1[1] += __uint_as_float(bqr.w); }
                 }
                 const float2 st = lds_st[j & 1][16 * n + p];
                 const float rstd = st.x, tm = st.y;
@@ -211,11 +300,13 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
                 const float a02 = fmaf(rstd, acc0[2], fmaf(tm, ws0.z, bs0.z)), a03 = fmaf(rstd, acc0[3], fmaf(tm, ws0.w, bs0.w));
                 const float a10 = fmaf(rstd, acc1[0], fmaf(tm, ws1.x, bs1.x)), a11 = fmaf(rstd, acc1[1], fmaf(tm, ws1.y, bs1.y));
                 const float a12 = fmaf(rstd, acc1[2], fmaf(tm, ws1.z, bs1.z)), a13 = fmaf(rstd, acc1[3], fmaf(tm, ws1.w, bs1.w));
-                ah[n][0] = in ? cvt_pk_h2(a00, a01) : 0u; ah[n][1] = in ? cvt_pk_h2(a02, a03) : 0u;
-                ah[n][2] = in ? cvt_pk_h2(a10, a11) : 0u; ah[n][3] = in ? cvt_pk_h2(a12, a13) : 0u;
-                if (n & 1) __builtin_amdgcn_sched_barrier(0);                 // two N-tiles' operand reads in flight at a time, not all NX
+                const uint32_t msk = in ? 0xffffffffu : 0u;                   // AND, not a select of the expressions: no branch around the epilogue
+                ah[n][0] = cvt_pk_h2(a00, a01) & msk; ah[n][1] = cvt_pk_h2(a02, a03) & msk;
+                ah[n][2] = cvt_pk_h2(a10, a11) & msk; ah[n][3] = cvt_pk_h2(a12, a13) & msk;
+                if (n & 1) P1_FENCE();                 // two N-tiles' operand reads in flight at a time, not all NX
             }
         }
+        tick(1);
         // ---- depthwise 3x3 (+identity), scatter form: row yin completes output row yin-1; then SimpleGate.  Two passes: registers
         //      (k, k+2) = a channel pair and its gate partners, so a pass ends with a finished g1 register ----
         h2_t g1h[NX][2];
@@ -229,8 +320,8 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
 #pragma unroll
                     for (int kk = 0; kk < 2; ++kk) {
                         const int k = kp + 2 * kk;
-                        L[n][kk] = from_left<1>(n > 0 ? ah[n - 1][k] : 0u, ah[n][k], n > 0);
-                        R[n][kk] = from_right<1>(n + 1 < NX ? ah[n + 1][k] : 0u, ah[n][k], n + 1 < NX);
+                        L[n][kk] = P1_ON(8) ? from_left<1>(n > 0 ? ah[n - 1][k] : 0u, ah[n][k], n > 0) : ah[n][k];
+                        R[n][kk] = P1_ON(8) ? from_right<1>(n + 1 < NX ? ah[n + 1][k] : 0u, ah[n][k], n + 1 < NX) : ah[n][k];
                     }
                 h2_t F[NX][2];
 #pragma unroll
@@ -238,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
                     const int ty = 2 - ti, cur = (kp * 3 + ti) & 1;
                     if (ti < 2) ld3(kp, ty - 1, wb[cur ^ 1]); else if (kp == 0) ld3(1, 2, wb[cur ^ 1]); else ld5(0, 4, wb[cur ^ 1]);
 #pragma unroll
-                    for (int tx = 0; tx < 3; ++tx)
+                    for (int tx = 0; tx < (P1_ON(4) ? 3 : 1); ++tx)
 #pragma unroll
                         for (int n = 0; n < NX; ++n)
 #pragma unroll
@@ -251,15 +342,16 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
                                 else if (ty == 1) P1[n][k] = __builtin_elementwise_fma(v, wk, tx == 0 ? P0[n][k] : P1[n][k]);
                                 else P0[n][k] = tx == 0 ? v * wk : __builtin_elementwise_fma(v, wk, P0[n][k]);
                             }
-                    __builtin_amdgcn_sched_barrier(0);
+                    P1_FENCE();
                 }
 #pragma unroll
                 for (int n = 0; n < NX; ++n) {                                // SimpleGate; zero padding of the 5x5: g1 is zero outside the image
                     const h2_t m = F[n][0] * F[n][1];
-                    g1h[n][kp] = (rin && colin[n]) ? m : hz;
+                    g1h[n][kp] = as_h2(as_u(m) & ((rin && colin[n]) ? 0xffffffffu : 0u));
                 }
             }
         }
+        tick(2);
         // ---- depthwise 5x5 (3x3 and identity folded), scatter form: g1 row yin-1 completes r row yin-3 ----
         h2_t Rr[NX][2];
 #pragma unroll
@@ -269,15 +361,18 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
             for (int n = 0; n < NX; ++n) {
                 const uint32_t cur = as_u(g1h[n][k]);
                 const uint32_t pv = n > 0 ? as_u(g1h[n - 1][k]) : 0u, nx = n + 1 < NX ? as_u(g1h[n + 1][k]) : 0u;
-                S[0][n] = from_left<2>(pv, cur, n > 0); S[1][n] = from_left<1>(pv, cur, n > 0); S[2][n] = cur;
-                S[3][n] = from_right<1>(nx, cur, n + 1 < NX); S[4][n] = from_right<2>(nx, cur, n + 1 < NX);
+                S[2][n] = cur;
+                if (P1_ON(32)) {
+                    S[0][n] = from_left<2>(pv, cur, n > 0); S[1][n] = from_left<1>(pv, cur, n > 0);
+                    S[3][n] = from_right<1>(nx, cur, n + 1 < NX); S[4][n] = from_right<2>(nx, cur, n + 1 < NX);
+                } else { S[0][n] = cur; S[1][n] = pv; S[3][n] = nx; S[4][n] = cur; }
             }
 #pragma unroll
             for (int ti = 0; ti < 5; ++ti) {                                  // ty = 4 first: it reads Q3 before ty = 3 overwrites it, and so on down to Q0
                 const int ty = 4 - ti, cur = (6 + k * 5 + ti) & 1;
                 if (ti < 4) ld5(k, ty - 1, wb[cur ^ 1]); else if (k == 0) ld5(1, 4, wb[cur ^ 1]);
 #pragma unroll
-                for (int tx = 0; tx < 5; ++tx) {
+                for (int tx = 0; tx < (P1_ON(16) ? 5 : 1); ++tx) {
                     const h2_t wk = as_h2(wb[cur][tx]);
 #pragma unroll
                     for (int n = 0; n < NX; ++n) {
@@ -290,46 +385,43 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
                         else Q0[n][k] = tx == 0 ? v * wk : __builtin_elementwise_fma(v, wk, Q0[n][k]);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                P1_FENCE();
             }
         }
+        tick(3);
         // ---- hand-over: r row yo = yin - 3 -> ring slot j & 1; next input row + its statistics -> slot (j + 1) & 1; ONE barrier ----
-        const int yo = yin - 3;
         char* rs = lds_r[j & 1];
 #pragma unroll
         for (int n = 0; n < NX; ++n)
             *(uint2*)(rs + (16 * n + p) * P1_PSR + (16 * g + 4 * q) * 2) = make_uint2(as_u(Rr[n][0]), as_u(Rr[n][1]));
-        stage_row((j + 1) & 1);
+        tick(4);
+        stage_row((j + 1) & 1, Xs);
+        tick(5);
         // Slot j & 1 of r and slot (j + 1) & 1 of x are complete after this barrier.  Both were last READ before the previous barrier
-        // (r: second 1x1 of iteration j - 2 precedes barrier j - 1; x: first 1x1 of iteration j - 1 precedes barrier j - 1).
-        __syncthreads();
-        // ---- second 1x1 on the finished r row, SimpleGate2, store, channel sums ----
-        if (yo >= Y0) {                                                       // workgroup-uniform; rows above the segment are warm-up
-            uint4 W2[2][2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) W2[m][s] = lds_w2[q][m][s][lane];
-#pragma unroll
-            for (int n = 0; n < NX; ++n) {
-                const uint4 b0 = *(const uint4*)(rs + (16 * n + p) * P1_PSR + (g * 8) * 2);
-                const uint4 b1 = *(const uint4*)(rs + (16 * n + p) * P1_PSR + (32 + g * 8) * 2);
-                f32x4_t c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-                c0 = mfma16h(W2[0][0], b0, c0); c1 = mfma16h(W2[1][0], b0, c1);
-                c0 = mfma16h(W2[0][1], b1, c0); c1 = mfma16h(W2[1][1], b1, c1);
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = c0[r] * sigmoidf_(c1[r]);
-                const int rc = 16 * n + p, gx = x0 - 3 + rc;
-                const bool ok = rc >= 3 && rc < 3 + A.vw && gx < w;           // own columns of this strip
-                if (ok) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) psum[r] += v[r];
-                    *(uint2*)(A.g2 + (((size_t)t * h + yo) * w + gx) * C + 16 * g + 4 * q) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                }
-                if (n & 1) __builtin_amdgcn_sched_barrier(0);                 // two N-tiles at a time (operands + accumulators of all NX at once spill)
-            }
+        // (r: the second 1x1 of row j - 2 runs at the top of iteration j - 1, x: the first 1x1 of iteration j - 1; both precede barrier j - 1).
+        if (P1_ON(128)) __syncthreads();
+        tick(6);
+    };
+#pragma unroll 1
+    for (int j = 0; j < nit; j += 2) {
+        if (DIST == 2) {
+            iteration(j, XA, XB);
+            if (j + 1 < nit) iteration(j + 1, XB, XA);
+        } else {                                        // one set: loaded at the top, staged at the end of the same iteration
+            iteration(j, XA, XA);
+            if (j + 1 < nit) iteration(j + 1, XA, XA);
         }
+    }
+    if (P1_ON(64)) {                                                          // drain: the last two rows of the segment
+        store_row(nit - 2);
+        second_gemm(nit - 1);
+        __syncthreads();
+        store_row(nit - 1);
+    }
+    if (!P1_ON(2048)) {
+        if (lane == 0)
+            for (int k = 0; k < 8; ++k) A.pool[((size_t)t * (A.nsx * A.nsy) + sy * A.nsx + sx) * C + 16 * q + k] = (float)tacc[k];
+        return;
     }
     // channel sums of this (frame, strip, segment) for CALayer2: wave q, lane group g own channels 16 g + 4 q + r
     if (A.pool) {

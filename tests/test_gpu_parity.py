@@ -262,6 +262,53 @@ def _gsts_pieces(eng_sd, name, tag):
     check(f"unit_fwd_ragged{tag}_{name}", to_cpu(out.t, C), O.gsts_unit(sd, blk + "encoder_level1.", x2, False, V), 1.2e-2)
 
 
+@pytest.mark.parametrize("T,h,w", [(3, 7, 21), (2, 5, 9), (2, 13, 70), (3, 40, 200), (2, 97, 130), (1, 64, 42), (1, 3, 40)])
+def test_cab_phase1_fused_kernel(T, h, w, engines):
+    """sn_cab_phase1 (fused LayerNorm -> 1x1 -> dw3x3 -> gate -> dw5x5 -> 1x1 -> gate2, csrc/sn_phase1.hip) alone against the reference's
+    g2 and its channel sums, CAB1 and both CAB2 directions: maps smaller than the 6 warm-up rows / the 48-pixel region, one strip, several
+    strips with a ragged last one, several row segments."""
+    from shiftnet_amd import lib as L
+    name = "gshift_deblur2"
+    eng, sd = engines(name)
+    V = O.VARIANTS[name]
+    C = V.c1
+    x = bf(torch.from_numpy(synth.unit_noise((T, C, h, w), seed=85 + h)))
+    xd = to_dev(x)
+    blk = "stage1.decoder_level1."
+    st = torch.cuda.current_stream().cuda_stream
+
+    def ref_g2(q, v):
+        a = O._conv(sd, f"{q}body.0.", v)
+        a = O._conv(sd, f"{q}body.1.conv_2.", a, groups=a.shape[1]) + a
+        a1, a2 = a.chunk(2, dim=1)
+        b1, b2 = O._conv(sd, f"{q}body.4.", O._rep_conv(sd, f"{q}body.3.", a1 * a2, groups=C)).chunk(2, dim=1)
+        return b1 * torch.sigmoid(b2)
+    for mode, rev, unit in ((0, False, "encoder_level1.1."), (1, False, "encoder_level1.0."), (2, True, "encoder_level1_1.0.")):
+        pre = blk + unit
+        with torch.no_grad():
+            if mode:
+                u = O.gsts_gather(x, rev, V.wrap)
+                hw = bf(O._conv(sd, pre + "conv1.", u[:, C:], groups=C // 2))
+                ref = ref_g2(pre, O.layer_norm_2d(torch.cat((u[:, :C], hw), 1), sd[pre + "norm.weight"], sd[pre + "norm.bias"]))
+                hwd = to_dev(hw)
+            else:
+                ref = ref_g2(pre, O.layer_norm_2d(x, sd[pre + "norm.weight"], sd[pre + "norm.bias"]))
+                hwd = None
+        p1 = eng.P.units[pre]["p1"]
+        src = L.UnitSrc(xd.data_ptr(), T, h, w, C, mode, 1 if (V.wrap and mode) else 0)
+        nblk = eng.lib.sn_cab_phase1_blocks(T, h, w)
+        assert nblk >= 1
+        g2 = torch.full((T, h, w, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+        pool = torch.full((T, nblk, C), float("nan"), dtype=torch.float32, device=DEV)
+        L.check(eng.lib.sn_cab_phase1(C_byref(src), hwd.data_ptr() if hwd is not None else None, p1["wfrag1"].data_ptr(), p1["bias"].data_ptr(),
+                                      p1["wsum"].data_ptr(), p1["w3"].data_ptr(), p1["w5"].data_ptr(), p1["wfrag2"].data_ptr(), g2.data_ptr(),
+                                      pool.data_ptr(), st), "sn_cab_phase1")
+        check(f"phase1_g2_{mode}_{T}x{h}x{w}", to_cpu(g2, C), ref, 1.2e-2)
+        sums = pool.sum(1).cpu()
+        rs = ref.sum((2, 3))
+        assert torch.isfinite(sums).all() and (sums - rs).abs().max().item() <= 1e-2 * max(1.0, rs.abs().max().item())
+
+
 def C_byref(s):
     return ctypes.byref(s)
 
