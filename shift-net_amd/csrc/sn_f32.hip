@@ -5,9 +5,10 @@
 // accumulation is a sequential fp32 FMA chain.  Results match the CPU oracle to fp32 round-off, so a wrong tap, slab,
 // gate half or weight row shows up as an error >> 1e-4 instead of hiding inside bf16 noise.
 //
-// These are direct (not MFMA) kernels: one thread per output element, operands served by L1/L2.  They are a
-// correctness-first path (fp32 FMA rate, ~1/16 of the bf16 MFMA rate on this chip); the bf16 kernels in
-// sn_conv.hip / sn_gsts*.hip are the throughput path.
+// Dense and grouped convolutions run as implicit GEMMs on the fp32 matrix-core instruction v_mfma_f32_16x16x4_f32 (conv32m_kernel:
+// exact fp32 products and sums, 157 TFLOP/s peak = the fp32 vector rate without its load / address overhead); depthwise convolutions
+// and the elementwise operators are direct kernels.  The bf16 kernels in sn_conv.hip / sn_gsts*.hip / sn_phase1.hip are the
+// throughput path.
 #include "sn_common.h"
 #include "../../include/shiftnet_hip.h"
 
@@ -111,6 +112,226 @@ __global__ __launch_bounds__(256) void conv32_kernel(const Conv32K P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution on v_mfma_f32_16x16x4_f32 (dense convs incl. the 1x1 / 2x2 / strided / concatenating / upsampling ones,
+// and the "+" RepConv with groups = C/8).  Operand roles as in the bf16 kernels: weights = A (M = 16 output channels), activations
+// = B (N = 16 pixels).  For this instruction lane l holds A[m = l & 15][k = l >> 4], B[k = l >> 4][n = l & 15] and
+// D[m = 4 (l >> 4) + r][n = l & 15], r = 0..3: one float per operand, k = 4 per instruction.  Which input channel a (lane group g4,
+// step s) slot means is our choice: within a block of 16 input channels lane group g4 takes channels 4 g4 + s in step s, so ONE
+// ds_read_b128 of the staged pixel delivers a lane's B operands of four consecutive MFMAs.
+//   workgroup = TH x TW output pixels x up to MTC M-tiles (blockIdx.z picks the M-chunk), 4 waves, NTW = TH TW / 64 N-tiles per wave;
+//   input patch staged 16 channels at a time in LDS as [pixel][24 floats] (16 + 8 pad: conflict-free ds_read_b128 lane groups),
+//   zero-filled outside the image and beyond the channel count (so ragged widths 3, 14, 18, 22 ... need no special case);
+//   weights straight from global memory (L1 / L2 resident), one float per lane and MFMA, fetched one tap ahead;
+//   grouped convs: an M-tile = two groups of 8 outputs whose inputs are the SAME 16 channels: block-diagonal A (half of it zero).
+constexpr int C32_CB = 32, C32_PSL = C32_CB + 8;      // input channels staged per barrier; LDS floats per pixel (40: conflict-free ds_read_b128 lane groups)
+template <int MTC, int TH, int TW>
+__global__ __launch_bounds__(256) void conv32m_kernel(const Conv32K P) {
+    extern __shared__ __attribute__((aligned(16))) float smem32[];
+    constexpr int NTW = (TH * TW) / 64, XB = TW / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), g4 = lane >> 4, p = lane & 15;
+    const int tiles_y = (P.hout + TH - 1) / TH;
+    const int t = blockIdx.y / tiles_y, ty = blockIdx.y - t * tiles_y, tx = blockIdx.x;
+    const int oy0 = ty * TH, ox0 = tx * TW, co0 = blockIdx.z * MTC * 16;
+    const int rh = (TH - 1) * P.stride + P.k, rw = (TW - 1) * P.stride + P.k, npatch = rh * rw;
+    const int iy0 = oy0 * P.stride - P.pad, ix0 = ox0 * P.stride - P.pad;
+    const int hs = P.in_mode == 1 ? P.hin >> 1 : P.hin, ws = P.in_mode == 1 ? P.win >> 1 : P.win;
+    const bool grouped = P.groups > 1;
+    const int cin_g = P.cin_total / P.groups;                       // dense: all input channels; grouped: 8
+    const int mt_n = min(MTC, (P.cout - co0 + 15) / 16);            // M-tiles of this workgroup that exist
+    // channel blocks this workgroup walks: dense -> ceil(cin / 32) blocks of 32 feeding every M-tile; grouped -> block cb = the 16 input
+    // channels of M-tile cb's two groups (they are the M-tile's own channel range), feeding that M-tile only
+    const int ncb = grouped ? mt_n : (P.cin_total + C32_CB - 1) / C32_CB;
+    const int nsub = grouped ? 1 : 2;                               // 16-channel sub-blocks (4 MFMA steps each) per staged block
+    // single-input tensors whose pixel stride and channel counts are multiples of 4 are staged with 16-byte loads
+    const bool vec = P.n_in == 1 && P.in_mode == 0 && (P.cs0 & 3) == 0 && (P.cin_total & 3) == 0 && ((size_t)P.in0 & 15) == 0;
+
+    f32x4_t acc[MTC][NTW];
+#pragma unroll
+    for (int m = 0; m < MTC; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    int pixbase[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        const int nn = wv * NTW + n, row = nn / XB, xb = nn - row * XB;
+        pixbase[n] = ((row * P.stride) * rw + (xb * 16 + p) * P.stride) * C32_PSL + 4 * g4;
+    }
+    const int ntap = P.k * P.k;
+    const size_t tapstride = (size_t)cin_g * P.cout;               // weights: [tap][cin per group][cout]
+    for (int cb = 0; cb < ncb; ++cb) {
+        const int cbase = grouped ? co0 + 16 * cb : cb * C32_CB;    // first input channel of the block
+        const int nch = grouped ? 16 : C32_CB;
+        __syncthreads();                                            // everybody is done reading the previous block
+        if (vec) {                                                  // element = (pixel, 4 consecutive channels)
+            const int q4 = nch >> 2;
+            for (int e = tid; e < npatch * q4; e += 256) {
+                const int pix = e / q4, c = (e - pix * q4) * 4, ci = cbase + c;
+                const int ry = pix / rw, rx = pix - ry * rw, gy = iy0 + ry, gx = ix0 + rx;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ci < P.cin_total && gy >= 0 && gy < P.hin && gx >= 0 && gx < P.win)
+                    v = *(const float4*)(P.in0 + (((size_t)t * hs + gy) * ws + gx) * P.cs0 + ci);
+                *(float4*)(smem32 + pix * C32_PSL + c) = v;
+            }
+        } else {
+            for (int e = tid; e < npatch * nch; e += 256) {
+                const int pix = e / nch, c = e - pix * nch, ci = cbase + c;
+                const int ry = pix / rw, rx = pix - ry * rw, gy = iy0 + ry, gx = ix0 + rx;
+                float v = 0.f;
+                if (ci < P.cin_total && gy >= 0 && gy < P.hin && gx >= 0 && gx < P.win) {
+                    const float* src = P.in0; int cc = ci, cs = P.cs0;                    // torch.cat of up to three inputs along channels
+                    if (P.n_in > 1 && cc >= P.cin0) { cc -= P.cin0; src = P.in1; cs = P.cs1; if (P.n_in > 2 && cc >= P.cin1) { cc -= P.cin1; src = P.in2; cs = P.cs2; } }
+                    const float* fr = src + (size_t)t * hs * ws * cs;
+                    v = P.in_mode == 0 ? fr[((size_t)gy * ws + gx) * cs + cc] : ld_bilinear32(fr, hs, ws, cs, cc, gy, gx);
+                }
+                smem32[pix * C32_PSL + c] = v;
+            }
+        }
+        __syncthreads();
+        const int m_lo = grouped ? cb : 0, m_hi = grouped ? cb + 1 : mt_n;                // M-tiles this block contributes to
+        for (int sb = 0; sb < nsub; ++sb) {
+            // this lane's A operands: output channel co0 + 16 m + p (A row = lane & 15), input channels 4 g4 + s of the 16-channel sub-block
+            const float* wp[MTC];                                                         // address of (tap 0, s = 0), or null: zero operand
+#pragma unroll
+            for (int m = 0; m < MTC; ++m) {
+                wp[m] = nullptr;
+                const int co = co0 + 16 * m + p;
+                if (m < m_lo || m >= m_hi || co >= P.cout) continue;
+                if (grouped) { if ((g4 >> 1) == (p >> 3)) wp[m] = P.w + (size_t)((4 * g4) & 7) * P.cout + co; }     // the M-tile's other group: zero
+                else { const int ci = cbase + 16 * sb + 4 * g4; if (ci < P.cin_total) wp[m] = P.w + (size_t)ci * P.cout + co; }
+            }
+            const int cleft = grouped ? 4 : P.cin_total - (cbase + 16 * sb + 4 * g4);     // channels of this lane's quad that exist
+            auto wload = [&](int tap, float (&d)[MTC][4]) {
+#pragma unroll
+                for (int m = 0; m < MTC; ++m)
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) d[m][s2] = (wp[m] && s2 < cleft) ? wp[m][tap * tapstride + (size_t)s2 * P.cout] : 0.f;
+            };
+            float wa[MTC][4], wn[MTC][4];
+            wload(0, wa);
+            for (int tap = 0; tap < ntap; ++tap) {
+                wload(tap + 1 < ntap ? tap + 1 : tap, wn);                                 // next tap's weights: in flight during this tap's MFMAs
+                const int dy = tap / P.k, dx = tap - dy * P.k, toff = (dy * rw + dx) * C32_PSL + 16 * sb;
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) {
+                    const float4 b = *(const float4*)(smem32 + pixbase[n] + toff);
+#pragma unroll
+                    for (int m = 0; m < MTC; ++m) {
+                        if (m < m_lo || m >= m_hi) continue;                               // workgroup-uniform
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][0], b.x, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][1], b.y, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][2], b.z, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][3], b.w, acc[m][n], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < MTC; ++m)
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) wa[m][s2] = wn[m][s2];
+            }
+        }
+    }
+    // ---- epilogue: lane (g4, p) holds output channels co0 + 16 m + 4 g4 + r of pixel p of each N-tile (same arithmetic as conv32_kernel) ----
+    const bool vout = P.out_mode == 0 && (P.cout & 3) == 0 && (P.cs_out & 3) == 0 && ((size_t)P.out & 15) == 0 &&
+                      (!P.res || ((P.cs_res & 3) == 0 && ((size_t)P.res & 15) == 0));
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        const int nn = wv * NTW + n, row = nn / XB, xb = nn - row * XB;
+        const int oy = oy0 + row, ox = ox0 + xb * 16 + p;
+        if (oy >= P.hout || ox >= P.wout) continue;
+        const size_t pix = ((size_t)t * P.hout + oy) * P.wout + ox;
+#pragma unroll
+        for (int m = 0; m < MTC; ++m) {
+            if (m >= mt_n) continue;
+            const int c0 = co0 + 16 * m + 4 * g4;
+            if (c0 >= P.cout) continue;
+            if (vout) {                                                                    // four consecutive channels: 16-byte residual load and store
+                float a[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
+                if (P.bias) { const float4 bb = *(const float4*)(P.bias + c0); a[0] += bb.x; a[1] += bb.y; a[2] += bb.z; a[3] += bb.w; }
+                if (P.act == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[r] = a[r] >= 0.f ? a[r] : a[r] * P.prelu;
+                }
+                if (P.oscale) {
+                    const float* os = P.oscale + (size_t)t * P.oscale_stride + c0;
+                    a[0] *= os[0]; a[1] *= os[1]; a[2] *= os[2]; a[3] *= os[3];
+                }
+                if (P.res) { const float4 rr = *(const float4*)(P.res + pix * P.cs_res + c0); a[0] += rr.x; a[1] += rr.y; a[2] += rr.z; a[3] += rr.w; }
+                *(float4*)((float*)P.out + pix * P.cs_out + c0) = make_float4(a[0], a[1], a[2], a[3]);
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = c0 + r;
+                if (c >= P.cout) continue;
+                float a = acc[m][n][r];
+                if (P.bias) a += P.bias[c];
+                if (P.act == 1) a = a >= 0.f ? a : a * P.prelu;
+                if (P.oscale) a *= P.oscale[(size_t)t * P.oscale_stride + c];
+                if (P.res) a += P.res[pix * P.cs_res + c];
+                if (P.out_mode == 0) {
+                    ((float*)P.out)[pix * P.cs_out + c] = a;
+                } else if (P.out_mode == 1) {
+                    const int cc = c >> 2, i = (c >> 1) & 1, jj = c & 1;
+                    ((float*)P.out)[(((size_t)t * 2 * P.hout + 2 * oy + i) * (2 * P.wout) + 2 * ox + jj) * P.cs_out + cc] = a;
+                } else {
+                    const size_t oi = (((size_t)t * P.cout + c) * P.hout + oy) * P.wout + ox;
+                    if (P.nchw_dtype == SN_F32) ((float*)P.out)[oi] = a + ((const float*)P.sc)[oi];
+                    else if (P.nchw_dtype == SN_F16) ((__half*)P.out)[oi] = __float2half(a + __half2float(((const __half*)P.sc)[oi]));
+                    else ((bf16_t*)P.out)[oi] = f_to_bf(a + bf_to_f(((const bf16_t*)P.sc)[oi]));
+                }
+            }
+        }
+    }
+}
+
+template <int MTC, int TH, int TW>
+int launch_conv32m(const Conv32K& K, hipStream_t st) {
+    const int rh = (TH - 1) * K.stride + K.k, rw = (TW - 1) * K.stride + K.k;
+    const size_t lds = (size_t)rh * rw * C32_PSL * sizeof(float);
+    if (lds > 160 * 1024) return SN_EINVAL;
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv32m_kernel<MTC, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return SN_ELAUNCH;
+    const int mt = (K.cout + 15) / 16;
+    dim3 grid((K.wout + TW - 1) / TW, ((K.hout + TH - 1) / TH) * K.T, (mt + MTC - 1) / MTC);
+    hipLaunchKernelGGL((conv32m_kernel<MTC, TH, TW>), grid, dim3(256), lds, st, K);
+    return sn_check_launch();
+}
+
+// Depthwise k x k conv (conv1 of CAB2, RepConv2, the depthwise RepConv of the "-s" variants), NHWC output: one thread = 4 consecutive
+// channels of one output pixel, 16-byte loads of activations, weights and the residual (the generic direct kernel above handled one
+// channel per thread: 2.7 ms for the 160-channel 3x3 at 136 x 224 x 36 against 0.4 ms of memory time).
+__global__ __launch_bounds__(256) void dw32_kernel(const Conv32K P) {
+    const int c4n = P.cout >> 2;
+    const size_t n = (size_t)P.T * P.hout * P.wout * c4n;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e % c4n) * 4;
+        const size_t pix = e / c4n;
+        const int ox = (int)(pix % P.wout), oy = (int)((pix / P.wout) % P.hout), t = (int)(pix / ((size_t)P.wout * P.hout));
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ky = 0; ky < P.k; ++ky) {
+            const int gy = oy - P.pad + ky;
+            if (gy < 0 || gy >= P.hin) continue;
+            for (int kx = 0; kx < P.k; ++kx) {
+                const int gx = ox - P.pad + kx;
+                if (gx < 0 || gx >= P.win) continue;
+                const float4 xv = *(const float4*)(P.in0 + (((size_t)t * P.hin + gy) * P.win + gx) * P.cs0 + c);
+                const float4 wv = *(const float4*)(P.w + (size_t)(ky * P.k + kx) * P.cout + c);
+                acc.x = fmaf(xv.x, wv.x, acc.x); acc.y = fmaf(xv.y, wv.y, acc.y); acc.z = fmaf(xv.z, wv.z, acc.z); acc.w = fmaf(xv.w, wv.w, acc.w);
+            }
+        }
+        float a[4] = {acc.x, acc.y, acc.z, acc.w};
+        if (P.bias) { const float4 bb = *(const float4*)(P.bias + c); a[0] += bb.x; a[1] += bb.y; a[2] += bb.z; a[3] += bb.w; }
+        if (P.act == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = a[r] >= 0.f ? a[r] : a[r] * P.prelu;
+        }
+        if (P.oscale) { const float* os = P.oscale + (size_t)t * P.oscale_stride + c; a[0] *= os[0]; a[1] *= os[1]; a[2] *= os[2]; a[3] *= os[3]; }
+        if (P.res) { const float4 rr = *(const float4*)(P.res + pix * P.cs_res + c); a[0] += rr.x; a[1] += rr.y; a[2] += rr.z; a[3] += rr.w; }
+        *(float4*)((float*)P.out + pix * P.cs_out + c) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+}
+
 struct Unit32 { const float* x; int T, h, w, C, mode, wrap; };
 
 // u = cat(roll(x), spatial_shift2(borrowed half)) (gshift_deblur1.py:504-528); CU = 3C/2, or C for the roll alone (Shift_CAB)
@@ -138,19 +359,27 @@ __global__ void gather32_kernel(const Unit32 U, const int8_t* offs, float* u, co
     }
 }
 
-// LayerNorm2d (gshift_deblur1.py:19-28): per pixel over K channels, biased variance, eps inside the sqrt
-__global__ void layernorm32_kernel(const float* x, int cs_x, int K, const float* w, const float* b, float* out, int cs_out, size_t npix) {
-    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
-        const float* xp = x + p * cs_x;
+// LayerNorm2d (gshift_deblur1.py:19-28): per pixel over K channels, biased variance, eps inside the sqrt.  16 lanes (one DPP row) per
+// pixel: lane i takes channels i, i + 16, ... (64-byte coalesced segments), the two reductions are DPP row sums.  K <= 128.
+__global__ __launch_bounds__(256) void layernorm32_kernel(const float* x, int cs_x, int K, const float* w, const float* b, float* out, int cs_out, size_t npix) {
+    const int i = threadIdx.x & 15;
+    for (size_t p = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4); p < npix + 15; p += (size_t)gridDim.x * 16) {      // (whole rows stay converged for the DPP sums)
+        const bool live = p < npix;
+        const float* xp = x + (live ? p : 0) * cs_x;
+        float v[8];
         float mu = 0.f;
-        for (int c = 0; c < K; ++c) mu += xp[c];
-        mu /= (float)K;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int c = i + 16 * j; v[j] = c < K ? xp[c] : 0.f; mu += v[j]; }
+        mu = row_sum16(mu) / (float)K;
         float var = 0.f;
-        for (int c = 0; c < K; ++c) { const float d = xp[c] - mu; var += d * d; }
-        var /= (float)K;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = (i + 16 * j) < K ? v[j] - mu : 0.f; var += d * d; }
+        var = row_sum16(var) / (float)K;
         const float rstd = 1.0f / sqrtf(var + 1e-6f);
+        if (!live) continue;
         float* op = out + p * cs_out;
-        for (int c = 0; c < K; ++c) op[c] = (xp[c] - mu) * rstd * w[c] + b[c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int c = i + 16 * j; if (c < K) op[c] = (v[j] - mu) * rstd * w[c] + b[c]; }
     }
 }
 
@@ -230,6 +459,18 @@ int sn32_conv2d(const sn32_conv_desc* d, void* stream) {
     K.w = d->w; K.bias = d->bias; K.act = d->act; K.prelu = d->prelu; K.oscale = d->oscale; K.oscale_stride = d->oscale_stride;
     K.res = d->res; K.cs_res = d->cs_res; K.out = d->out; K.cs_out = d->cs_out; K.out_mode = d->out_mode; K.nchw_dtype = d->nchw_dtype; K.sc = d->sc;
     const size_t n = (size_t)d->T * d->h_out * d->w_out * d->c_out;
+    const int cin_g = K.cin_total / d->groups, cout_g = d->c_out / d->groups;
+    if (d->groups == 1 || (cin_g == 8 && cout_g == 8 && d->c_out % 16 == 0)) {          // matrix cores: dense convs and the "+" RepConv
+        hipStream_t st = (hipStream_t)stream;
+        const int mt = (d->c_out + 15) / 16;
+        if (d->stride == 2) return mt <= 2 ? launch_conv32m<2, 4, 16>(K, st) : launch_conv32m<5, 4, 16>(K, st);
+        return mt == 1 ? launch_conv32m<1, 8, 32>(K, st) : (mt <= 3 ? launch_conv32m<3, 8, 32>(K, st) : launch_conv32m<5, 8, 32>(K, st));
+    }
+    if (d->groups == d->c_out && cin_g == 1 && d->stride == 1 && d->in_mode == 0 && d->out_mode == 0 && (d->c_out & 3) == 0 && (d->cs_in[0] & 3) == 0 &&
+        (d->cs_out & 3) == 0 && (!d->res || (d->cs_res & 3) == 0) && (((size_t)d->in[0] | (size_t)d->out | (size_t)d->res | (size_t)d->w) & 15) == 0) {
+        hipLaunchKernelGGL(dw32_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, K);      // depthwise, 4 channels per thread
+        return sn_check_launch();
+    }
     if ((d->c_out / d->groups) % 4 == 0)      // a thread's four channels share a group (and the weight row is 16-byte aligned: c_out % 4 == 0)
         hipLaunchKernelGGL(conv32_kernel<4>, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, K);
     else
@@ -247,8 +488,8 @@ int sn32_gsts_gather(const sn_unit_src* s, const int8_t* offs, float* u, void* s
 
 int sn32_layernorm(const float* x, int cs_x, int K, const float* w, const float* b, float* out, int cs_out, long long npix, void* stream) {
     sn_clear_error();
-    if (!x || !w || !b || !out || K < 1 || cs_x < K || cs_out < K || npix < 1) return SN_EINVAL;
-    hipLaunchKernelGGL(layernorm32_kernel, dim3(grid_for((size_t)npix)), dim3(256), 0, (hipStream_t)stream, x, cs_x, K, w, b, out, cs_out, (size_t)npix);
+    if (!x || !w || !b || !out || K < 1 || K > 128 || cs_x < K || cs_out < K || npix < 1) return SN_EINVAL;
+    hipLaunchKernelGGL(layernorm32_kernel, dim3(grid_for((size_t)npix * 16)), dim3(256), 0, (hipStream_t)stream, x, cs_x, K, w, b, out, cs_out, (size_t)npix);
     return sn_check_launch();
 }
 
