@@ -60,9 +60,9 @@ def kernel_alg_bytes(fn, meta):
     if meta and meta[0] == "naf":
         _, T, h, w, c, mode = meta
         px = T * h * w * 2
-        return {"sn_gsts_shiftconv": px * c, "sn_scale_gemm_res": px * 3 * c, "sn_ln_gemm_gate": px * (2.5 * c if mode else 2 * c),
-                "sn_dw5m_gemm_gate": px * 2 * c, "sn_grp5_gemm_gate": px * 2 * c,
-                "sn_cab_phase1": px * (2.5 * c if mode else 2 * c)}.get(fn, 0)       # phase 1: read x (+ hw), write g2
+        p1 = px * (2.5 * c if mode else 2 * c)                                       # phase 1: read x (+ hw), write g2 (or g1)
+        return {"sn_gsts_shiftconv": px * c, "sn_gsts_cab2_phase2": px * 3 * c, "sn_cab1_phase2": px * 3 * c, "sn_ln_gemm_gate": p1,
+                "sn_dw5m_gemm_gate": px * 2 * c, "sn_grp5_gemm_gate": px * 2 * c, "sn_gsts_cab2_phase1": p1, "sn_cab1_phase1": p1}.get(fn, 0)
     if meta and meta[0] == "conv":
         _, T, ho, wo, cin, cs_out, k, stride, in_mode, out_mode = meta
         pin = T * ho * wo * stride * stride / (4 if in_mode == 1 else 1)
@@ -303,14 +303,16 @@ def main():
             if fn == "sn_conv2d":                       # one GPU kernel per (M-tiles, tile shape): key by template instance
                 mt = -(-max(meta[5], 1) // 16) if meta[9] != 1 else -(-meta[5] * 4 // 16)
                 key = f"sn_conv2d<mt{mt},{'8x32' if meta[7] == 1 else '4x16'}>"
-            elif fn in ("sn_ln_gemm_gate", "sn_cab_phase1"):
+            elif fn == "sn_ln_gemm_gate":
                 key = f"{fn}<{'cab2' if meta[5] else 'cab1'}>"
+            elif fn in ("sn_gsts_cab2_phase2", "sn_cab1_phase2"):
+                key = "sn_cab_phase2"                    # one GPU kernel behind both entry points
             a = agg.setdefault(key, {"ms": 0.0, "n": 0, "bytes": 0.0, "gsts": bool(meta and meta[0] == "naf")})
             d = e0.elapsed_time(e1)
             a["ms"] += d; a["n"] += 1; a["bytes"] += kernel_alg_bytes(fn, meta)
             if meta and meta[0] == "naf":
                 unit_ms += d
-                if fn == "sn_scale_gemm_res":            # one CAB finished: its fused-unit bytes = read x + write y
+                if fn in ("sn_gsts_cab2_phase2", "sn_cab1_phase2"):            # one CAB finished: its fused-unit bytes = read x + write y
                     unit_bytes += 2 * meta[1] * meta[2] * meta[3] * meta[4] * 2
                     n_cabs += 1
         eng.prof = None
@@ -321,10 +323,10 @@ def main():
         # coalesced reads on gfx950.  A figure below 0.9 x the algorithmic bytes cannot be right (every input is read at least once):
         # it is then reported as null with the reason (round 2's file averaged in the launches of a small parity clip).
         SYM = {"sn_dw5m_gemm_gate": "dw5m_gemm_gate_kernel", "sn_ln_gemm_gate<cab2>": "ln_gemm_gate_kernel<64, true>",
-               "sn_ln_gemm_gate<cab1>": "ln_gemm_gate_kernel<64, false>", "sn_scale_gemm_res": "scale_gemm_res_kernel<64",
+               "sn_ln_gemm_gate<cab1>": "ln_gemm_gate_kernel<64, false>", "sn_cab_phase2": "scale_gemm_res_kernel<64",
                "sn_gsts_shiftconv": "shiftconv_kernel<32", "sn_conv2d<mt1,8x32>": "conv3_fast_kernel<1, 16, 8>",
                "sn_conv2d<mt2,8x32>": "conv3_fast_kernel<2, 24, 8>", "sn_ca_mlp": "ca_mlp_kernel",
-               "sn_cab_phase1<cab1>": "cab_phase1_kernel<2", "sn_cab_phase1<cab2>": "cab_phase1_kernel<3"}
+               "sn_cab1_phase1": "cab_phase1_kernel<2", "sn_gsts_cab2_phase1": "cab_phase1_kernel<3"}
         pmc, pmc_note = None, "no PMC file under profiles/"
         headline = (args.variant, h, w, L, args.dtype, len(quads)) == (VARIANT, H, W, ONE_LEN, "bf16", 1)
         try:

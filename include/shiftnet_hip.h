@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 3      /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
+#define SN_ABI_VERSION 5      /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
 
 /* element types of NCHW tensors exchanged with the PyTorch side */
 #define SN_F32 0
@@ -103,10 +103,15 @@ typedef struct sn_unit_src {
     int T, h, w, C;      /* C in {64, 80} */
     int mode;            /* 0: CAB1 (no shift, u = x[t]); 1: CAB2 of a forward unit; 2: CAB2 of a reverse unit */
     int wrap;            /* 0: boundary frame kept (gshift_deblur1.py:513,517); 1: circular temporal roll (gshift_deblur2.py:504-505);
-                            2: the neighbour of the boundary frame lives in the HALO slot just outside x -- frame index -1 for
-                            a forward unit, T for a reverse unit -- i.e. x points at frame 1 of a [T+2]-frame allocation whose
-                            outer frames were filled by the adjacent rank of a temporally split window (only the borrowed
-                            half-channels of the slot are read) */
+                            2: x is a frame range of a temporally split window and the neighbour of its boundary frame (frame -1 for a
+                            forward unit, T for a reverse unit) belongs to the adjacent rank: only the half the unit borrows exists
+                            here, in `halo` */
+    const void* halo;    /* wrap == 2, mode 1 / 2: the neighbour frame's borrowed half-channels, CONTIGUOUS [h][w][C/2] (same element type
+                            as x): forward units the upper half of the previous rank's last frame, reverse units the lower half of the
+                            next rank's first frame -- the receive buffer of the halo exchange itself, no copy into a strided slot */
+    int t0, nt;          /* frames [t0, t0 + nt) of x are processed (nt == 0: all T).  Outputs, pool rows and the neighbour rule are indexed
+                            by the absolute frame, so a unit can be launched in pieces: the frames that need no halo while the exchange is
+                            in flight, the boundary frame after it */
 } sn_unit_src;
 
 /* validation op: materialise u = cat(y, spatial_shift2(hw)) : [T][h][w][3C/2] exactly as channel_shift returns it
@@ -159,22 +164,37 @@ int sn_dw5m_blocks(int h, int w);
 int sn_dw5m_gemm_gate(const void* g1p, const float* ca_in, const void* ttab, const void* wfrag, void* g2, float* pool,
                       int T, int h, int w, int C, void* stream);
 
-/* ---- fused phase 1 of CAB1 / CAB2, depthwise variants without the inner CALayer2 (C = 64: Shift-Net-s deblur), csrc/sn_phase1.hip ----
- * g2 = SimpleGate2(body[4](RepConv(SimpleGate(RepConv2(body[0](norm(u)))))))  (gshift_deblur2.py:186-214 CAB1, :215-258 CAB2) in ONE kernel:
- * u is read once, g2 written once; `a`, g1 and r never reach HBM (what sn_ln_gemm_gate + sn_dw5m_gemm_gate do in two kernels with g1 in
- * HBM).  s / hw: as for sn_ln_gemm_gate (hw = sn_gsts_shiftconv's output for mode 1 / 2, NULL for mode 0).
- * wfrag1, bias, wsum, w3, w5, wfrag2: prep.pack_phase1 (LayerNorm folded and applied after the 1x1: wsum = row sums of the bf16 weights;
- * w3 / w5: packed-fp16 stencil tables in accumulator-lane order; wfrag2: fp16 fragments of body[4]).
- * g2: [T][h][w][C] NHWC bf16.  pool: NULL or [T][sn_cab_phase1_blocks(T,h,w)][C] f32 partial channel sums of g2 (CALayer2, finished by
- * sn_ca_mlp).  sn_cab_phase1_blocks queries the current device (the work split depends on its CU count); < 0 on error. */
-int sn_cab_phase1_blocks(int T, int h, int w);
-int sn_cab_phase1(const sn_unit_src* s, const void* hw, const void* wfrag1, const float* bias, const float* wsum, const uint32_t* w3,
-                  const uint32_t* w5, const void* wfrag2, void* g2, float* pool, void* stream);
+/* ---- the two phases of a GSTS unit's blocks (sn_gsts_cab2_phase1 / phase2, sn_cab1_phase1 / phase2) --------------------
+ * The global average pool of CALayer2 (gshift_deblur1.py:76-87) is the one grid-wide dependency inside CAB2 / CAB1, so a block is two
+ * passes over the frame: phase 1 up to g2 and its channel sums, [sn_ca_mlp on the sums], phase 2 from g2 to the block's output.
+ *
+ * PHASE 1, fused, depthwise variants without the inner CALayer2 (C = 64: Shift-Net-s deblur), csrc/sn_phase1.hip:
+ *   g2 = SimpleGate2(body[4](RepConv(SimpleGate(RepConv2(body[0](norm(u)))))))   (gshift_deblur2.py:186-214 CAB1, :215-258 CAB2)
+ * in ONE kernel: u is read once, g2 written once; `a`, g1 and r never reach HBM.  (The other variants run phase 1 as sn_ln_gemm_gate +
+ * sn_dw5m_gemm_gate / sn_grp5_gemm_gate with g1 in HBM.)  sn_gsts_cab2_phase1: s->mode 1 / 2, hw = sn_gsts_shiftconv's output;
+ * sn_cab1_phase1: s->mode 0.  Weights: prep.pack_phase1 --
+ *   wfrag1  bf16 A fragments of body[0] (LayerNorm affine folded, gate-paired rows) [8][K/32][64][8];
+ *   wfragx  bf16 [8][16][8]: k-slots 0..7 of the LayerNorm k-step of every row: (W1 hi, W1 lo, W1 hi, W1 lo, b hi, b lo, b hi, b lo), W1 = the
+ *           row sum of the bf16 weights, b = the folded bias: the kernel feeds the RAW input to the MFMA and normalises afterwards;
+ *   w3 / w5 packed-fp16 stencil tables in accumulator-lane order; wfrag2: fp16 A fragments of body[4] (sigmoid rows times -log2 e).
+ * g2: [T][h][w][C] NHWC bf16.  pool: NULL or [T][sn_phase1_pool_blocks(T,h,w)][C] f32 partial channel sums of g2 (CALayer2, finished by
+ * sn_ca_mlp).  sn_phase1_pool_blocks queries the current device (the work split depends on its CU count); < 0 on error. */
+typedef struct sn_phase1_weights {
+    const void* wfrag1;
+    const void* wfragx;
+    const uint32_t* w3;
+    const uint32_t* w5;
+    const void* wfrag2;
+} sn_phase1_weights;
+int sn_phase1_pool_blocks(int T, int h, int w);
+int sn_gsts_cab2_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, void* stream);
+int sn_cab1_phase1(const sn_unit_src* s, const sn_phase1_weights* wt, void* g2, float* pool, void* stream);
 
-/* y = shortcut + beta * body[7](ca * g2) (gshift_deblur1.py:201,210,254): beta and the optional bias are folded
- * into wfrag/bias; the shortcut is the ROLLED tensor for CAB2 (mode 1/2) and x for CAB1 (mode 0). */
-int sn_scale_gemm_res(const sn_unit_src* s, const void* g2, const float* ca, const void* wfrag, const float* bias,
-                      void* y, void* stream);
+/* PHASE 2, all variants (C = 64 / 80): y = shortcut + beta * body[7](ca * g2) (gshift_deblur1.py:201,210,254): beta and the optional bias
+ * are folded into wfrag / bias; the shortcut is the ROLLED tensor for CAB2 (s->mode 1 / 2: sn_gsts_cab2_phase2) and x itself for CAB1
+ * (s->mode 0: sn_cab1_phase2).  ca: [T][C] f32 from sn_ca_mlp. */
+int sn_gsts_cab2_phase2(const sn_unit_src* s, const void* g2, const float* ca, const void* wfrag, const float* bias, void* y, void* stream);
+int sn_cab1_phase2(const sn_unit_src* s, const void* g2, const float* ca, const void* wfrag, const float* bias, void* y, void* stream);
 
 
 /* ---- fp32-storage path (csrc/sn_f32.hip) -----------------------------------------------------------------------

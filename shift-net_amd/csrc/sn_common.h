@@ -96,12 +96,33 @@ __device__ __forceinline__ float sum_rows4(float x) {
     return c + d;
 }
 
-// Temporal neighbour of frame t for the half-channel roll (gshift_deblur1.py:504-518).  `wrap`: 0 = the boundary frame is kept
-// (callers never ask for its neighbour), 1 = circular inside the tensor (gshift_deblur2.py:504-505), 2 = the neighbour lives in
-// the HALO slot just outside the tensor -- frame index -1 / T -- filled by the adjacent rank of a temporally split window
-// (shiftnet_amd/temporal_split.py); frame offsets are therefore computed in ptrdiff_t.
-__device__ __forceinline__ int sn_prev_frame(int t, int T, int wrap) { return t > 0 ? t - 1 : (wrap == 2 ? -1 : T - 1); }
-__device__ __forceinline__ int sn_next_frame(int t, int T, int wrap) { return t < T - 1 ? t + 1 : (wrap == 2 ? T : 0); }
+// Where the half-channel slabs of the virtual 1.5 C-channel input u of a GSTS unit come from (gshift_deblur1.py:504-528
+// keep, gshift_deblur2.py:499-519 circular).  Every slab is C/2 consecutive channels of one frame: element (pixel i, channel c) of
+//   u[:, :C/2]  = p0[i * s0 + c],   u[:, C/2:C] = p1[i * s1 + c],   borrowed half (input of the spatial shift) = pb[i * sb + c].
+// mode 0: CAB1, u = x[t].  mode 1 / 2: forward / reverse unit.  wrap 0: the window's boundary frame is kept un-rolled; 1: circular roll
+// inside the tensor; 2: the boundary frame's neighbour belongs to the adjacent rank of a temporally split window
+// (shiftnet_amd/temporal_split.py) and only its borrowed half exists here, as the contiguous [h][w][C/2] buffer `halo` (pixel stride C/2).
+// frame sub-range of an sn_unit_src: (first frame, count); false when it does not lie inside [0, T)
+#define SN_FRAME_RANGE(s, T0, NT) const int T0 = (s)->nt > 0 ? (s)->t0 : 0, NT = (s)->nt > 0 ? (s)->nt : (s)->T; \
+    if (T0 < 0 || NT < 1 || T0 + NT > (s)->T) return SN_EINVAL
+template <typename E> struct SnSlabs { const E* p0; const E* p1; const E* pb; int s0, s1, sb; };
+template <typename E>
+__device__ __forceinline__ SnSlabs<E> sn_unit_slabs(const E* x, const E* halo, int T, int hw, int C, int mode, int wrap, int t) {
+    const int Ch = C >> 1;
+    const E* xt = x + (ptrdiff_t)t * hw * C;
+    SnSlabs<E> s;
+    s.p0 = xt; s.p1 = xt + Ch; s.pb = xt; s.s0 = s.s1 = s.sb = C;
+    if (mode == 1) {                                   // forward: u[:, :Ch] = x[t-1][Ch:], u[:, Ch:] = x[t][:Ch], borrowed = x[t-1][Ch:]
+        if (t > 0 || wrap == 1) { s.p0 = x + (ptrdiff_t)(t > 0 ? t - 1 : T - 1) * hw * C + Ch; s.p1 = xt; s.pb = s.p0; }
+        else if (wrap == 2) { s.p0 = halo; s.s0 = Ch; s.p1 = xt; s.pb = halo; s.sb = Ch; }
+        else s.pb = xt;                                // kept boundary frame: borrowed = its own lower half
+    } else if (mode == 2) {                            // reverse: u[:, :Ch] = x[t][Ch:], u[:, Ch:] = x[t+1][:Ch], borrowed = x[t+1][:Ch]
+        if (t < T - 1 || wrap == 1) { s.p0 = xt + Ch; s.p1 = x + (ptrdiff_t)(t < T - 1 ? t + 1 : 0) * hw * C; s.pb = s.p1; }
+        else if (wrap == 2) { s.p0 = xt + Ch; s.p1 = halo; s.s1 = Ch; s.pb = halo; s.sb = Ch; }
+        else s.pb = xt + Ch;                           // kept boundary frame: borrowed = its own upper half
+    }
+    return s;
+}
 
 // wave-uniform wave index (threadIdx-derived values are "divergent" to the compiler; make it provably uniform)
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }

@@ -332,28 +332,22 @@ __global__ __launch_bounds__(256) void dw32_kernel(const Conv32K P) {
     }
 }
 
-struct Unit32 { const float* x; int T, h, w, C, mode, wrap; };
+struct Unit32 { const float* x; const float* halo; int T, h, w, C, mode, wrap, t0; };
 
 // u = cat(roll(x), spatial_shift2(borrowed half)) (gshift_deblur1.py:504-528); CU = 3C/2, or C for the roll alone (Shift_CAB)
 __global__ void gather32_kernel(const Unit32 U, const int8_t* offs, float* u, const int CU) {
-    const int t = blockIdx.y, Ch = U.C >> 1, hw = U.h * U.w;
-    int f0 = t, o0 = 0, f1 = t, o1 = Ch, fb = t, ob = 0;      // SURVEY.md 8a-1 table (same as sn_gsts.hip::unit_slabs)
-    if (U.mode == 1) {
-        if (t > 0 || U.wrap) { f0 = sn_prev_frame(t, U.T, U.wrap); o0 = Ch; f1 = t; o1 = 0; fb = f0; ob = Ch; }
-    } else if (U.mode == 2) {
-        if (t < U.T - 1 || U.wrap) { f0 = t; o0 = Ch; f1 = sn_next_frame(t, U.T, U.wrap); o1 = 0; fb = f1; ob = 0; }
-        else { fb = t; ob = Ch; }
-    }
+    const int t = U.t0 + blockIdx.y, Ch = U.C >> 1, hw = U.h * U.w;
+    const SnSlabs<float> s = sn_unit_slabs<float>(U.x, U.halo, U.T, hw, U.C, U.mode, U.wrap, t);      // SURVEY.md 8a-1 table (sn_common.h)
     const size_t n = (size_t)hw * CU;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const int i = (int)(e / CU), c = (int)(e - (size_t)i * CU);
         float v = 0.f;
-        if (c < Ch) v = U.x[((ptrdiff_t)f0 * hw + i) * U.C + o0 + c];
-        else if (c < U.C) v = U.x[((ptrdiff_t)f1 * hw + i) * U.C + o1 + c - Ch];
+        if (c < Ch) v = s.p0[(size_t)i * s.s0 + c];
+        else if (c < U.C) v = s.p1[(size_t)i * s.s1 + c - Ch];
         else {
             const int k = c - U.C, y = i / U.w, x = i - y * U.w;
             const int sy = y + offs[2 * k], sx = x + offs[2 * k + 1];
-            if (sy >= 0 && sy < U.h && sx >= 0 && sx < U.w) v = U.x[(((ptrdiff_t)fb * U.h + sy) * U.w + sx) * U.C + ob + k];
+            if (sy >= 0 && sy < U.h && sx >= 0 && sx < U.w) v = s.pb[((size_t)sy * U.w + sx) * s.sb + k];
         }
         u[(size_t)t * n + e] = v;
     }
@@ -480,9 +474,11 @@ int sn32_conv2d(const sn32_conv_desc* d, void* stream) {
 
 int sn32_gsts_gather(const sn_unit_src* s, const int8_t* offs, float* u, void* stream) {
     sn_clear_error();
-    if (!s || !s->x || !u || (s->C & 1) || s->T < 1 || s->mode < 1 || s->mode > 2) return SN_EINVAL;
-    Unit32 U; U.x = (const float*)s->x; U.T = s->T; U.h = s->h; U.w = s->w; U.C = s->C; U.mode = s->mode; U.wrap = s->wrap;
-    hipLaunchKernelGGL(gather32_kernel, dim3(1024, s->T), dim3(256), 0, (hipStream_t)stream, U, offs, u, offs ? s->C + s->C / 2 : s->C);
+    if (!s || !s->x || !u || (s->C & 1) || s->T < 1 || s->mode < 1 || s->mode > 2 || s->wrap < 0 || s->wrap > 2 || (s->wrap == 2 && !s->halo)) return SN_EINVAL;
+    Unit32 U; U.x = (const float*)s->x; U.halo = (const float*)s->halo; U.T = s->T; U.h = s->h; U.w = s->w; U.C = s->C; U.mode = s->mode; U.wrap = s->wrap;
+    SN_FRAME_RANGE(s, t0, nt);
+    U.t0 = t0;
+    hipLaunchKernelGGL(gather32_kernel, dim3(1024, nt), dim3(256), 0, (hipStream_t)stream, U, offs, u, offs ? s->C + s->C / 2 : s->C);
     return sn_check_launch();
 }
 

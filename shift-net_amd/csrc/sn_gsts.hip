@@ -2,7 +2,7 @@
 //
 // Production kernels of this file:
 //   sn_gsts_shiftconv (K0): hw = dw3x3(spatial_shift(borrowed half))     LDS-staged gather, never materialises the shift
-//   sn_scale_gemm_res (K4): y  = roll(x) + beta * W3 . (ca * g2)         per-pixel MFMA, rolled shortcut
+//   sn_gsts_cab2_phase2 / sn_cab1_phase2 (K4): y  = roll(x) + beta * W3 . (ca * g2)         per-pixel MFMA, rolled shortcut
 //   sn_gsts_gather / sn_temporal_roll: validation op / Shift_CAB roll (pure index work)
 // The temporal roll is only ever an address computation (frame/channel-offset pairs below).
 #include "sn_common.h"
@@ -11,46 +11,28 @@
 namespace {
 
 struct UnitK {
-    const bf16_t* x;
-    int T, h, w, C, mode, wrap;
+    const bf16_t* x; const bf16_t* halo;
+    int T, h, w, C, mode, wrap, t0;
 };
-
-struct Slabs {
-    int f0, o0;   // u[:, :C/2]  = x[f0][o0 : o0 + C/2]
-    int f1, o1;   // u[:, C/2:C] = x[f1][o1 : o1 + C/2]
-    int fb, ob;   // borrowed half (input of the spatial shift) = x[fb][ob : ob + C/2]
-};
-
-// SURVEY.md 8a-1 table; gshift_deblur1.py:504-528 (keep) / gshift_deblur2.py:499-519 (wrap)
-__device__ __forceinline__ Slabs unit_slabs(const UnitK& U, int t) {
-    const int Ch = U.C >> 1;
-    Slabs s;
-    s.f0 = t; s.o0 = 0; s.f1 = t; s.o1 = Ch; s.fb = t; s.ob = 0;
-    if (U.mode == 1) {
-        if (t > 0 || U.wrap) { s.f0 = sn_prev_frame(t, U.T, U.wrap); s.o0 = Ch; s.f1 = t; s.o1 = 0; s.fb = s.f0; s.ob = Ch; }
-        else { s.fb = t; s.ob = 0; }
-    } else if (U.mode == 2) {
-        if (t < U.T - 1 || U.wrap) { s.f0 = t; s.o0 = Ch; s.f1 = sn_next_frame(t, U.T, U.wrap); s.o1 = 0; s.fb = s.f1; s.ob = 0; }
-        else { s.fb = t; s.ob = Ch; }
-    }
-    return s;
+__device__ __forceinline__ SnSlabs<bf16_t> unit_slabs(const UnitK& U, int t) {
+    return sn_unit_slabs<bf16_t>(U.x, U.halo, U.T, U.h * U.w, U.C, U.mode, U.wrap, t);
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // validation op: u = cat(y, shift(hw))
 __global__ void gather_kernel(const UnitK U, const int8_t* offs, bf16_t* u, const int CU) {
-    const int t = blockIdx.y, Ch = U.C >> 1, hw = U.h * U.w;
-    const Slabs s = unit_slabs(U, t);
+    const int t = U.t0 + blockIdx.y, Ch = U.C >> 1, hw = U.h * U.w;
+    const SnSlabs<bf16_t> s = unit_slabs(U, t);
     const size_t n = (size_t)hw * CU;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const int i = (int)(e / CU), c = (int)(e - (size_t)i * CU);
         bf16_t v = 0;
-        if (c < Ch) v = U.x[((ptrdiff_t)s.f0 * hw + i) * U.C + s.o0 + c];
-        else if (c < U.C) v = U.x[((ptrdiff_t)s.f1 * hw + i) * U.C + s.o1 + c - Ch];
+        if (c < Ch) v = s.p0[(size_t)i * s.s0 + c];
+        else if (c < U.C) v = s.p1[(size_t)i * s.s1 + c - Ch];
         else {
             const int k = c - U.C, y = i / U.w, x = i - y * U.w;
             const int sy = y + offs[2 * k], sx = x + offs[2 * k + 1];
-            if (sy >= 0 && sy < U.h && sx >= 0 && sx < U.w) v = U.x[(((ptrdiff_t)s.fb * U.h + sy) * U.w + sx) * U.C + s.ob + k];
+            if (sy >= 0 && sy < U.h && sx >= 0 && sx < U.w) v = s.pb[((size_t)sy * U.w + sx) * s.sb + k];
         }
         u[(size_t)t * n + e] = v;
     }
@@ -69,9 +51,11 @@ __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const Xcd
     constexpr int PCS = CH / 8;
     int t, ty_, tx_;
     if (!sn_xcd_tile(G, t, ty_, tx_)) return;      // XCD-aware walk: the 34-wide windows of x-neighbours overlap by 18 columns
+    t += U.t0;
     const int tid = threadIdx.x, y0 = ty_ * 16, x0 = tx_ * 16;
-    const Slabs s = unit_slabs(U, t);
-    const bf16_t* src = U.x + (ptrdiff_t)s.fb * U.h * U.w * U.C + s.ob;
+    const SnSlabs<bf16_t> s = unit_slabs(U, t);
+    const bf16_t* src = s.pb;
+    const int sstr = s.sb;
     const int px = tid & 15, py = tid >> 4, oy = y0 + py, ox = x0 + px;
     const bool valid = oy < U.h && ox < U.w;
     // interior tiles (every tap position p+tap of every output pixel is inside the image): no conv-padding masks at all,
@@ -93,7 +77,7 @@ __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const Xcd
                 const int gy = y0 - 9 + ry, gx = x0 - 9 + rx;
                 const bool in = idx < RW * RW * np && gy >= 0 && gy < U.h && gx >= 0 && gx < U.w;
                 lo[k] = idx < RW * RW * np ? (in ? pix * PSB + pc * 16 : -(pix * PSB + pc * 16) - 1) : 0x7fffffff;
-                v[k] = *(const uint4*)(src + (in ? ((size_t)gy * U.w + gx) * U.C + (pc0 + pc) * 8 : 0));
+                v[k] = *(const uint4*)(src + (in ? ((size_t)gy * U.w + gx) * sstr + (pc0 + pc) * 8 : 0));
             }
             if (pc0) __syncthreads();                             // every wave is done reading the previous pass
 #pragma unroll
@@ -168,11 +152,12 @@ void scale_gemm_res_kernel(const UnitK U, const bf16_t* __restrict__ g2, const f
                            const uint4* __restrict__ wfrag, const float* __restrict__ bias, bf16_t* y) {
     constexpr int CH = C / 2, KS = (C + 31) / 32, MT = C / 16;
     const int lane = threadIdx.x & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
-    const int t = blockIdx.y, hw = U.h * U.w;
-    const Slabs sl = unit_slabs(U, t);
+    const int t = U.t0 + blockIdx.y, hw = U.h * U.w;
+    const SnSlabs<bf16_t> sl = unit_slabs(U, t);
     const int ibase = blockIdx.x * (64 * NT) + wv * (16 * NT);
     const int c0 = g * 4 * MT;                   // lane (g,p) owns channels [c0, c0 + 4 MT): one contiguous 8*MT-byte run of the shortcut and of y
-    const bf16_t* const sbase = c0 < CH ? U.x + (ptrdiff_t)sl.f0 * hw * C + sl.o0 + c0 : U.x + (ptrdiff_t)sl.f1 * hw * C + sl.o1 + c0 - CH;
+    const bf16_t* const sbase = c0 < CH ? sl.p0 + c0 : sl.p1 + c0 - CH;
+    const int sstr = c0 < CH ? sl.s0 : sl.s1;                                  // pixel stride of this lane's half (C, or C/2 for a halo half-frame)
     bf16x8_t B[NT][KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -213,7 +198,7 @@ void scale_gemm_res_kernel(const UnitK U, const bf16_t* __restrict__ g2, const f
         const int i = ibase + n * 16 + p;
         if (i >= hw) continue;
         uint32_t sc[2 * MT], o[2 * MT];
-        const bf16_t* sp = sbase + (size_t)i * C;
+        const bf16_t* sp = sbase + (size_t)i * sstr;
 #pragma unroll
         for (int m = 0; m + 1 < MT; m += 2) { const uint4 q = *(const uint4*)(sp + m * 4); sc[2 * m] = q.x; sc[2 * m + 1] = q.y; sc[2 * m + 2] = q.z; sc[2 * m + 3] = q.w; }
         if (MT & 1) { const uint2 q = *(const uint2*)(sp + (MT - 1) * 4); sc[2 * MT - 2] = q.x; sc[2 * MT - 1] = q.y; }
@@ -230,11 +215,13 @@ void scale_gemm_res_kernel(const UnitK U, const bf16_t* __restrict__ g2, const f
 }
 
 UnitK to_k(const sn_unit_src* s) {
-    UnitK u; u.x = (const bf16_t*)s->x; u.T = s->T; u.h = s->h; u.w = s->w; u.C = s->C; u.mode = s->mode; u.wrap = s->wrap;
+    UnitK u; u.x = (const bf16_t*)s->x; u.halo = (const bf16_t*)s->halo; u.T = s->T; u.h = s->h; u.w = s->w; u.C = s->C; u.mode = s->mode; u.wrap = s->wrap;
+    u.t0 = s->nt > 0 ? s->t0 : 0;
     return u;
 }
 bool unit_ok(const sn_unit_src* s) {
-    return s && s->x && (s->C == 64 || s->C == 80) && s->T > 0 && s->h > 0 && s->w > 0 && s->mode >= 0 && s->mode <= 2;
+    return s && s->x && (s->C == 64 || s->C == 80) && s->T > 0 && s->h > 0 && s->w > 0 && s->mode >= 0 && s->mode <= 2 && s->wrap >= 0 &&
+           s->wrap <= 2 && (s->wrap != 2 || s->mode == 0 || s->halo);
 }
 
 }  // namespace
@@ -244,21 +231,24 @@ extern "C" {
 int sn_gsts_gather(const sn_unit_src* s, const int8_t* offs, void* u, void* stream) {
     sn_clear_error();
     if (!unit_ok(s) || !offs || !u || s->mode == 0) return SN_EINVAL;
-    hipLaunchKernelGGL(gather_kernel, dim3(1024, s->T), dim3(256), 0, (hipStream_t)stream, to_k(s), offs, (bf16_t*)u, s->C + s->C / 2);
+    SN_FRAME_RANGE(s, t0, nt);
+    hipLaunchKernelGGL(gather_kernel, dim3(1024, nt), dim3(256), 0, (hipStream_t)stream, to_k(s), offs, (bf16_t*)u, s->C + s->C / 2);
     return sn_check_launch();
 }
 
 int sn_temporal_roll(const sn_unit_src* s, void* y, void* stream) {
     sn_clear_error();
-    if (!s || !s->x || !y || y == s->x || (s->C & 1) || s->mode < 1 || s->mode > 2 || s->T < 1) return SN_EINVAL;
-    hipLaunchKernelGGL(gather_kernel, dim3(1024, s->T), dim3(256), 0, (hipStream_t)stream, to_k(s), (const int8_t*)nullptr, (bf16_t*)y, s->C);
+    if (!s || !s->x || !y || y == s->x || (s->C & 1) || s->mode < 1 || s->mode > 2 || s->T < 1 || (s->wrap == 2 && !s->halo)) return SN_EINVAL;
+    SN_FRAME_RANGE(s, t0, nt);
+    hipLaunchKernelGGL(gather_kernel, dim3(1024, nt), dim3(256), 0, (hipStream_t)stream, to_k(s), (const int8_t*)nullptr, (bf16_t*)y, s->C);
     return sn_check_launch();
 }
 
 int sn_gsts_shiftconv(const sn_unit_src* s, const int8_t* offs, const uint32_t* w1, void* hw, void* stream) {
     sn_clear_error();
     if (!unit_ok(s) || !offs || !w1 || !hw || s->mode == 0) return SN_EINVAL;
-    const XcdTiles G = sn_xcd_tiles((s->w + 15) / 16, (s->h + 15) / 16, s->T);
+    SN_FRAME_RANGE(s, t0, nt);
+    const XcdTiles G = sn_xcd_tiles((s->w + 15) / 16, (s->h + 15) / 16, nt);
     const dim3 grid = sn_xcd_grid(G);
     if (s->C == 64) {
         constexpr int PP = 4;
@@ -275,16 +265,32 @@ int sn_gsts_shiftconv(const sn_unit_src* s, const int8_t* offs, const uint32_t* 
 }
 
 
-int sn_scale_gemm_res(const sn_unit_src* s, const void* g2, const float* ca, const void* wfrag, const float* bias,
-                      void* y, void* stream) {
+}  // extern "C"
+
+namespace {
+int cab_phase2(const sn_unit_src* s, const void* g2, const float* ca, const void* wfrag, const float* bias, void* y, void* stream) {
     sn_clear_error();
     if (!unit_ok(s) || !g2 || !ca || !wfrag || !y || y == s->x) return SN_EINVAL;
     const int npx = s->h * s->w;
     constexpr int PXWG = 64 * SN_K4_NT;
-    dim3 grid((npx + PXWG - 1) / PXWG, s->T);
+    SN_FRAME_RANGE(s, t0, nt);
+    dim3 grid((npx + PXWG - 1) / PXWG, nt);
     if (s->C == 64) hipLaunchKernelGGL((scale_gemm_res_kernel<64, SN_K4_NT>), grid, dim3(256), 0, (hipStream_t)stream, to_k(s), (const bf16_t*)g2, ca, (const uint4*)wfrag, bias, (bf16_t*)y);
     else hipLaunchKernelGGL((scale_gemm_res_kernel<80, SN_K4_NT>), grid, dim3(256), 0, (hipStream_t)stream, to_k(s), (const bf16_t*)g2, ca, (const uint4*)wfrag, bias, (bf16_t*)y);
     return sn_check_launch();
+}
+}  // namespace
+
+extern "C" {
+
+int sn_gsts_cab2_phase2(const sn_unit_src* s, const void* g2, const float* ca, const void* wfrag, const float* bias, void* y, void* stream) {
+    if (!s || (s->mode != 1 && s->mode != 2)) return SN_EINVAL;
+    return cab_phase2(s, g2, ca, wfrag, bias, y, stream);
+}
+
+int sn_cab1_phase2(const sn_unit_src* s, const void* g2, const float* ca, const void* wfrag, const float* bias, void* y, void* stream) {
+    if (!s || s->mode != 0) return SN_EINVAL;
+    return cab_phase2(s, g2, ca, wfrag, bias, y, stream);
 }
 
 }  // extern "C"

@@ -12,19 +12,9 @@
 namespace {
 
 struct UnitK2 {
-    const bf16_t* x;
-    int T, h, w, C, mode, wrap;
+    const bf16_t* x; const bf16_t* halo;
+    int T, h, w, C, mode, wrap, t0;
 };
-
-struct Slabs2 { int f0, o0, f1, o1; };
-
-__device__ __forceinline__ Slabs2 unit_slabs2(const UnitK2& U, int t) {
-    const int Ch = U.C >> 1;
-    Slabs2 s; s.f0 = t; s.o0 = 0; s.f1 = t; s.o1 = Ch;
-    if (U.mode == 1) { if (t > 0 || U.wrap) { s.f0 = sn_prev_frame(t, U.T, U.wrap); s.o0 = Ch; s.f1 = t; s.o1 = 0; } }
-    else if (U.mode == 2) { if (t < U.T - 1 || U.wrap) { s.f0 = t; s.o0 = Ch; s.f1 = sn_next_frame(t, U.T, U.wrap); s.o1 = 0; } }
-    return s;
-}
 
 // ------------------------------------------------------------------------------------------------------------
 #define SN_K12_TH 8
@@ -43,9 +33,10 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
     const int lane = threadIdx.x & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
     int t, tyi, txi;
     if (!sn_xcd_tile(G, t, tyi, txi)) return;     // XCD-aware walk (sn_common.h): ring rows / columns of neighbouring tiles meet in one L2
+    t += U.t0;
     const int oy0 = tyi * TH, ox0 = txi * TW;
     const int hw = U.h * U.w;
-    const Slabs2 sl = unit_slabs2(U, t);
+    const SnSlabs<bf16_t> sl = sn_unit_slabs<bf16_t>(U.x, U.halo, U.T, hw, C, U.mode, U.wrap, t);
 
     // weight fragments and bias of one chunk, fetched one chunk AHEAD (they come from L2: ~1 us when loaded at the point of use)
     bf16x8_t Wf[2][KS];
@@ -70,15 +61,15 @@ __global__ __launch_bounds__(SN_K12_NWV * 64) void ln_gemm_gate_kernel(const Uni
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const int kk0 = s * 32 + g * 8;
-        const bf16_t* b0 = U.x + (ptrdiff_t)sl.f0 * hw * C + sl.o0 + (kk0 < CH ? kk0 : 0);
-        const bf16_t* b1 = U.x + (ptrdiff_t)sl.f1 * hw * C + sl.o1 + (kk0 >= CH && kk0 < C ? kk0 - CH : 0);
+        const bf16_t* b0 = sl.p0 + (kk0 < CH ? kk0 : 0);
+        const bf16_t* b1 = sl.p1 + (kk0 >= CH && kk0 < C ? kk0 - CH : 0);
         slab[s] = kk0 < CH ? b0 : b1;                   // padding slots (kk0 >= K) re-read x and are zeroed below
-        sstride[s] = C;
+        sstride[s] = kk0 < CH ? sl.s0 : sl.s1;          // C, or C/2 for the halo half-frame of a temporally split window
         if (WITH_HW) {
             const bf16_t* b2 = hwb + (size_t)t * hw * CH + (kk0 >= C && kk0 < K ? kk0 - C : 0);
             const bool ishw = kk0 >= C && kk0 < K;
             slab[s] = ishw ? b2 : slab[s];
-            sstride[s] = ishw ? CH : C;
+            sstride[s] = ishw ? CH : sstride[s];
         }
     }
     bf16x8_t B[NTW][KS];
@@ -469,9 +460,12 @@ int sn_ln_gemm_gate(const sn_unit_src* s, const void* hw, const void* wfrag, con
                     void* g1, float* pool, int g1_blocked, void* stream) {
     sn_clear_error();
     if (!s || !s->x || (s->C != 64 && s->C != 80) || s->mode < 0 || s->mode > 2 || !wfrag || !bias || !wdw || !g1 ||
-        (s->mode != 0 && !hw) || (g1_blocked && s->C != 64) || (g1_blocked != 0 && g1_blocked != 2)) return SN_EINVAL;
-    UnitK2 u; u.x = (const bf16_t*)s->x; u.T = s->T; u.h = s->h; u.w = s->w; u.C = s->C; u.mode = s->mode; u.wrap = s->wrap;
-    const XcdTiles G = sn_xcd_tiles((s->w + 31) / 32, (s->h + SN_K12_TH - 1) / SN_K12_TH, s->T);
+        (s->mode != 0 && !hw) || (g1_blocked && s->C != 64) || (g1_blocked != 0 && g1_blocked != 2) || (s->wrap == 2 && s->mode != 0 && !s->halo))
+        return SN_EINVAL;
+    UnitK2 u; u.x = (const bf16_t*)s->x; u.halo = (const bf16_t*)s->halo; u.T = s->T; u.h = s->h; u.w = s->w; u.C = s->C; u.mode = s->mode; u.wrap = s->wrap;
+    SN_FRAME_RANGE(s, t0, nt);
+    u.t0 = t0;
+    const XcdTiles G = sn_xcd_tiles((s->w + 31) / 32, (s->h + SN_K12_TH - 1) / SN_K12_TH, nt);
     const dim3 grid = sn_xcd_grid(G);
     hipStream_t st = (hipStream_t)stream;
 #define SN_LAUNCH_K12(CC, HW_) hipLaunchKernelGGL((ln_gemm_gate_kernel<CC, HW_>), grid, dim3(SN_K12_NWV * 64), 0, st, u, G, (const bf16_t*)hw, \

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -120,10 +121,12 @@ class Plan:
             u["w_toep5"] = self._dev(prep.pack_toeplitz(w5, 5))           # K3m: 5x5 on the matrix cores
         i += 1
         u["w_gate"] = self._dev(prep.pack_gate_gemm(sd[f"{pre}body.{i}.weight"], c))
-        if c == 64 and not V.grouped_rep and not V.denoise:      # fused phase 1 (sn_cab_phase1): Shift-Net-s deblur
+        if c == 64 and not V.grouped_rep and not V.denoise:      # fused phase 1 (sn_gsts_cab2_phase1 / sn_cab1_phase1): Shift-Net-s deblur
             p1 = prep.pack_phase1(sd[f"{pre}body.0.weight"], sd[pre + "norm.weight"], sd[pre + "norm.bias"], sd[f"{pre}body.1.conv_2.weight"],
                                   sd[f"{pre}body.{i - 1}.conv_1.weight"], sd[f"{pre}body.{i - 1}.conv_2.weight"], sd[f"{pre}body.{i}.weight"], c)
-            u["p1"] = {k: self._dev(v) for k, v in p1.items()}
+            d = {k: self._dev(v) for k, v in p1.items()}
+            d["desc"] = L.Phase1Weights(*(d[k].data_ptr() for k in ("wfrag1", "wfragx", "w3", "w5", "wfrag2")))   # the tensors stay referenced in d
+            u["p1"] = d
         i += 1
         i += 1
         self.add_ca(f"{pre}ca2", f"{pre}body.{i}."); i += 1
@@ -206,12 +209,13 @@ class Engine:
         self.prof: Optional[list] = None      # bench.py attaches a list to collect (fn, label, meta, ev0, ev1)
         self._meta: Tuple = ()
         self.split = None                     # temporal_split.TemporalSplit: this engine holds a frame range of a longer window
+        self._side = None                     # side stream of the halo exchanges (created on first use)
         # hipGraph replay of the whole forward (~1400 launches per window), opt-in with SN_GRAPH=1: the first call with a given input
         # signature runs eagerly, the second one is captured, later ones replay, so the Python / ctypes / allocator work per launch
         # disappears.  Measured on MI355X: neutral at 1280x720 (126.4 vs 126.0 ms per window: the GPU is never starved there, kernels
         # average 90 us), it pays on small clips where the ~10 us squeeze-excite kernels dominate the launch stream.
         self.use_graph = os.environ.get("SN_GRAPH", "0") == "1"
-        self._graphs: Dict[Tuple, object] = {}
+        self._graphs: "OrderedDict[Tuple, object]" = OrderedDict()   # LRU over input signatures, at most GRAPH_SLOTS captured graphs alive
 
     # ---- low level wrappers --------------------------------------------------------------------------------
     def _stream(self) -> int:
@@ -232,8 +236,6 @@ class Engine:
     act_dtype = torch.bfloat16
 
     def _new(self, T: int, h: int, w: int, cs: int) -> torch.Tensor:
-        if self.split is not None:            # one spare frame on each side: the halo slots of temporal_split.TemporalSplit
-            return torch.empty((T + 2, h, w, cs), dtype=self.act_dtype, device=self.dev)[1:T + 1]
         return torch.empty((T, h, w, cs), dtype=self.act_dtype, device=self.dev)
 
     def conv(self, name: str, ins: Sequence[Act], *, stride: int = 1, pad: Optional[int] = None, prelu: Optional[float] = None,
@@ -299,7 +301,7 @@ class Engine:
         raise NotImplementedError("bf16 CABs apply the CALayer scale and the residual in conv2's epilogue (fused_cab_tail)")
 
     # ---- blocks (oracle/shiftnet_oracle.py has the same names) ----------------------------------------------
-    fused_phase1 = True        # Shift-Net-s deblur: sn_cab_phase1 instead of sn_ln_gemm_gate + sn_dw5m_gemm_gate (tests switch it off for A/B)
+    fused_phase1 = True        # Shift-Net-s deblur: sn_gsts_cab2_phase1 / sn_cab1_phase1 instead of sn_ln_gemm_gate + sn_dw5m_gemm_gate (tests switch it off for A/B)
     fused_cab_tail = True      # Engine32 (one kernel per reference module) runs conv, conv, pool, MLP, scale + residual instead
 
     def cab(self, pre: str, x: Act, extra: Optional[Act] = None) -> Act:
@@ -324,25 +326,55 @@ class Engine:
         return self.scale_residual(r, x, self.ca_mlp(pre + "CA", pool, npix), extra)
 
     def _wrap_flag(self, mode: int, circular: bool) -> int:
-        """sn_unit_src.wrap: 0 keep the boundary frame, 1 circular, 2 neighbour frame in the halo slot (temporal split)."""
+        """sn_unit_src.wrap: 0 keep the window's boundary frame, 1 circular, 2 the neighbour frame's half arrives from the adjacent rank."""
         if self.split is not None and mode:
-            return self.split.wrap_flag(mode) if (circular or self.split.wrap_flag(mode) == 2) else 0
+            return self.split.wrap_flag(mode, circular)
         return 1 if circular else 0
 
-    def _unit_src(self, x: Act, mode: int) -> L.UnitSrc:
+    def _unit_src(self, x: Act, mode: int, *, wrap: Optional[int] = None, halo: Optional[torch.Tensor] = None, t0: int = 0, nt: int = 0) -> L.UnitSrc:
         T, h, w, cs = x.dims
         assert cs == x.c
-        return L.UnitSrc(x.t.data_ptr(), T, h, w, x.c, mode, self._wrap_flag(mode, self.V.wrap))
+        wrap = self._wrap_flag(mode, self.V.wrap) if wrap is None else wrap
+        return L.UnitSrc(x.t.data_ptr(), T, h, w, x.c, mode, wrap, halo.data_ptr() if halo is not None else None, t0, nt)
+
+    def _split_pieces(self, x: Act, mode: int, circular: bool):
+        """Launch plan of a shifted operator on a temporally split window (temporal_split.py): [(wrap, halo, t0, nt), ...].
+
+        Without a split (or where this rank has no neighbour on the borrowing side): one piece, all frames.  Otherwise the frames that
+        need no halo are launched FIRST, on the compute stream; the halo exchange runs meanwhile on the engine's side stream (it waits
+        only for the producer of x), and the boundary frame -- the only one that reads the neighbour's half -- follows once it arrived."""
+        T = x.dims[0]
+        flag = self._wrap_flag(mode, circular)
+        if self.split is None:
+            yield (flag, None, 0, 0)
+            return
+        main = torch.cuda.current_stream(self.dev)
+        ready = main.record_event()                       # x is complete here (stream order)
+        recv = flag == 2                                  # this rank's boundary frame borrows from a neighbour rank
+        bt = 0 if mode == 1 else T - 1
+        if recv and T > 1:
+            yield (0, None, 1 if mode == 1 else 0, T - 1)  # the boundary frame is outside the range, so its rule does not matter
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.dev)
+        with torch.cuda.stream(self._side):               # every rank takes part: one that receives nothing may still have to send
+            self._side.wait_event(ready)
+            x.t.record_stream(self._side)
+            halo = self.split.exchange(x.t, mode, circular)
+        if recv:
+            main.wait_stream(self._side)
+            halo.record_stream(main)
+            yield (2, halo, bt, 1)
+        else:
+            yield (flag, None, 0, 0)
 
     def temporal_roll(self, x: Act, reverse: bool) -> Act:
         T, h, w, cs = x.dims
         assert cs == x.c, "Shift_CAB widths (24, 80) are stored unpadded"
         y = self._new(T, h, w, cs)
         mode = 2 if reverse else 1
-        if self.split is not None:
-            self.split.exchange(x.t, mode)
-        s = L.UnitSrc(x.t.data_ptr(), T, h, w, x.c, mode, self._wrap_flag(mode, False))
-        self._call("sn_temporal_roll", "sn_temporal_roll", C.byref(s), y.data_ptr(), self._stream())
+        for wrap, halo, t0, nt in self._split_pieces(x, mode, False):
+            s = self._unit_src(x, mode, wrap=wrap, halo=halo, t0=t0, nt=nt)
+            self._call("sn_temporal_roll", "sn_temporal_roll", C.byref(s), y.data_ptr(), self._stream())
         return Act(y, x.c)
 
     def shift_cab(self, pre: str, x: Act, reverse: bool) -> Act:
@@ -352,62 +384,72 @@ class Engine:
     def naf(self, pre: str, x: Act, mode: int) -> Act:
         """CAB2 (mode 1/2, fed by the GSTS gather of x) or CAB1 (mode 0) (gshift_deblur1.py:183-255).
 
-        K0 sn_gsts_shiftconv (CAB2 only) -> K12 sn_ln_gemm_gate -> K3 (sn_dw5m_gemm_gate for the depthwise variants,
-        sn_grp5_gemm_gate for the grouped "+" ones) -> sn_ca_mlp -> K4 sn_scale_gemm_res.  The global average pool of
-        CALayer2 sits between K3 and K4 and forbids a single pass."""
-        lib, st, V, P = self.lib, self._stream(), self.V, self.P
+        Phase 1: [K0 sn_gsts_shiftconv (CAB2 only)] -> sn_gsts_cab2_phase1 / sn_cab1_phase1 (Shift-Net-s deblur: ONE kernel up to g2), or K12 sn_ln_gemm_gate -> K3
+        (sn_dw5m_gemm_gate depthwise with the inner CALayer2 of the denoisers, sn_grp5_gemm_gate for the grouped "+" RepConv); then sn_ca_mlp
+        and phase 2, K4 sn_gsts_cab2_phase2 / sn_cab1_phase2.  The global average pool of CALayer2 sits between the phases and forbids a single pass
+        (DESIGN.md section 3).  Every frame is independent inside a CAB (the pool is per frame), so on a temporally split window the chain
+        runs in two pieces: all frames but the boundary one while the halo exchange is in flight, then the boundary frame."""
+        lib, V, P = self.lib, self.V, self.P
         u = P.units[pre]
         T, h, w, c = x.dims
         self._meta = ("naf", T, h, w, c, mode)
-        if mode and self.split is not None:
-            self.split.exchange(x.t, mode)              # neighbour rank's half-frame into the halo slot (one per shifted unit)
-        src = self._unit_src(x, mode)
-        hw_ptr = None
-        if mode:
-            hwb = self._new(T, h, w, c // 2)
-            self._call("sn_gsts_shiftconv", "sn_gsts_shiftconv", C.byref(src), P.offs.data_ptr(), u["w1"].data_ptr(), hwb.data_ptr(), st)
-            hw_ptr = hwb.data_ptr()
-        if "p1" in u and self.fused_phase1:             # phase 1 in ONE kernel: neither a, g1 nor r leave the CU (csrc/sn_phase1.hip)
-            p1 = u["p1"]
-            g2 = self._new(T, h, w, c)
-            nblk = lib.sn_cab_phase1_blocks(T, h, w)
-            if nblk < 1:
-                raise L.ShiftNetLibError(f"sn_cab_phase1_blocks failed with code {nblk}")
-            pool2 = torch.empty((T, nblk, c), dtype=torch.float32, device=self.dev)
-            self._call("sn_cab_phase1", "sn_cab_phase1", C.byref(src), hw_ptr, p1["wfrag1"].data_ptr(), p1["bias"].data_ptr(), p1["wsum"].data_ptr(),
-                       p1["w3"].data_ptr(), p1["w5"].data_ptr(), p1["wfrag2"].data_ptr(), g2.data_ptr(), pool2.data_ptr(), st)
-            ca2 = self.ca_mlp(pre + "ca2", pool2, h * w)
-            y = self._new(T, h, w, c)
-            self._call("sn_scale_gemm_res", "sn_scale_gemm_res", C.byref(src), g2.data_ptr(), ca2.data_ptr(), u["w_out"].data_ptr(), None,
-                       y.data_ptr(), st)
-            return Act(y, c)
-        mstencil = not V.grouped_rep                    # depthwise RepConv (C = 64): Toeplitz-MFMA 5x5 on a channel-planar g1
-        if mstencil:
-            g1 = torch.empty((T, h, c, lib.sn_planar_pitch(w)), dtype=torch.bfloat16, device=self.dev)
-        else:
-            g1 = self._new(T, h, w, c)
-        pool1 = torch.empty((T, lib.sn_lngate_blocks(h, w), c), dtype=torch.float32, device=self.dev) if V.denoise else None
-        self._call("sn_ln_gemm_gate", "sn_ln_gemm_gate", C.byref(src), hw_ptr, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(),
-                   u["w_dw3_h2"].data_ptr(), g1.data_ptr(), pool1.data_ptr() if pool1 is not None else None, 2 if mstencil else 0, st)
-        # denoise: CALayer2 on g1.  `ca1` must stay referenced until the K3 launch below: a temporary would go back to the caching
-        # allocator at once and g2 / pool2, which K3 WRITES, could be carved out of the block K3 still READS its scale from
-        # (intermittent wrong frames at the small pyramid levels; found by the full-size determinism check of config 4).
-        ca1 = self.ca_mlp(pre + "ca1", pool1, h * w) if V.denoise else None
-        ca1_ptr = ca1.data_ptr() if ca1 is not None else None
+        fused = "p1" in u and self.fused_phase1          # phase 1 in ONE kernel: neither a, g1 nor r leave the CU (csrc/sn_phase1.hip)
+        mstencil = not V.grouped_rep                     # depthwise RepConv (C = 64): Toeplitz-MFMA 5x5 on a channel-planar g1
+        hwb = self._new(T, h, w, c // 2) if mode else None
         g2 = self._new(T, h, w, c)
-        if mstencil:
-            pool2 = torch.empty((T, lib.sn_dw5m_blocks(h, w), c), dtype=torch.float32, device=self.dev)
-            self._call("sn_dw5m_gemm_gate", "sn_dw5m_gemm_gate", g1.data_ptr(), ca1_ptr, u["w_toep5"].data_ptr(), u["w_gate"].data_ptr(),
-                       g2.data_ptr(), pool2.data_ptr(), T, h, w, c, st)
-        else:       # "+" RepConv (groups = C/8) as a block-diagonal MFMA GEMM fused with the 1x1 / SimpleGate2 that follow it
-            pool2 = torch.empty((T, lib.sn_grp5_blocks(h, w), c), dtype=torch.float32, device=self.dev)
-            self._call("sn_grp5_gemm_gate", "sn_grp5_gemm_gate", g1.data_ptr(), ca1_ptr, u["w_grp"].data_ptr(), u["w_gate"].data_ptr(),
-                       g2.data_ptr(), pool2.data_ptr(), T, h, w, c, st)
-        ca2 = self.ca_mlp(pre + "ca2", pool2, h * w)
         y = self._new(T, h, w, c)
+        g1 = pool1 = ca1 = None
+        if fused:
+            nb2 = lib.sn_phase1_pool_blocks(T, h, w)
+            if nb2 < 1:
+                raise L.ShiftNetLibError(f"sn_phase1_pool_blocks failed with code {nb2}")
+        else:
+            g1 = (torch.empty((T, h, c, lib.sn_planar_pitch(w)), dtype=torch.bfloat16, device=self.dev) if mstencil else self._new(T, h, w, c))
+            nb2 = lib.sn_dw5m_blocks(h, w) if mstencil else lib.sn_grp5_blocks(h, w)
+            if V.denoise:      # CALayer2 on g1.  ca1 / pool1 stay referenced until the end of this method: a temporary would go back to the
+                # caching allocator at once and g2 / pool2, which K3 WRITES, could be carved out of the block K3 still READS its scale
+                # from (intermittent wrong frames at the small pyramid levels; found by the full-size determinism check of config 4)
+                pool1 = torch.empty((T, lib.sn_lngate_blocks(h, w), c), dtype=torch.float32, device=self.dev)
+                ca1 = torch.empty((T, c), dtype=torch.float32, device=self.dev)
+        pool2 = torch.empty((T, nb2, c), dtype=torch.float32, device=self.dev)
+        ca2 = torch.empty((T, c), dtype=torch.float32, device=self.dev)
         b_out = u["b_out"].data_ptr() if u["b_out"] is not None else None
-        self._call("sn_scale_gemm_res", "sn_scale_gemm_res", C.byref(src), g2.data_ptr(), ca2.data_ptr(), u["w_out"].data_ptr(), b_out,
-                   y.data_ptr(), st)
+        es = 2                                           # bytes per activation element
+
+        def ca_mlp(name: str, pool: torch.Tensor, ca: torch.Tensor, f0: int, n: int) -> None:
+            q = P.cas[name]
+            nblk = pool.shape[1]
+            self._call("sn_ca_mlp", f"sn_ca_mlp[{name}]", pool.data_ptr() + f0 * nblk * c * 4, nblk, c, q["c"], q["cr"], 1.0 / (h * w),
+                       q["wa"].data_ptr(), q["wb"].data_ptr(), ca.data_ptr() + f0 * c * 4, n, self._stream())
+
+        for wrap, halo, t0, nt in (self._split_pieces(x, mode, V.wrap) if mode else [(0, None, 0, 0)]):
+            st = self._stream()
+            src = self._unit_src(x, mode, wrap=wrap, halo=halo, t0=t0, nt=nt)
+            f0, n = (t0, nt) if nt else (0, T)           # frame range of this piece for the operators that take plain pointers
+            if mode:
+                self._call("sn_gsts_shiftconv", "sn_gsts_shiftconv", C.byref(src), P.offs.data_ptr(), u["w1"].data_ptr(), hwb.data_ptr(), st)
+            hw_ptr = hwb.data_ptr() if mode else None
+            if fused:
+                wt = C.byref(u["p1"]["desc"])
+                if mode:
+                    self._call("sn_gsts_cab2_phase1", "sn_gsts_cab2_phase1", C.byref(src), hw_ptr, wt, g2.data_ptr(), pool2.data_ptr(), st)
+                else:
+                    self._call("sn_cab1_phase1", "sn_cab1_phase1", C.byref(src), wt, g2.data_ptr(), pool2.data_ptr(), st)
+            else:
+                self._call("sn_ln_gemm_gate", "sn_ln_gemm_gate", C.byref(src), hw_ptr, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(),
+                           u["w_dw3_h2"].data_ptr(), g1.data_ptr(), pool1.data_ptr() if pool1 is not None else None, 2 if mstencil else 0, st)
+                ca1_ptr = None
+                if V.denoise:
+                    ca_mlp(pre + "ca1", pool1, ca1, f0, n)
+                    ca1_ptr = ca1.data_ptr() + f0 * c * 4
+                fr1 = g1.stride(0) * es * f0
+                fr2 = g2.stride(0) * es * f0
+                k3 = "sn_dw5m_gemm_gate" if mstencil else "sn_grp5_gemm_gate"
+                self._call(k3, k3, g1.data_ptr() + fr1, ca1_ptr, u["w_toep5" if mstencil else "w_grp"].data_ptr(), u["w_gate"].data_ptr(),
+                           g2.data_ptr() + fr2, pool2.data_ptr() + f0 * nb2 * c * 4, n, h, w, c, st)
+            ca_mlp(pre + "ca2", pool2, ca2, f0, n)
+            k4 = "sn_gsts_cab2_phase2" if mode else "sn_cab1_phase2"
+            self._call(k4, k4, C.byref(src), g2.data_ptr(), ca2.data_ptr(), u["w_out"].data_ptr(), b_out, y.data_ptr(), st)
         return Act(y, c)
 
     def gsts_unit(self, pre: str, x: Act, reverse: bool) -> Act:
@@ -519,7 +561,9 @@ class Engine:
         ent = self._graphs.get(key)
         if ent is None:                         # first sight of this signature: eager (also the warm-up the capture needs)
             self._graphs[key] = "seen"
+            self._evict_graphs()
             return self._forward(x, noise_map, past, future)
+        self._graphs.move_to_end(key)
         if ent == "eager":
             return self._forward(x, noise_map, past, future)
         if ent == "seen":
@@ -527,11 +571,17 @@ class Engine:
                 sx = x.clone()
                 sn = noise_map.clone() if noise_map is not None else None
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g):       # its __exit__ ends the capture on an exception too: the stream is never left capturing
                     so = self._forward(sx, sn, past, future)
                 ent = self._graphs[key] = (g, sx, sn, so)
+                self._evict_graphs()
             except Exception as e:                                  # noqa: BLE001  (capture unsupported here: stay eager, say so once)
                 import warnings
+                if torch.cuda.is_current_stream_capturing():        # belt and braces: a capture that __exit__ could not end
+                    try:
+                        g.capture_end()
+                    except Exception:                               # noqa: BLE001
+                        pass
                 warnings.warn(f"shiftnet_amd: hipGraph capture failed ({type(e).__name__}: {e}); running eagerly")
                 self._graphs[key] = "eager"
                 torch.cuda.synchronize(self.dev)
@@ -542,6 +592,21 @@ class Engine:
             sn.copy_(noise_map)
         g.replay()
         return so.clone()                       # the graph owns `so`: hand out a copy, like the fresh tensor upstream returns
+
+    GRAPH_SLOTS = 2          # captured graphs kept per engine: each pins its whole activation pool (GBs at 720p), so a client that varies
+    #                          the window shape must not accumulate them
+
+    def _evict_graphs(self) -> None:
+        live = [k for k, v in self._graphs.items() if isinstance(v, tuple)]
+        while len(live) > self.GRAPH_SLOTS:
+            k = live.pop(0)                     # least recently used
+            g = self._graphs.pop(k)[0]
+            g.reset()                           # frees the graph's private memory pool
+        while len(self._graphs) > 16:           # the "seen" / "eager" markers are bounded too
+            k = next(iter(self._graphs))
+            v = self._graphs.pop(k)
+            if isinstance(v, tuple):
+                v[0].reset()
 
     def _forward(self, x: torch.Tensor, noise_map: Optional[torch.Tensor], past: int, future: int,
                  out_dtype: Optional[torch.dtype] = None, shortcut: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -556,9 +621,9 @@ class Engine:
         hi = T - (future if (sp is None or sp.rank == sp.world - 1) else 0)
         n_out = max(hi - lo, 0)
         out = torch.empty((n_out, 3, H, W), dtype=out_dtype or x.dtype, device=x.device)
+        if sp is not None:
+            sp.validate(n_out)              # collective: all ranks raise together, none is left waiting in an exchange
         if n_out == 0:
-            if sp is not None:
-                raise ValueError("temporal split: every rank must restore at least one frame (the halo exchanges are collective)")
             return out                      # T <= past+future yields an empty tensor upstream as well
         x0 = self.cab("feat_extract.1.", self.conv("feat_extract.0", [self._ingest(x, noise_map)]))
         t = x0

@@ -156,10 +156,9 @@ class Engine32(Engine):
         T, h, w, c = x.dims
         y = self._new(T, h, w, c)
         mode = 2 if reverse else 1
-        if self.split is not None:
-            self.split.exchange(x.t, mode)
-        s = L.UnitSrc(x.t.data_ptr(), T, h, w, c, mode, self._wrap_flag(mode, False))
-        self._call("sn32_gsts_gather", "sn32_temporal_roll", C.byref(s), None, y.data_ptr(), self._stream())
+        for wrap, halo, t0, nt in self._split_pieces(x, mode, False):
+            s = self._unit_src(x, mode, wrap=wrap, halo=halo, t0=t0, nt=nt)
+            self._call("sn32_gsts_gather", "sn32_temporal_roll", C.byref(s), None, y.data_ptr(), self._stream())
         return Act(y, c)
 
     def _ca(self, name: str, g: torch.Tensor) -> torch.Tensor:
@@ -175,14 +174,13 @@ class Engine32(Engine):
         dsd = P.dsd
         self._meta = ("naf32", T, h, w, c, mode)
         if mode:
-            if self.split is not None:
-                self.split.exchange(x.t, mode)
             ug = self._new(T, h, w, c + c // 2)                                   # cat(roll(x), spatial_shift2(borrowed half))
-            s = L.UnitSrc(x.t.data_ptr(), T, h, w, c, mode, self._wrap_flag(mode, V.wrap))
-            self._call("sn32_gsts_gather", "sn32_gsts_gather", C.byref(s), P.offs.data_ptr(), ug.data_ptr(), st)
+            vin = self._new(T, h, w, c + c // 2)                                  # cat(shortcut, conv1(shifted)): a second gather fills [:c], conv1 overwrites [c:]
+            for wrap, halo, t0, nt in self._split_pieces(x, mode, V.wrap):        # (temporal split: the boundary frame after its halo arrived)
+                s = self._unit_src(x, mode, wrap=wrap, halo=halo, t0=t0, nt=nt)
+                self._call("sn32_gsts_gather", "sn32_gsts_gather", C.byref(s), P.offs.data_ptr(), ug.data_ptr(), self._stream())
+                self._call("sn32_gsts_gather", "sn32_gsts_gather", C.byref(s), P.offs.data_ptr(), vin.data_ptr(), self._stream())
             shortcut = ug[..., :c]
-            vin = self._new(T, h, w, c + c // 2)                                  # cat(shortcut, conv1(shifted)): a second gather fills
-            self._call("sn32_gsts_gather", "sn32_gsts_gather", C.byref(s), P.offs.data_ptr(), vin.data_ptr(), st)   # [:c], conv1 overwrites [c:]
             self._conv32(pre + "conv1.weight", None, [ug[..., c:]], [c // 2], k=3, groups=c // 2, out=vin[..., c:])
             kk = c + c // 2
         else:

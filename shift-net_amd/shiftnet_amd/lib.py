@@ -15,16 +15,28 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libshiftnet_hip.so")
 
 SN_F32, SN_F16, SN_BF16 = 0, 1, 2
 
-ABI_VERSION = 3      # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so from before a struct / signature change fails the check in load()
+ABI_VERSION = 5      # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so from before a struct / signature change fails the check in load()
 
 SYMBOLS = [          # include/shiftnet_hip.h, production ABI
     "sn_abi_version", "sn_selftest_mfma", "sn_ingest", "sn_conv2d", "sn_conv_pool_blocks", "sn_ca_mlp",
     "sn_cab_ca", "sn_cab_ca_scratch_floats", "sn_planar_pitch", "sn_nhwc_to_planar", "sn_dw5m_blocks",
-    "sn_dw5m_gemm_gate", "sn_gsts_gather", "sn_temporal_roll", "sn_gsts_shiftconv", "sn_scale_gemm_res",
+    "sn_dw5m_gemm_gate", "sn_gsts_gather", "sn_temporal_roll", "sn_gsts_shiftconv", "sn_gsts_cab2_phase2", "sn_cab1_phase2",
     "sn_ingest_u8", "sn_egress_blocks", "sn_egress_u8", "sn_ssim_blocks", "sn_ssim_u8",
     "sn32_conv2d", "sn32_gsts_gather", "sn32_layernorm", "sn32_gate", "sn32_chan_sum", "sn32_scale_residual", "sn32_ingest",
-    "sn_ln_gemm_gate", "sn_lngate_blocks", "sn_grp5_gemm_gate", "sn_grp5_blocks", "sn_cab_phase1", "sn_cab_phase1_blocks",
+    "sn_ln_gemm_gate", "sn_lngate_blocks", "sn_grp5_gemm_gate", "sn_grp5_blocks", "sn_gsts_cab2_phase1", "sn_cab1_phase1", "sn_phase1_pool_blocks",
 ]
+
+
+class Phase1Weights(C.Structure):
+    """sn_phase1_weights (prep.pack_phase1; device pointers)."""
+    _fields_ = [("wfrag1", C.c_void_p), ("wfragx", C.c_void_p), ("w3", C.c_void_p), ("w5", C.c_void_p), ("wfrag2", C.c_void_p)]
+
+
+def cab_phase1(lib, src: "UnitSrc", hw_ptr, wt: "Phase1Weights", g2_ptr, pool_ptr, stream) -> int:
+    """sn_gsts_cab2_phase1 (src.mode 1 / 2) or sn_cab1_phase1 (mode 0)."""
+    if src.mode:
+        return lib.sn_gsts_cab2_phase1(C.byref(src), hw_ptr, C.byref(wt), g2_ptr, pool_ptr, stream)
+    return lib.sn_cab1_phase1(C.byref(src), C.byref(wt), g2_ptr, pool_ptr, stream)
 
 
 class ConvDesc(C.Structure):
@@ -53,7 +65,7 @@ class Conv32Desc(C.Structure):
 
 class UnitSrc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("T", C.c_int), ("h", C.c_int), ("w", C.c_int), ("C", C.c_int),
-                ("mode", C.c_int), ("wrap", C.c_int)]
+                ("mode", C.c_int), ("wrap", C.c_int), ("halo", C.c_void_p), ("t0", C.c_int), ("nt", C.c_int)]
 
 
 class ShiftNetLibError(RuntimeError):
@@ -99,9 +111,11 @@ def load() -> C.CDLL:
     lib.sn_lngate_blocks.argtypes = [ci, ci]
     lib.sn_grp5_gemm_gate.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.sn_grp5_blocks.argtypes = [ci, ci]
-    lib.sn_cab_phase1_blocks.argtypes = [ci, ci, ci]
-    lib.sn_cab_phase1.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
-    lib.sn_scale_gemm_res.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp, vp]
+    lib.sn_phase1_pool_blocks.argtypes = [ci, ci, ci]
+    lib.sn_gsts_cab2_phase1.argtypes = [C.POINTER(UnitSrc), vp, C.POINTER(Phase1Weights), vp, vp, vp]
+    lib.sn_cab1_phase1.argtypes = [C.POINTER(UnitSrc), C.POINTER(Phase1Weights), vp, vp, vp]
+    lib.sn_gsts_cab2_phase2.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp, vp]
+    lib.sn_cab1_phase2.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp, vp]
     lib.sn_ingest_u8.argtypes = [vp, vp, ci, ci, ci, ci, vp]
     lib.sn_egress_blocks.argtypes = []
     lib.sn_egress_u8.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci, vp]

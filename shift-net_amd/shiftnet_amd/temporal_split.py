@@ -9,10 +9,15 @@ unit the lower half-channels of frame t+1.  So before every shifted unit each ra
 of the unit's input to one neighbour and receives one (41.5 MB at level 1 / 1080p / C = 80 in bf16; 56 (48) exchanges per
 forward), deblur2's circular roll closing the ring between the last and the first rank (gshift_deblur2.py:504-505).
 
-The received half-frame lands in a HALO slot just outside the local tensor (every activation of a split engine is
-allocated with one spare frame on each side), and the kernels are told so through ``sn_unit_src.wrap == 2``: the
-neighbour of local frame 0 / T-1 is then frame index -1 / T (csrc/sn_common.h: sn_prev_frame / sn_next_frame).  Nothing
-else in the engine changes; stage 2 trims ``past`` frames on the first rank and ``future`` frames on the last only.
+The received half-frame is a contiguous ``[h, w, C/2]`` buffer of its own -- the receive buffer of the exchange -- handed to the
+kernels through ``sn_unit_src.halo`` together with ``wrap == 2`` (csrc/sn_common.h: sn_unit_slabs): no halo-padded allocations, no copy
+into a strided slot.  The sender packs its strided half-frame once (RCCL / gloo send contiguous memory).  Nothing else in the engine
+changes; stage 2 trims ``past`` frames on the first rank and ``future`` frames on the last only.
+
+Overlap: a shifted unit needs the neighbour's half-frame only for ONE of its frames (local frame 0 of a forward unit, the last one of a
+reverse unit).  The engine therefore posts the exchange on a side stream as soon as the unit's input exists, runs the unit's CAB2 for
+all other frames on the compute stream meanwhile, and waits for the halo only before the boundary frame's launches
+(``Engine.naf`` with ``split`` set; ``sn_unit_src`` addresses frame ranges through its base pointer, T and wrap flag).
 """
 from __future__ import annotations
 
@@ -38,61 +43,65 @@ class TemporalSplit:
         assert 0 <= rank < world
         self.rank, self.world, self.circular, self.group = rank, world, circular, group
 
-    # which neighbour exists for this rank (None = the window boundary, where the reference keeps the frame un-rolled)
-    def prev_rank(self) -> Optional[int]:
+    # Which rank owns the frame a boundary frame borrows from (None = the window boundary, where the reference keeps the frame
+    # un-rolled).  `circular` is the roll's own rule: GSTS units of deblur2 close the ring (gshift_deblur2.py:504-505), every other unit and
+    # Shift_CAB's roll (gshift_denoise1.py:167-179) do not -- also on a module whose GSTS units are circular.
+    def prev_rank(self, circular: bool) -> Optional[int]:
         if self.rank > 0:
             return self.rank - 1
-        return self.world - 1 if (self.circular and self.world > 1) else None
+        return self.world - 1 if (circular and self.world > 1) else None
 
-    def next_rank(self) -> Optional[int]:
+    def next_rank(self, circular: bool) -> Optional[int]:
         if self.rank < self.world - 1:
             return self.rank + 1
-        return 0 if (self.circular and self.world > 1) else None
+        return 0 if (circular and self.world > 1) else None
 
-    def wrap_flag(self, mode: int) -> int:
-        """``sn_unit_src.wrap`` for a unit of direction ``mode`` (1 forward, 2 reverse) on this rank."""
-        nb = self.prev_rank() if mode == 1 else self.next_rank()
+    def wrap_flag(self, mode: int, circular: bool) -> int:
+        """``sn_unit_src.wrap`` for an operator of direction ``mode`` (1 forward, 2 reverse) on this rank."""
+        nb = self.prev_rank(circular) if mode == 1 else self.next_rank(circular)
         if nb is not None:
-            return 2                                  # neighbour frame in the halo slot
-        return 1 if self.circular else 0              # single-rank circular roll / kept boundary frame
+            return 2                                  # the neighbour frame's half arrives from that rank
+        return 1 if circular else 0                   # (single rank) circular roll / kept boundary frame
 
-    @staticmethod
-    def halo_base(x: torch.Tensor) -> torch.Tensor:
-        """The [T+2, h, w, C] allocation a unit input [T, h, w, C] is the middle of."""
-        base = x._base
-        if base is None or base.dim() != 4 or base.shape[0] != x.shape[0] + 2 or x.storage_offset() != base.storage_offset() + base.stride(0):
-            raise RuntimeError("temporal split: unit inputs must come from a halo-padded allocation (Engine._new)")
-        return base
+    def validate(self, n_local_frames: int) -> None:
+        """Collective check, once per forward and BEFORE any exchange: every rank must hold at least one frame.  A rank that raised
+        on its own while the others entered the exchanges would leave them hanging."""
+        flag = torch.tensor([1 if n_local_frames < 1 else 0], dtype=torch.int32)
+        if dist.get_backend(self.group) != "gloo":
+            flag = flag.cuda()
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        if int(flag.item()):
+            raise ValueError("temporal split: every rank must hold at least one frame of the window (the halo exchanges are collective)")
 
-    def exchange(self, x: torch.Tensor, mode: int) -> None:
-        """Fill this rank's halo slot of ``x`` ([T,h,w,C], NHWC) for a unit of direction ``mode`` and feed the neighbour's.
+    def exchange(self, x: torch.Tensor, mode: int, circular: bool) -> Optional[torch.Tensor]:
+        """One halo exchange for a unit of direction ``mode`` on input ``x`` ([T,h,w,C], NHWC): returns the neighbour's half-frame as a
+        contiguous [h,w,C/2] tensor (None where this rank has no neighbour on that side) and feeds the other neighbour.
 
-        forward: the upper half-channels of my LAST frame go to the next rank's slot -1;
-        reverse: the lower half-channels of my FIRST frame go to the previous rank's slot T."""
-        base = self.halo_base(x)
-        T, _, _, C = x.shape
+        forward: the upper half-channels of my LAST frame go to the next rank; I receive the previous rank's.
+        reverse: the lower half-channels of my FIRST frame go to the previous rank; I receive the next rank's."""
+        T, h, w, C = x.shape
         Ch = C // 2
         if mode == 1:
-            dst, src = self.next_rank(), self.prev_rank()
+            dst, src = self.next_rank(circular), self.prev_rank(circular)
             send = x[T - 1, :, :, Ch:] if dst is not None else None
-            slot = base[0, :, :, Ch:] if src is not None else None
         else:
-            dst, src = self.prev_rank(), self.next_rank()
+            dst, src = self.prev_rank(circular), self.next_rank(circular)
             send = x[0, :, :, :Ch] if dst is not None else None
-            slot = base[T + 1, :, :, :Ch] if src is not None else None
-        if send is None and slot is None:
-            return
-        staged = dist.get_backend(self.group) == "gloo" and x.is_cuda           # gloo moves host memory: stage through the CPU
-        ops, rbuf = [], None
+        if send is None and src is None:
+            return None
+        staged = dist.get_backend(self.group) == "gloo" and x.is_cuda            # gloo moves host memory: stage through the CPU (one-GPU tests)
+        ops, halo, rbuf = [], None, None
         if send is not None:
-            sbuf = send.contiguous()
+            sbuf = send.contiguous()                                             # the one pack: a half-frame is strided in NHWC
             if staged:
                 sbuf = sbuf.cpu()
             ops.append(dist.P2POp(dist.isend, sbuf, dst, self.group))
-        if slot is not None:
-            rbuf = torch.empty(slot.shape, dtype=x.dtype, device="cpu" if staged else x.device)
+        if src is not None:
+            halo = torch.empty((h, w, Ch), dtype=x.dtype, device=x.device)
+            rbuf = torch.empty((h, w, Ch), dtype=x.dtype, device="cpu") if staged else halo        # RCCL receives straight into the kernels' buffer
             ops.append(dist.P2POp(dist.irecv, rbuf, src, self.group))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
-        if slot is not None:
-            slot.copy_(rbuf)
+        if staged and halo is not None:
+            halo.copy_(rbuf)
+        return halo

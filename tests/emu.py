@@ -6,6 +6,7 @@ host-prepared weights (shiftnet_amd/prep.py) and comparing with the oracle prove
 conventions agree, independently of a GPU.  (bf16 rounding is not emulated: everything here is fp32.)
 """
 import numpy as np
+import torch
 
 
 def frag_to_np(wfrag):
@@ -311,38 +312,42 @@ def cab_phase1(x, hwb, pk, mode, wrap):
     DPP neighbour fetches are index arithmetic of the kernel and not emulated; everything the HOST prepares (prep.pack_phase1) is decoded
     exactly as the kernel addresses it.  x [T,h,w,C] (bf16-representable), hwb [T,h,w,C/2] or None -> (g2 [T,h,w,C], sums [T,C])."""
     w1 = frag_to_np(pk["wfrag1"]); MT, KS = w1.shape[:2]
+    wx = np.zeros((MT, 1, 64, 8), np.float32); wx[:, 0, :16] = pk["wfragx"].float().numpy()      # LayerNorm k-step: only k-slots 0..7 (lanes 0..15)
+    w1x = np.concatenate([w1, wx], 1)
     w2 = pk["wfrag2"].float().numpy()
-    bias, wsum = pk["bias"].numpy(), pk["wsum"].numpy()
     t3 = pk["w3"].numpy().view(np.uint32); t5 = pk["w5"].numpy().view(np.uint32)
     T, h, w, C = x.shape; Ch = C // 2
     K = C + Ch if hwb is not None else C
     assert C == 64 and KS * 32 == K
+    bf = lambda v: torch.tensor(v, dtype=torch.float32).to(torch.bfloat16).float().numpy()      # noqa: E731
     xf = x.reshape(T, h * w, C)
     hf = hwb.reshape(T, h * w, Ch) if hwb is not None else None
     a = np.zeros((T, h * w, 2 * C), np.float32)           # natural a-channel order: first half | gate partners
     for t in range(T):
         f0, o0, f1, o1, _, _ = unit_slabs(T, C, t, mode, wrap)
         for i0 in range(0, h * w, 16):
-            bfrag = np.zeros((KS, 64, 8), np.float32)
-            st = np.zeros((16, 2), np.float32)
+            bfrag = np.zeros((KS + 1, 64, 8), np.float32)
+            rstd = np.zeros(16, np.float32)
             for p in range(16):
                 i = min(i0 + p, h * w - 1)
                 u = np.concatenate([xf[f0, i, o0:o0 + Ch], xf[f1, i, o1:o1 + Ch]] + ([hf[t, i]] if hf is not None else []))
-                mean = u.sum() / K; var = max((u * u).sum() / K - mean * mean, 0.0)
-                rstd = 1.0 / np.sqrt(var + 1e-6)
-                st[p] = (rstd, -rstd * mean)
+                mean = np.float32(u.sum() / K); var = np.float32(max((u * u).sum() / K - mean * mean, 0.0))
+                ve = np.float32(var + np.float32(1e-6))
+                rstd[p] = np.float32(1.0) / np.sqrt(ve)
+                sigma = np.float32(ve * rstd[p])
+                m_hi = bf(-mean); m_lo = bf(np.float32(-mean - m_hi)); s_hi = bf(sigma); s_lo = bf(np.float32(sigma - s_hi))
+                bfrag[KS, p] = (m_hi, m_hi, m_lo, m_lo, s_hi, s_hi, s_lo, s_lo)            # lane group 0; groups 1..3 read the zero slot
                 for g in range(4):
                     for s in range(KS):
                         bfrag[s, g * 16 + p] = u[s * 32 + g * 8: s * 32 + g * 8 + 8]          # RAW operands
-            regs = mfma_tiles(w1, bfrag)
+            regs = mfma_tiles(w1x, bfrag)
             for lane in range(64):
                 g, p = lane >> 4, lane & 15
                 if i0 + p >= h * w:
                     continue
                 for q in range(4):
                     for half in range(2):
-                        pos = g * 4 * MT + (2 * q + half) * 4
-                        v = st[p, 0] * regs[2 * q + half, lane] + (st[p, 1] * wsum[pos:pos + 4] + bias[pos:pos + 4])
+                        v = rstd[p] * regs[2 * q + half, lane]
                         c0 = half * C + 16 * g + 4 * q
                         a[t, i0 + p, c0:c0 + 4] = v.astype(np.float16).astype(np.float32)
     a = a.reshape(T, h, w, 2 * C)
@@ -392,5 +397,5 @@ def cab_phase1(x, hwb, pk, mode, wrap):
                 for q in range(4):
                     b1, b2 = regs[2 * q, lane], regs[2 * q + 1, lane]
                     c0 = 16 * g + 4 * q
-                    g2[t, i0 + p, c0:c0 + 4] = b1 / (1.0 + np.exp(-b2))
+                    g2[t, i0 + p, c0:c0 + 4] = b1 / (1.0 + np.exp2(b2))          # the gate rows carry -log2(e)
     return g2.reshape(T, h, w, C), g2.sum(1)

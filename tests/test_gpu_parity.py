@@ -264,7 +264,7 @@ def _gsts_pieces(eng_sd, name, tag):
 
 @pytest.mark.parametrize("T,h,w", [(3, 7, 21), (2, 5, 9), (2, 13, 70), (3, 40, 200), (2, 97, 130), (1, 64, 42), (1, 3, 40)])
 def test_cab_phase1_fused_kernel(T, h, w, engines):
-    """sn_cab_phase1 (fused LayerNorm -> 1x1 -> dw3x3 -> gate -> dw5x5 -> 1x1 -> gate2, csrc/sn_phase1.hip) alone against the reference's
+    """sn_gsts_cab2_phase1 / sn_cab1_phase1 (fused LayerNorm -> 1x1 -> dw3x3 -> gate -> dw5x5 -> 1x1 -> gate2, csrc/sn_phase1.hip) alone against the reference's
     g2 and its channel sums, CAB1 and both CAB2 directions: maps smaller than the 6 warm-up rows / the 48-pixel region, one strip, several
     strips with a ragged last one, several row segments."""
     from shiftnet_amd import lib as L
@@ -296,13 +296,11 @@ def test_cab_phase1_fused_kernel(T, h, w, engines):
                 hwd = None
         p1 = eng.P.units[pre]["p1"]
         src = L.UnitSrc(xd.data_ptr(), T, h, w, C, mode, 1 if (V.wrap and mode) else 0)
-        nblk = eng.lib.sn_cab_phase1_blocks(T, h, w)
+        nblk = eng.lib.sn_phase1_pool_blocks(T, h, w)
         assert nblk >= 1
         g2 = torch.full((T, h, w, C), float("nan"), dtype=torch.bfloat16, device=DEV)
         pool = torch.full((T, nblk, C), float("nan"), dtype=torch.float32, device=DEV)
-        L.check(eng.lib.sn_cab_phase1(C_byref(src), hwd.data_ptr() if hwd is not None else None, p1["wfrag1"].data_ptr(), p1["bias"].data_ptr(),
-                                      p1["wsum"].data_ptr(), p1["w3"].data_ptr(), p1["w5"].data_ptr(), p1["wfrag2"].data_ptr(), g2.data_ptr(),
-                                      pool.data_ptr(), st), "sn_cab_phase1")
+        L.check(L.cab_phase1(eng.lib, src, hwd.data_ptr() if hwd is not None else None, p1["desc"], g2.data_ptr(), pool.data_ptr(), st), "phase 1")
         check(f"phase1_g2_{mode}_{T}x{h}x{w}", to_cpu(g2, C), ref, 1.2e-2)
         sums = pool.sum(1).cpu()
         rs = ref.sum((2, 3))
@@ -555,6 +553,19 @@ def test_hipgraph_replay_is_bit_identical_to_eager():
         t_eager = (time.perf_counter() - t0) / 5
     assert any(isinstance(v, tuple) for v in eng._graphs.values()), "no graph was captured"
     assert torch.equal(outs[0], ea) and torch.equal(outs[1], ea) and torch.equal(outs[2], eb) and torch.equal(outs[3], ea)
+    # the cache is an LRU with GRAPH_SLOTS captured graphs: a client that varies the window shape does not pin one activation pool per shape
+    eng.use_graph = True
+    try:
+        with torch.no_grad():
+            for T in (5, 6, 7):
+                xs = xa[:, :T].contiguous()
+                e = net(xs); c = net(xs); r = net(xs)
+                assert torch.equal(e, c) and torch.equal(e, r)
+            live = [k for k, v in eng._graphs.items() if isinstance(v, tuple)]
+            assert len(live) == eng.GRAPH_SLOTS and live[-1][0][0] == 7
+            assert torch.equal(net(xa), ea)                 # the evicted signature still works (eager again, then re-captured)
+    finally:
+        eng.use_graph = False
     REPORT.append({"name": "hipgraph_small_clip", "ms_eager": 1e3 * t_eager, "ms_graph": 1e3 * t_graph})
 
 

@@ -1,14 +1,15 @@
 """Intra-window temporal split (shiftnet_amd/temporal_split.py).
 
-CPU part (gloo, world 2 and 3): the halo exchange and the boundary rules, checked against the CPU oracle -- every rank
-rebuilds the gathered 1.5C-channel input of a shifted unit for ITS frames from its local frames plus the halo slot, and the
+CPU part (gloo, world 2, 3 and 8): the halo exchange and the boundary rules, checked against the CPU oracle -- every rank
+rebuilds the gathered 1.5C-channel input of a shifted unit for ITS frames from its local frames plus the received half-frame, and the
 concatenation over ranks must equal the oracle's gather on the whole window, bit for bit, for circular (deblur2) and kept
 (all other variants) boundaries and both directions; a whole oracle shift block run rank-locally with the exchange before
 every unit must equal the single-process block.
 
 GPU part (-m gpu): two processes on the one MI355X of the GPU box, gloo for the exchange (RCCL refuses two ranks on one
 device), each running the HIP engine on half of a window: the concatenated output equals the single-process long-window
-output BIT FOR BIT for Shift-Net-s (circular ring between the two ranks) and Shift-Net+ (kept boundaries).
+output BIT FOR BIT for Shift-Net-s (circular ring between the two ranks) and Shift-Net+ (kept boundaries), AND the CPU oracle's
+output on the long window (>= 48 dB for bf16 modules, 1e-4 for float32 ones).
 """
 import os
 import socket
@@ -35,27 +36,26 @@ def _setup(rank, world, port):
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
 
-def _halo_tensor(x_nchw):
-    """[T,C,h,w] -> NHWC unit input allocated like Engine._new in split mode: the middle of a [T+2,h,w,C] buffer."""
-    T, C, h, w = x_nchw.shape
-    buf = torch.full((T + 2, h, w, C), float("nan"))
-    v = buf[1:T + 1]
-    v.copy_(x_nchw.permute(0, 2, 3, 1))
-    return v
+def _nhwc(x_nchw):
+    return x_nchw.permute(0, 2, 3, 1).contiguous()
 
 
-def _local_gather(O, v, mode, flag):
-    """The unit's gathered input for the LOCAL frames from the halo-padded tensor and the kernel flag (0 keep, 1 circular, 2 halo)."""
-    base = v._base
-    T = v.shape[0]
-    nchw = lambda t: t.permute(0, 3, 1, 2).contiguous()
+def _local_gather(O, x_local, halo, mode, flag):
+    """The unit's gathered 1.5C-channel input for the LOCAL frames, from the local frames, the received half-frame `halo` ([h,w,C/2], what the
+    kernels get as sn_unit_src.halo) and the kernel flag (0 keep, 1 circular, 2 halo) -- the rule csrc/sn_common.h: sn_unit_slabs implements."""
     rev = mode == 2
-    if flag == 2:      # neighbour in the halo slot: gather on [slot, local] / [local, slot] and drop the extra row
-        ext = nchw(base[0:T + 1] if not rev else base[1:T + 2]).clone()
-        ext[torch.isnan(ext)] = 0.0                                    # the half of the slot nobody fills (and nobody reads)
-        g = O.gsts_gather(ext, rev, False)
-        return g[1:] if not rev else g[:-1]
-    return O.gsts_gather(nchw(v), rev, flag == 1)
+    if flag != 2:
+        return O.gsts_gather(x_local, rev, flag == 1)
+    T, C, h, w = x_local.shape
+    nb = torch.zeros((1, C, h, w))                                       # the neighbour frame: only the borrowed half exists on this rank
+    hh = halo.permute(2, 0, 1)
+    if not rev:
+        nb[0, C // 2:] = hh                                              # forward units borrow the UPPER half of the previous frame
+        g = O.gsts_gather(torch.cat((nb, x_local)), False, False)
+        return g[1:]
+    nb[0, :C // 2] = hh                                                  # reverse units the LOWER half of the next frame
+    g = O.gsts_gather(torch.cat((x_local, nb)), True, False)
+    return g[:-1]
 
 
 def _cpu_worker(rank, world, port, circular):
@@ -67,39 +67,58 @@ def _cpu_worker(rank, world, port, circular):
     name = "gshift_deblur2" if circular else "gshift_denoise2"         # both C = 64, 4 units per block
     V = O.VARIANTS[name]
     assert V.wrap == circular
-    T, C, h, w = 7, V.c1, 20, 24
+    T, C, h, w = max(7, world + 3), V.c1, 20, 24
     x = torch.from_numpy(synth.unit_noise((T, C, h, w), seed=55))
     a, b = partition(T, world)[rank]
     sp = TemporalSplit(rank, world, circular)
+    sp.validate(b - a)
     for mode in (1, 2):
-        v = _halo_tensor(x[a:b])
-        sp.exchange(v, mode)
-        mine = _local_gather(O, v, mode, sp.wrap_flag(mode) if (circular or sp.wrap_flag(mode) == 2) else 0)
+        halo = sp.exchange(_nhwc(x[a:b]), mode, circular)
+        flag = sp.wrap_flag(mode, circular)
+        assert (halo is not None) == (flag == 2) and (halo is None or (halo.is_contiguous() and tuple(halo.shape) == (h, w, C // 2)))
+        mine = _local_gather(O, x[a:b], halo, mode, flag)
         full = O.gsts_gather(x, mode == 2, circular)
         assert torch.equal(mine, full[a:b]), (rank, mode)
+        # Shift_CAB's roll never wraps, also on a circular module: the window's outer ranks keep their boundary frame
+        flag_nc = sp.wrap_flag(mode, False)
+        assert flag_nc == (2 if (rank > 0 if mode == 1 else rank < world - 1) else 0)
+        sp.exchange(_nhwc(x[a:b]), mode, False)
     # a whole shift block, rank-local, with one exchange per unit
-    sd = synth_state_dict(name)
-    blk = "stage1.decoder_level1."
-    with torch.no_grad():
-        ref = O.shift_block(sd, blk, x, V)
-        cur = x[a:b]
-        for i in range(V.units):
-            mode = 2 if i % 2 else 1
-            v = _halo_tensor(cur)
-            sp.exchange(v, mode)
-            flag = sp.wrap_flag(mode) if (circular or sp.wrap_flag(mode) == 2) else 0
-            u = _local_gather(O, v, mode, flag)
-            pre = f"{blk}{O._UNIT_NAMES[i]}."
-            cur = O.cab1(sd, pre + "1.", O.cab2(sd, pre + "0.", u, V), V)
-    assert torch.allclose(cur, ref[a:b], rtol=0, atol=2e-6 * float(ref.abs().max())), rank
+    if world <= 3:
+        sd = synth_state_dict(name)
+        blk = "stage1.decoder_level1."
+        with torch.no_grad():
+            ref = O.shift_block(sd, blk, x, V)
+            cur = x[a:b]
+            for i in range(V.units):
+                mode = 2 if i % 2 else 1
+                halo = sp.exchange(_nhwc(cur), mode, circular)
+                u = _local_gather(O, cur, halo, mode, sp.wrap_flag(mode, circular))
+                pre = f"{blk}{O._UNIT_NAMES[i]}."
+                cur = O.cab1(sd, pre + "1.", O.cab2(sd, pre + "0.", u, V), V)
+        assert torch.allclose(cur, ref[a:b], rtol=0, atol=2e-6 * float(ref.abs().max())), rank
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("circular", [True, False])
+@pytest.mark.parametrize("world,circular", [(2, True), (2, False), (3, True), (3, False), (8, True)])
 def test_halo_exchange_and_boundaries_cpu(world, circular):
+    """gloo ranks on CPU: the exchange (contiguous receive buffers), the boundary rules and -- world 8, deblur2 -- the closed ring."""
     mp.spawn(_cpu_worker, args=(world, _free_port(), circular), nprocs=world, join=True)
+
+
+def _empty_rank_worker(rank, world, port):
+    _setup(rank, world, port)
+    from shiftnet_amd.temporal_split import TemporalSplit
+    sp = TemporalSplit(rank, world, False)
+    with pytest.raises(ValueError):
+        sp.validate(0 if rank == 1 else 3)          # ONE rank has nothing to restore: EVERY rank raises, nobody is left in an exchange
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_empty_rank_is_refused_collectively():
+    mp.spawn(_empty_rank_worker, args=(2, _free_port()), nprocs=2, join=True)
 
 
 def test_partition():
@@ -148,4 +167,24 @@ def test_temporal_split_equals_long_window_bit_for_bit(name, dt, tmp_path):
     full = np.load(tmp_path / "full.npy")
     parts = np.concatenate([np.load(tmp_path / f"part{r}.npy") for r in range(world)], 0)
     assert parts.shape == full.shape == (6, 3, 48, 64)
-    assert np.array_equal(parts, full)
+    assert np.array_equal(parts, full)                                   # split HIP == unsplit HIP, bit for bit
+    # ... and against the CPU oracle on the long window (the reference restated), not only against ourselves
+    for p in (ROOT, os.path.join(ROOT, "shift-net_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from oracle import shiftnet_oracle as O
+    from shiftnet_amd import synth
+    from shiftnet_amd.weights import synth_state_dict
+    V = O.VARIANTS[name]
+    blur, _ = synth.blurred_clip(10, 48, 64, seed=17)
+    x = O.frames_to_tensor(list(blur))
+    tdt = getattr(torch, dt)
+    xq = x.to(tdt).float()                                                # the module input is rounded to its dtype
+    nm = torch.full((1, 10, 1, 48, 64), 30.0 / 255.0).to(tdt).float() if V.denoise else None
+    with torch.no_grad():
+        ref = O.forward(V, synth_state_dict(name), xq, nm, 2, 2).numpy()
+    if dt == "float32":
+        assert np.abs(parts - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    else:
+        mse = float(np.mean((parts - ref) ** 2))
+        assert 10 * np.log10(1.0 / mse) >= 48.0

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fused phase-1 kernel (sn_cab_phase1) against the oracle, with a breakdown of where any error sits (row / column / channel -> wave q,
+"""Fused phase-1 kernel (sn_gsts_cab2_phase1 / sn_cab1_phase1) against the oracle, with a breakdown of where any error sits (row / column / channel -> wave q,
 lane group g, register r), then its time at the level-1 and level-2 sizes of config 2 next to sn_ln_gemm_gate + sn_dw5m_gemm_gate.
 usage: check_phase1.py [--no-time]"""
 import ctypes as C
@@ -42,11 +42,9 @@ def main():
         T, h, w, c = xd.shape
         src = L.UnitSrc(xd.data_ptr(), T, h, w, c, mode, 1 if (V.wrap and mode) else 0)
         g2 = torch.full((T, h, w, c), float("nan"), dtype=torch.bfloat16, device=dev)
-        nblk = lib.sn_cab_phase1_blocks(T, h, w)
+        nblk = lib.sn_phase1_pool_blocks(T, h, w)
         pool = torch.zeros((T, nblk, c), dtype=torch.float32, device=dev)
-        L.check(lib.sn_cab_phase1(C.byref(src), hwb.data_ptr() if hwb is not None else None, u["wfrag1"].data_ptr(), u["bias"].data_ptr(),
-                                  u["wsum"].data_ptr(), u["w3"].data_ptr(), u["w5"].data_ptr(), u["wfrag2"].data_ptr(), g2.data_ptr(),
-                                  pool.data_ptr(), st), "sn_cab_phase1")
+        L.check(L.cab_phase1(lib, src, hwb.data_ptr() if hwb is not None else None, u["desc"], g2.data_ptr(), pool.data_ptr(), st), "phase 1")
         torch.cuda.synchronize()
         return g2, pool, nblk
 
@@ -95,15 +93,14 @@ def main():
             u = P.units[pre]
             src = L.UnitSrc(xd.data_ptr(), T, h, w, Cc, mode, 1 if mode else 0)
             g2 = torch.empty((T, h, w, Cc), dtype=torch.bfloat16, device=dev)
-            nblk = lib.sn_cab_phase1_blocks(T, h, w)
+            nblk = lib.sn_phase1_pool_blocks(T, h, w)
             pool = torch.zeros((T, nblk, Cc), dtype=torch.float32, device=dev)
             p1 = u["p1"]
             g1 = torch.empty((T, h, Cc, lib.sn_planar_pitch(w)), dtype=torch.bfloat16, device=dev)
             pool2 = torch.empty((T, lib.sn_dw5m_blocks(h, w), Cc), dtype=torch.float32, device=dev)
             hp = hwb.data_ptr() if mode else None
             calls = {
-                "sn_cab_phase1": lambda: lib.sn_cab_phase1(C.byref(src), hp, p1["wfrag1"].data_ptr(), p1["bias"].data_ptr(), p1["wsum"].data_ptr(),
-                                                           p1["w3"].data_ptr(), p1["w5"].data_ptr(), p1["wfrag2"].data_ptr(), g2.data_ptr(), pool.data_ptr(), st),
+                "phase1 fused": lambda: L.cab_phase1(lib, src, hp, p1["desc"], g2.data_ptr(), pool.data_ptr(), st),
                 "K12": lambda: lib.sn_ln_gemm_gate(C.byref(src), hp, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(), u["w_dw3_h2"].data_ptr(), g1.data_ptr(), None, 2, st),
                 "K3m": lambda: lib.sn_dw5m_gemm_gate(g1.data_ptr(), None, u["w_toep5"].data_ptr(), u["w_gate"].data_ptr(), g2.data_ptr(), pool2.data_ptr(), T, h, w, Cc, st),
             }

@@ -74,7 +74,7 @@ def main():
             rec(f"m{mode}.ca2", ca2, store)
             y = eng._new(T, h, w, c)
             b_out = u["b_out"].data_ptr() if u["b_out"] is not None else None
-            L.check(lib.sn_scale_gemm_res(C.byref(src), g2.data_ptr(), ca2.data_ptr(), u["w_out"].data_ptr(), b_out, y.data_ptr(), st), "k4")
+            L.check((lib.sn_gsts_cab2_phase2 if src.mode else lib.sn_cab1_phase2)(C.byref(src), g2.data_ptr(), ca2.data_ptr(), u["w_out"].data_ptr(), b_out, y.data_ptr(), st), "k4")
             rec(f"m{mode}.K4.y", y, store)
     store = {}
     c0 = V.c0

@@ -46,7 +46,7 @@ def main():
                                                g1.data_ptr(), None, 2 if mst else 0, st),
             "K3": (lambda: lib.sn_dw5m_gemm_gate(g1.data_ptr(), None, u["w_toep5"].data_ptr(), u["w_gate"].data_ptr(), g2.data_ptr(), pool2.data_ptr(), T, h, w, c, st))
             if mst else (lambda: lib.sn_grp5_gemm_gate(g1.data_ptr(), None, u["w_grp"].data_ptr(), u["w_gate"].data_ptr(), g2.data_ptr(), pool2.data_ptr(), T, h, w, c, st)),
-            "K4": lambda: lib.sn_scale_gemm_res(C.byref(src), g2.data_ptr(), ca2.data_ptr(), u["w_out"].data_ptr(), b_out, y.data_ptr(), st),
+            "K4": lambda: (lib.sn_gsts_cab2_phase2 if src.mode else lib.sn_cab1_phase2)(C.byref(src), g2.data_ptr(), ca2.data_ptr(), u["w_out"].data_ptr(), b_out, y.data_ptr(), st),
         }
         for k, f in calls.items():
             for _ in range(3):
