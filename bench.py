@@ -151,7 +151,11 @@ def main():
     ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS), help="BASELINE.json config preset (default: 2)")
     ap.add_argument("--dtype", default=None, choices=list(DTYPES), help="module dtype (fp32 runs the fp32 engine)")
     ap.add_argument("--quadrants", action="store_true", help="denoise CLI tiling: 4 overlapping quadrants per step")
+    ap.add_argument("--lib", default=None, help="A/B measurements only: another build of libshiftnet_hip.so (the line then carries its path)")
     args = ap.parse_args()
+    if args.lib:
+        from shiftnet_amd import lib as _L
+        _L.LIB_PATH = os.path.abspath(args.lib)
     if args.config is not None:
         c = CONFIGS[args.config]
         args.variant, args.height, args.width, args.one_len = c["variant"], c["height"], c["width"], c["one_len"]
@@ -374,7 +378,8 @@ def main():
                                    + ("as the denoise CLI's 4 quadrants of %dx%d, " % (ww, hh) if args.quadrants else "")
                                    + (f"module dtype {args.dtype}, " if args.dtype != "bf16" else "")
                                    + "one window per GPU, synthetic checkpoint", "parallelism": f"clip-parallel x{world}",
-                       "baseline_config": args.config if args.config is not None else (2 if (args.variant, h, w, L) == (VARIANT, H, W, ONE_LEN) else None)},
+                       "baseline_config": args.config if args.config is not None else (2 if (args.variant, h, w, L) == (VARIANT, H, W, ONE_LEN) else None),
+                       **({"ab_library": args.lib} if args.lib else {})},
             # the roofline this path is graded on is the FUSED GSTS UNIT (channel_shift + CAB2 + CAB1: read x, write y per
             # CAB = 4 T C h w s bytes) over the time of every GSTS kernel; intermediates count zero bytes.
             "roofline": {"bound": "hbm", "scope": "fused GSTS unit (SURVEY.md 8d), all pyramid levels of one window", "achieved": round(ach_unit, 1),

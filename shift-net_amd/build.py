@@ -18,13 +18,14 @@ def needs_build(out: str = OUT) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build(OUT):
-        return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+def build(force: bool = False, verbose: bool = False, out: str = OUT, flags=()) -> str:
+    """out / flags: one-off variant libraries for A/B runs (tools/); the product is OUT with no flags."""
+    if not force and not needs_build(out):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize",
-           "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", out, *flags] + [os.path.join(CSRC, s) for s in SOURCES]
     for f in os.environ.get("SN_HIPCC_FLAGS", "").split():      # extra compiler flags for one-off builds (e.g. --save-temps)
         cmd.insert(1, f)
     if verbose:
@@ -35,7 +36,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError("hipcc failed")
     if verbose:
         sys.stderr.write(r.stderr)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -68,6 +68,10 @@ constexpr int sn_conv_waves(int mt, int th) {         // generic conv: 8x32 / 4x
 }
 // (feat_extract.0 -- 8 input channels -- and the concatenating 3x3 convs rconcat / conv_hr0 stay on the generic kernel: routing them
 // through conv3_fast_kernel measured neutral in round 2, 122.7 vs 122.0 ms and 673.7 vs 664.8 ms.)
+// (Round 3 A/B: 4-row tiles for >= 3 M-tiles -- 2 N-tiles per wave: 40 / 48 channels 76-80 registers and 19.6 KB of LDS = 6 waves per SIMD
+// instead of 4 / 3, 64 and 80 channels 4 instead of 2 -- measured SLOWER: config 3 679.8 -> 708.1 ms (the 40 / 48-channel convs 141.0 ->
+// 160.6 ms, 80-channel 17.5 -> 20.8), config 5 window 464.6 -> 480.5 ms.  The wide convs are not short of occupancy any more; halving
+// the tile raises the halo reads 1.33x -> 1.59x and doubles the weight-fragment fetches per pixel, 36-115 KB per workgroup and tile.)
 constexpr int sn_conv3_waves(int mt, int cs) {
     return mt == 1 ? 7 : mt == 2 ? 6 : mt == 3 ? (cs == 48 ? 3 : 4) : mt == 4 ? 3 : 2;
 }
@@ -750,6 +754,12 @@ int sn_ingest(const void* src, int dt, const void* noise, void* dst, int T, int 
     return sn_check_launch();
 }
 
+// key of the specialised single-input 3x3 path (M-tiles * 1000 + channels), 0: the generic kernel
+static int conv3_key(const sn_conv_desc* d) {
+    if (!(d->k == 3 && d->stride == 1 && d->pad == 1 && d->in_mode == 0 && d->out_mode == 0 && d->n_in == 1 && d->ks == (9 * d->cs_in + 31) / 32)) return 0;
+    const int key = d->mt * 1000 + d->cs_in;
+    return (key == 1016 || key == 2024 || key == 4064 || key == 3040 || key == 3048 || key == 5080) ? key : 0;
+}
 static void conv_tile(const sn_conv_desc* d, int* th, int* tw) {
     if (d->stride == 1) { *tw = 32; *th = 8; }   // (16x32 tiles for narrow convs measured slower: 47.4 vs 44.2 ms per window)
     else { *th = 4; *tw = 16; }
@@ -783,11 +793,9 @@ int sn_conv2d(const sn_conv_desc* d, void* stream) {
     K.ps = d->stride == 1 ? 16 * sn_lds_slots(blocks) : ((blocks & 1) ? K.cv * 2 : K.cv * 2 + 16);     // stride 2: odd slot count (pixels 2 apart)
     K.rh = K.rw = 0;
     int th, tw; conv_tile(d, &th, &tw);
-    if (d->k == 3 && d->stride == 1 && d->pad == 1 && d->in_mode == 0 && d->out_mode == 0 && d->ks == (9 * d->n_in * d->cs_in + 31) / 32) {
-        // the specialised single-input 3x3 path (same tile shape: sn_conv_pool_blocks is unchanged); key = M-tiles, channels
+    {   // the specialised single-input 3x3 path; key = M-tiles, channels
         hipStream_t st = (hipStream_t)stream;
-        const int key = d->n_in == 1 ? d->mt * 1000 + d->cs_in : 0;
-        switch (key) {
+        switch (conv3_key(d)) {
             case 1016: return launch_conv3_fast<1, 16>(K, d->T, st);
             case 2024: return launch_conv3_fast<2, 24>(K, d->T, st);
             case 4064: return launch_conv3_fast<4, 64>(K, d->T, st);

@@ -40,14 +40,19 @@ def main():
         pool2 = torch.empty((T, nb, c), dtype=torch.float32, device=dev)
         ca2 = torch.ones((T, c + 16), dtype=torch.float32, device=dev)
         b_out = u["b_out"].data_ptr() if u["b_out"] is not None else None
+        fused = "p1" in u                 # Shift-Net-s deblur: phase 1 is one kernel (sn_gsts_cab2_phase1)
+        pool1 = torch.empty((T, max(lib.sn_phase1_pool_blocks(T, h, w), 1), c), dtype=torch.float32, device=dev)
         calls = {
             "K0": lambda: lib.sn_gsts_shiftconv(C.byref(src), P.offs.data_ptr(), u["w1"].data_ptr(), hwb.data_ptr(), st),
+            "P1": lambda: L.cab_phase1(lib, src, hwb.data_ptr(), u["p1"]["desc"], g2.data_ptr(), pool1.data_ptr(), st),
             "K12": lambda: lib.sn_ln_gemm_gate(C.byref(src), hwb.data_ptr(), u["w_ln"].data_ptr(), u["b_ln"].data_ptr(), u["w_dw3_h2"].data_ptr(),
                                                g1.data_ptr(), None, 2 if mst else 0, st),
             "K3": (lambda: lib.sn_dw5m_gemm_gate(g1.data_ptr(), None, u["w_toep5"].data_ptr(), u["w_gate"].data_ptr(), g2.data_ptr(), pool2.data_ptr(), T, h, w, c, st))
             if mst else (lambda: lib.sn_grp5_gemm_gate(g1.data_ptr(), None, u["w_grp"].data_ptr(), u["w_gate"].data_ptr(), g2.data_ptr(), pool2.data_ptr(), T, h, w, c, st)),
             "K4": lambda: (lib.sn_gsts_cab2_phase2 if src.mode else lib.sn_cab1_phase2)(C.byref(src), g2.data_ptr(), ca2.data_ptr(), u["w_out"].data_ptr(), b_out, y.data_ptr(), st),
         }
+        for k in (("K12", "K3") if fused else ("P1",)):
+            del calls[k]
         for k, f in calls.items():
             for _ in range(3):
                 L.check(f(), k)
@@ -59,7 +64,7 @@ def main():
                 f()
             e1.record(); torch.cuda.synchronize()
             res[(k, T)] = e0.elapsed_time(e1) / n * 1e3 / T
-        # the chain K0 -> K12 -> K3 -> K4 back to back (producer/consumer through the cache when T = 3)
+        # the chain K0 -> (P1 | K12 -> K3) -> K4 back to back (producer/consumer through the cache when T = 3)
         for _ in range(2):
             for f in calls.values():
                 f()
@@ -73,7 +78,9 @@ def main():
         e1.record(); torch.cuda.synchronize()
         res[("chain", T)] = e0.elapsed_time(e1) / n * 1e3 / T
     print(f"{name}: us per FRAME at 360x640 (T=3: Infinity-Cache resident, T=20: streaming)")
-    for k in ("K0", "K12", "K3", "K4", "chain"):
+    for k in ("K0", "P1", "K12", "K3", "K4", "chain"):
+        if (k, 3) not in res:
+            continue
         a, b = res[(k, 3)], res[(k, 20)]
         print(f"  {k:6s} warm {a:7.2f}   cold {b:7.2f}   warm/cold {a / b:5.2f}")
 
