@@ -212,24 +212,21 @@ __global__ __launch_bounds__(256) void conv32m_kernel(const Conv32K P) {
             for (int tap = 0; tap < ntap; ++tap) {
                 wload(tap + 1 < ntap ? tap + 1 : tap, wn);                                 // next tap's weights: in flight during this tap's MFMAs
                 const int dy = tap / P.k, dx = tap - dy * P.k, toff = (dy * rw + dx) * C32_PSL + 16 * sb;
-                // k-step outermost, then N-tile, then M-tile: consecutive MFMAs go to DIFFERENT accumulators (a dependent v_mfma_f32_16x16x4_f32
-                // issues after 40 cycles, an independent one after 32) -- also for the grouped conv, where a block feeds ONE M-tile.  Every
-                // accumulator still sees its k-steps in the same order: results are bit-identical to the m-outer form.
-                float bk[NTW][4];
+                // (k-step outermost, so that consecutive MFMAs go to different accumulators -- a dependent v_mfma_f32_16x16x4_f32 issues after
+                // 40 cycles, an independent one after 32 -- measured SLOWER, bit-identical: 744 -> 791 ms per quadrant forward, the grouped 5x5
+                // 1465 -> 1777 us.  The B fragments of all N-tiles are then live at once and the kernel is not MFMA-issue-bound.)
 #pragma unroll
                 for (int n = 0; n < NTW; ++n) {
                     const float4 b = *(const float4*)(smem32 + pixbase[n] + toff);
-                    bk[n][0] = b.x; bk[n][1] = b.y; bk[n][2] = b.z; bk[n][3] = b.w;
+#pragma unroll
+                    for (int m = 0; m < MTC; ++m) {
+                        if (m < m_lo || m >= m_hi) continue;                               // workgroup-uniform
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][0], b.x, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][1], b.y, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][2], b.z, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][3], b.w, acc[m][n], 0, 0, 0);
+                    }
                 }
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-                    for (int n = 0; n < NTW; ++n)
-#pragma unroll
-                        for (int m = 0; m < MTC; ++m) {
-                            if (m < m_lo || m >= m_hi) continue;                           // workgroup-uniform
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][s2], bk[n][s2], acc[m][n], 0, 0, 0);
-                        }
 #pragma unroll
                 for (int m = 0; m < MTC; ++m)
 #pragma unroll

@@ -43,6 +43,9 @@ __global__ void gather_kernel(const UnitK U, const int8_t* offs, bf16_t* u, cons
 // PP = 8-channel chunks of the 34 x 34 window staged per pass = the whole borrowed half at once: 79 / 97 KB of LDS = two / one
 // 4-wave workgroups per CU.  (Two chunks per pass -- 42 KB, three workgroups per CU -- measured slower in round 2: 12.4 vs 10.1 ms
 // per window of config 2, 51.8 vs 48.9 ms of config 3.)
+// Not VALU-bound either, although 38 % of its wave cycles issue VALU: a round-3 build with the staging loop's index arithmetic made
+// incremental (~750 instead of ~1170 VALU per wave, bit-identical) measured 10.68 vs 10.30 ms per window on the same box.  What the
+// kernel waits for is its own load -> LDS -> barrier -> compute chain at two workgroups per CU.
 template <int CH, int PP>
 __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const XcdTiles G, const int8_t* __restrict__ offs,
                                                       const uint32_t* __restrict__ w1d, bf16_t* hw) {
