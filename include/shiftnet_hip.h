@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 5      /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
+#define SN_ABI_VERSION 6      /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
 
 /* element types of NCHW tensors exchanged with the PyTorch side */
 #define SN_F32 0
@@ -186,9 +186,20 @@ typedef struct sn_phase1_weights {
     const uint32_t* w5;
     const void* wfrag2;
 } sn_phase1_weights;
+/* Optional fold of CALayer2's squeeze-excite MLP (gshift_deblur1.py:76-87) into phase 1: the LAST workgroup of a frame to finish reduces
+ * the frame's partial sums in a fixed order (bit-reproducible whichever workgroup that is) and writes ca[t][C] = sigmoid(wb relu(wa mean)),
+ * so no sn_ca_mlp launch sits between the phases.  wa:[cr][c], wb:[c][cr] f32 (conv_du.0 / conv_du.2), c == C.
+ * ticket: [>= T] u32 counters, ZERO before the first use; every launch leaves them zero again.  NULL: partial sums only. */
+typedef struct sn_se_fold {
+    const float* wa;
+    const float* wb;
+    int c, cr;
+    unsigned* ticket;
+    float* ca;
+} sn_se_fold;
 int sn_phase1_pool_blocks(int T, int h, int w);
-int sn_gsts_cab2_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, void* stream);
-int sn_cab1_phase1(const sn_unit_src* s, const sn_phase1_weights* wt, void* g2, float* pool, void* stream);
+int sn_gsts_cab2_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se, void* stream);
+int sn_cab1_phase1(const sn_unit_src* s, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se, void* stream);
 
 /* PHASE 2, all variants (C = 64 / 80): y = shortcut + beta * body[7](ca * g2) (gshift_deblur1.py:201,210,254): beta and the optional bias
  * are folded into wfrag / bias; the shortcut is the ROLLED tensor for CAB2 (s->mode 1 / 2: sn_gsts_cab2_phase2) and x itself for CAB1

@@ -124,6 +124,62 @@ __device__ __forceinline__ SnSlabs<E> sn_unit_slabs(const E* x, const E* halo, i
     return s;
 }
 
+// ---- squeeze-excite folded into its producer (shiftnet_hip.h: sn_se_fold) -------------------------------------------------------
+// CALayer2 needs the global average pool of g2: every workgroup of a frame stores its partial channel sums, and the LAST workgroup of
+// the frame to finish (a ticket counter per frame) reduces them in a FIXED order -- so the result does not depend on which workgroup
+// was last: bit-reproducible -- and runs the C -> C/r -> C MLP, instead of a separate sn_ca_mlp launch between the two phases.
+// Inter-workgroup visibility (per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed by other CUs' stores;
+// cdna_hip_programming.md Guideline 16, counter form): partial sums leave as sc1 (write-through) stores -> every wave waits for
+// its stores (vmcnt(0)) -> workgroup barrier -> lane 0 takes the ticket with a relaxed agent-scope fetch_add; the last arriver issues an
+// agent-scope ACQUIRE fence, re-arms the counter and reads the partial sums with sc1 loads.
+struct SeFold { const float* wa; const float* wb; float* ca; unsigned* ticket; float inv_hw; int c, cr; };
+__device__ __forceinline__ void sn_pool_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// pool_t: [nblk][cpad] partial sums of frame t (this workgroup's row already stored with sn_pool_store); lds: >= 16 + nthreads + 2 * 128
+// floats, no longer read by anybody in the workgroup once its first barrier is passed; cpad <= 128, cr <= 128.  Called by ALL threads.
+__device__ __forceinline__ void sn_se_tail(const SeFold& S, const float* pool_t, int nblk, int cpad, int t, float* lds, int tid, int nthreads) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's partial-sum stores are acknowledged by memory
+    __syncthreads();
+    unsigned* flag = (unsigned*)lds;
+    if (tid == 0) *flag = __hip_atomic_fetch_add(S.ticket + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nblk - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!*flag) return;                                              // workgroup-uniform
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(S.ticket + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch on this stream
+    }
+    __syncthreads();
+    float* acc = lds + 16; float* mean = acc + nthreads; float* hid = mean + 128;
+    // the nblk rows are split over nthreads / cpad thread groups, each walks its rows in order; the groups are then added in order
+    const int parts = nthreads / cpad, ch = tid % cpad, part = tid / cpad;
+    float sm = 0.f;
+    if (part < parts) {
+#pragma unroll 8
+        for (int b = part; b < nblk; b += parts) sm += __hip_atomic_load(pool_t + (size_t)b * cpad + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    acc[tid] = sm;
+    __syncthreads();
+    if (tid < cpad) {
+        float m = 0.f;
+        for (int q = 0; q < parts; ++q) m += acc[q * cpad + tid];
+        mean[tid] = m * S.inv_hw;
+    }
+    __syncthreads();
+    if (tid < S.cr) {
+        float hsum = 0.f;
+        for (int j = 0; j < S.c; ++j) hsum += S.wa[tid * S.c + j] * mean[j];
+        hid[tid] = hsum > 0.f ? hsum : 0.f;
+    }
+    __syncthreads();
+    if (tid < cpad) {
+        float o = 0.f;
+        if (tid < S.c) {
+            for (int j = 0; j < S.cr; ++j) o += S.wb[tid * S.cr + j] * hid[j];
+            o = sigmoidf_(o);
+        }
+        S.ca[(size_t)t * cpad + tid] = o;                            // read by the NEXT kernel on the stream: the kernel boundary publishes it
+    }
+}
+
 // wave-uniform wave index (threadIdx-derived values are "divergent" to the compiler; make it provably uniform)
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 

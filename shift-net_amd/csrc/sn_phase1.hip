@@ -45,6 +45,7 @@ struct P1Args {
     const uint4* wfrag2;
     bf16_t* g2; float* pool;
     int nsx, nsy, seg, vw;
+    SeFold se;                           // se.ca == nullptr: partial channel sums only (sn_ca_mlp follows as its own launch)
 };
 
 __device__ __forceinline__ f32x4_t mfma16h(const uint4 a, const uint4 b, const f32x4_t c) {
@@ -402,8 +403,10 @@ __global__ __launch_bounds__(256, 2) void cab_phase1_kernel(const P1Args A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float sm = row_sum16(psum[r]);
-            if (p == 0) A.pool[((size_t)t * nblk + blk) * C + 16 * g + 4 * q + r] = sm;
+            if (p == 0) sn_pool_store(&A.pool[((size_t)t * nblk + blk) * C + 16 * g + 4 * q + r], sm);
         }
+        // the last workgroup of the frame finishes CALayer2 (lds_o is free: its last reader, store_row, is behind the tail's first barrier)
+        if (A.se.ca) sn_se_tail(A.se, A.pool + (size_t)t * nblk * C, nblk, C, t, (float*)&lds_o[0][0], tid, 256);
     }
 }
 
@@ -443,7 +446,7 @@ int sn_phase1_pool_blocks(int T, int h, int w) {
     return nsx * nsy;
 }
 
-static int cab_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, void* stream) {
+static int cab_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se, void* stream) {
     sn_clear_error();
     if (!s || !s->x || s->C != 64 || s->mode < 0 || s->mode > 2 || s->T < 1 || s->h < 1 || s->w < 1 || !wt || !wt->wfrag1 || !wt->wfragx || !wt->w3 ||
         !wt->w5 || !wt->wfrag2 || !g2 || (s->mode != 0 && !hw) || s->wrap < 0 || s->wrap > 2 || (s->wrap == 2 && s->mode != 0 && !s->halo)) return SN_EINVAL;
@@ -453,6 +456,12 @@ static int cab_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weig
     A.x = (const bf16_t*)s->x; A.halo = (const bf16_t*)s->halo; A.hwb = (const bf16_t*)hw; A.T = s->T; A.h = s->h; A.w = s->w; A.mode = s->mode; A.wrap = s->wrap;
     A.wfrag1 = (const uint4*)wt->wfrag1; A.wfragx = (const uint4*)wt->wfragx; A.w3 = wt->w3; A.w5 = wt->w5; A.wfrag2 = (const uint4*)wt->wfrag2;
     A.g2 = (bf16_t*)g2; A.pool = pool;
+    A.se.ca = nullptr;
+    if (se) {
+        if (!pool || !se->wa || !se->wb || !se->ticket || !se->ca || se->c != 64 || se->cr < 1 || se->cr > 128) return SN_EINVAL;
+        A.se.wa = se->wa; A.se.wb = se->wb; A.se.ca = se->ca; A.se.ticket = se->ticket; A.se.inv_hw = 1.0f / ((float)s->h * (float)s->w);
+        A.se.c = se->c; A.se.cr = se->cr;
+    }
     p1_partition(s->T, s->h, s->w, ncu, P1_VWMAX, A.nsx, A.vw, A.nsy, A.seg);       // from the WHOLE unit: it fixes the pool layout
     SN_FRAME_RANGE(s, t0, nt);
     A.t0 = t0;
@@ -463,14 +472,14 @@ static int cab_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weig
     return sn_check_launch();
 }
 
-int sn_gsts_cab2_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, void* stream) {
+int sn_gsts_cab2_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se, void* stream) {
     if (!s || (s->mode != 1 && s->mode != 2)) return SN_EINVAL;
-    return cab_phase1(s, hw, wt, g2, pool, stream);
+    return cab_phase1(s, hw, wt, g2, pool, se, stream);
 }
 
-int sn_cab1_phase1(const sn_unit_src* s, const sn_phase1_weights* wt, void* g2, float* pool, void* stream) {
+int sn_cab1_phase1(const sn_unit_src* s, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se, void* stream) {
     if (!s || s->mode != 0) return SN_EINVAL;
-    return cab_phase1(s, nullptr, wt, g2, pool, stream);
+    return cab_phase1(s, nullptr, wt, g2, pool, se, stream);
 }
 
 }  // extern "C"

@@ -210,6 +210,7 @@ class Engine:
         self._meta: Tuple = ()
         self.split = None                     # temporal_split.TemporalSplit: this engine holds a frame range of a longer window
         self._side = None                     # side stream of the halo exchanges (created on first use)
+        self._tickets = None                  # sn_se_fold frame counters: zero between launches (the kernels re-arm them)
         # hipGraph replay of the whole forward (~1400 launches per window), opt-in with SN_GRAPH=1: the first call with a given input
         # signature runs eagerly, the second one is captured, later ones replay, so the Python / ctypes / allocator work per launch
         # disappears.  Measured on MI355X: neutral at 1280x720 (126.4 vs 126.0 ms per window: the GPU is never starved there, kernels
@@ -301,6 +302,7 @@ class Engine:
         raise NotImplementedError("bf16 CABs apply the CALayer scale and the residual in conv2's epilogue (fused_cab_tail)")
 
     # ---- blocks (oracle/shiftnet_oracle.py has the same names) ----------------------------------------------
+    fold_se = True             # fused phase 1: CALayer2's MLP is finished by the frame's last workgroup (sn_se_fold) instead of an sn_ca_mlp launch
     fused_phase1 = True        # Shift-Net-s deblur: sn_gsts_cab2_phase1 / sn_cab1_phase1 instead of sn_ln_gemm_gate + sn_dw5m_gemm_gate (tests switch it off for A/B)
     fused_cab_tail = True      # Engine32 (one kernel per reference module) runs conv, conv, pool, MLP, scale + residual instead
 
@@ -422,6 +424,7 @@ class Engine:
             self._call("sn_ca_mlp", f"sn_ca_mlp[{name}]", pool.data_ptr() + f0 * nblk * c * 4, nblk, c, q["c"], q["cr"], 1.0 / (h * w),
                        q["wa"].data_ptr(), q["wb"].data_ptr(), ca.data_ptr() + f0 * c * 4, n, self._stream())
 
+        folded = False
         for wrap, halo, t0, nt in (self._split_pieces(x, mode, V.wrap) if mode else [(0, None, 0, 0)]):
             st = self._stream()
             src = self._unit_src(x, mode, wrap=wrap, halo=halo, t0=t0, nt=nt)
@@ -431,10 +434,18 @@ class Engine:
             hw_ptr = hwb.data_ptr() if mode else None
             if fused:
                 wt = C.byref(u["p1"]["desc"])
+                sep = None
+                if self.fold_se and T <= self.MAX_TICKETS:
+                    if self._tickets is None:
+                        self._tickets = torch.zeros((self.MAX_TICKETS,), dtype=torch.int32, device=self.dev)
+                    q = P.cas[pre + "ca2"]
+                    se = L.SeFold(q["wa"].data_ptr(), q["wb"].data_ptr(), q["c"], q["cr"], self._tickets.data_ptr(), ca2.data_ptr())
+                    sep = C.byref(se)
                 if mode:
-                    self._call("sn_gsts_cab2_phase1", "sn_gsts_cab2_phase1", C.byref(src), hw_ptr, wt, g2.data_ptr(), pool2.data_ptr(), st)
+                    self._call("sn_gsts_cab2_phase1", "sn_gsts_cab2_phase1", C.byref(src), hw_ptr, wt, g2.data_ptr(), pool2.data_ptr(), sep, st)
                 else:
-                    self._call("sn_cab1_phase1", "sn_cab1_phase1", C.byref(src), wt, g2.data_ptr(), pool2.data_ptr(), st)
+                    self._call("sn_cab1_phase1", "sn_cab1_phase1", C.byref(src), wt, g2.data_ptr(), pool2.data_ptr(), sep, st)
+                folded = sep is not None
             else:
                 self._call("sn_ln_gemm_gate", "sn_ln_gemm_gate", C.byref(src), hw_ptr, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(),
                            u["w_dw3_h2"].data_ptr(), g1.data_ptr(), pool1.data_ptr() if pool1 is not None else None, 2 if mstencil else 0, st)
@@ -447,7 +458,8 @@ class Engine:
                 k3 = "sn_dw5m_gemm_gate" if mstencil else "sn_grp5_gemm_gate"
                 self._call(k3, k3, g1.data_ptr() + fr1, ca1_ptr, u["w_toep5" if mstencil else "w_grp"].data_ptr(), u["w_gate"].data_ptr(),
                            g2.data_ptr() + fr2, pool2.data_ptr() + f0 * nb2 * c * 4, n, h, w, c, st)
-            ca_mlp(pre + "ca2", pool2, ca2, f0, n)
+            if not (fused and folded):
+                ca_mlp(pre + "ca2", pool2, ca2, f0, n)
             k4 = "sn_gsts_cab2_phase2" if mode else "sn_cab1_phase2"
             self._call(k4, k4, C.byref(src), g2.data_ptr(), ca2.data_ptr(), u["w_out"].data_ptr(), b_out, y.data_ptr(), st)
         return Act(y, c)
@@ -593,6 +605,7 @@ class Engine:
         g.replay()
         return so.clone()                       # the graph owns `so`: hand out a copy, like the fresh tensor upstream returns
 
+    MAX_TICKETS = 4096       # frames per tensor the squeeze-excite fold has counters for (longer windows fall back to sn_ca_mlp)
     GRAPH_SLOTS = 2          # captured graphs kept per engine: each pins its whole activation pool (GBs at 720p), so a client that varies
     #                          the window shape must not accumulate them
 

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libshiftnet_hip.so")
 
 SN_F32, SN_F16, SN_BF16 = 0, 1, 2
 
-ABI_VERSION = 5      # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so from before a struct / signature change fails the check in load()
+ABI_VERSION = 6      # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so from before a struct / signature change fails the check in load()
 
 SYMBOLS = [          # include/shiftnet_hip.h, production ABI
     "sn_abi_version", "sn_selftest_mfma", "sn_ingest", "sn_conv2d", "sn_conv_pool_blocks", "sn_ca_mlp",
@@ -32,11 +32,17 @@ class Phase1Weights(C.Structure):
     _fields_ = [("wfrag1", C.c_void_p), ("wfragx", C.c_void_p), ("w3", C.c_void_p), ("w5", C.c_void_p), ("wfrag2", C.c_void_p)]
 
 
-def cab_phase1(lib, src: "UnitSrc", hw_ptr, wt: "Phase1Weights", g2_ptr, pool_ptr, stream) -> int:
+class SeFold(C.Structure):
+    """sn_se_fold: CALayer2's MLP finished by the last workgroup of each frame of the phase-1 launch."""
+    _fields_ = [("wa", C.c_void_p), ("wb", C.c_void_p), ("c", C.c_int), ("cr", C.c_int), ("ticket", C.c_void_p), ("ca", C.c_void_p)]
+
+
+def cab_phase1(lib, src: "UnitSrc", hw_ptr, wt: "Phase1Weights", g2_ptr, pool_ptr, stream, se: "SeFold" = None) -> int:
     """sn_gsts_cab2_phase1 (src.mode 1 / 2) or sn_cab1_phase1 (mode 0)."""
+    sep = C.byref(se) if se is not None else None
     if src.mode:
-        return lib.sn_gsts_cab2_phase1(C.byref(src), hw_ptr, C.byref(wt), g2_ptr, pool_ptr, stream)
-    return lib.sn_cab1_phase1(C.byref(src), C.byref(wt), g2_ptr, pool_ptr, stream)
+        return lib.sn_gsts_cab2_phase1(C.byref(src), hw_ptr, C.byref(wt), g2_ptr, pool_ptr, sep, stream)
+    return lib.sn_cab1_phase1(C.byref(src), C.byref(wt), g2_ptr, pool_ptr, sep, stream)
 
 
 class ConvDesc(C.Structure):
@@ -112,8 +118,8 @@ def load() -> C.CDLL:
     lib.sn_grp5_gemm_gate.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.sn_grp5_blocks.argtypes = [ci, ci]
     lib.sn_phase1_pool_blocks.argtypes = [ci, ci, ci]
-    lib.sn_gsts_cab2_phase1.argtypes = [C.POINTER(UnitSrc), vp, C.POINTER(Phase1Weights), vp, vp, vp]
-    lib.sn_cab1_phase1.argtypes = [C.POINTER(UnitSrc), C.POINTER(Phase1Weights), vp, vp, vp]
+    lib.sn_gsts_cab2_phase1.argtypes = [C.POINTER(UnitSrc), vp, C.POINTER(Phase1Weights), vp, vp, C.POINTER(SeFold), vp]
+    lib.sn_cab1_phase1.argtypes = [C.POINTER(UnitSrc), C.POINTER(Phase1Weights), vp, vp, C.POINTER(SeFold), vp]
     lib.sn_gsts_cab2_phase2.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp, vp]
     lib.sn_cab1_phase2.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp, vp]
     lib.sn_ingest_u8.argtypes = [vp, vp, ci, ci, ci, ci, vp]

@@ -521,6 +521,44 @@ def test_denoise_unit_is_reproducible_under_allocator_churn():
                     assert torch.equal(ref, y), (T, h, w, mode)
 
 
+def test_squeeze_excite_fold_matches_ca_mlp_and_is_reproducible(engines):
+    """sn_se_fold: the last workgroup of each frame of the fused phase-1 launch finishes CALayer2 (fixed-order reduction of the partial sums
+    + the MLP).  Against sn_ca_mlp on the very same partial sums (another summation order: 1e-6), bit-identical over repeated launches
+    whichever workgroup arrives last, counters left at zero -- at a production size (184 workgroups per frame) and a small one."""
+    from shiftnet_amd import lib as L
+    eng, sd = engines("gshift_deblur2")
+    lib, P = eng.lib, eng.P
+    st = torch.cuda.current_stream().cuda_stream
+    C_ = 64
+    for (T, h, w), reps in (((6, 360, 640), 12), ((3, 20, 44), 4)):
+        x = torch.from_numpy(synth.unit_noise((T, h, w, C_), seed=7)).to(torch.bfloat16).to(DEV)
+        hwb = torch.from_numpy(synth.unit_noise((T, h, w, C_ // 2), seed=8)).to(torch.bfloat16).to(DEV)
+        for mode, unit in ((0, "encoder_level1.1."), (1, "encoder_level1.0.")):
+            pre = "stage1.decoder_level1." + unit
+            p1, q = P.units[pre]["p1"], P.cas[pre + "ca2"]
+            src = L.UnitSrc(x.data_ptr(), T, h, w, C_, mode, 1 if mode else 0)
+            nblk = lib.sn_phase1_pool_blocks(T, h, w)
+            g2 = torch.empty((T, h, w, C_), dtype=torch.bfloat16, device=DEV)
+            tickets = torch.zeros((T,), dtype=torch.int32, device=DEV)
+            ref = first = None
+            for r in range(reps):
+                pool = torch.full((T, nblk, C_), float("nan"), dtype=torch.float32, device=DEV)
+                ca = torch.full((T, C_), float("nan"), dtype=torch.float32, device=DEV)
+                se = L.SeFold(q["wa"].data_ptr(), q["wb"].data_ptr(), q["c"], q["cr"], tickets.data_ptr(), ca.data_ptr())
+                L.check(L.cab_phase1(lib, src, hwb.data_ptr() if mode else None, p1["desc"], g2.data_ptr(), pool.data_ptr(), st, se), "phase 1 + fold")
+                torch.cuda.synchronize()
+                assert int(tickets.abs().sum()) == 0, "counters not re-armed"
+                if ref is None:
+                    ref = torch.empty_like(ca)
+                    L.check(lib.sn_ca_mlp(pool.data_ptr(), nblk, C_, q["c"], q["cr"], 1.0 / (h * w), q["wa"].data_ptr(), q["wb"].data_ptr(),
+                                          ref.data_ptr(), T, st), "sn_ca_mlp")
+                    torch.cuda.synchronize()
+                    first = ca.clone()
+                    assert torch.isfinite(ca).all() and (ca - ref).abs().max().item() <= 2e-6, (T, h, w, mode, (ca - ref).abs().max().item())
+                else:
+                    assert torch.equal(ca, first), (T, h, w, mode, r)
+
+
 def test_hipgraph_replay_is_bit_identical_to_eager():
     """SN_GRAPH=1 path: second call captures the whole forward into a hipGraph, later calls replay it; results must be bit
     identical to the eager run and must follow the INPUT (the graph reads a static buffer the new input is copied into)."""
