@@ -46,6 +46,9 @@ __global__ void gather_kernel(const UnitK U, const int8_t* offs, bf16_t* u, cons
 // Not VALU-bound either, although 38 % of its wave cycles issue VALU: a round-3 build with the staging loop's index arithmetic made
 // incremental (~750 instead of ~1170 VALU per wave, bit-identical) measured 10.68 vs 10.30 ms per window on the same box.  What the
 // kernel waits for is its own load -> LDS -> barrier -> compute chain at two workgroups per CU.
+// A persistent, software-pipelined build (64 workgroups per XCD walking tile lists, the next tile's window in flight in 76 registers
+// while the current one is computed; bit-identical) was slower as well: 11.88 vs 10.33 ms per window of config 2, 74.5 vs 49.4 ms of
+// config 3 (C = 80: one workgroup per CU) -- the fourth register-prefetch pipeline on this path that lost to plain occupancy.
 template <int CH, int PP>
 __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const XcdTiles G, const int8_t* __restrict__ offs,
                                                       const uint32_t* __restrict__ w1d, bf16_t* hw) {
