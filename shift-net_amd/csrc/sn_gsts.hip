@@ -48,12 +48,21 @@ __global__ void gather_kernel(const UnitK U, const int8_t* offs, bf16_t* u, cons
 // kernel waits for is its own load -> LDS -> barrier -> compute chain at two workgroups per CU.
 // A persistent, software-pipelined build (64 workgroups per XCD walking tile lists, the next tile's window in flight in 76 registers
 // while the current one is computed; bit-identical) was slower as well: 11.88 vs 10.33 ms per window of config 2, 74.5 vs 49.4 ms of
+// config 3 (C = 80: one workgroup per CU) -- the fourth register-prefetch pipeline on this path that lost to plain occupancy.  So was a
+// ROW-WALKING build (strip of 32 columns, ring of 20 input rows in LDS: 1.56 instead of 4.5 window bytes per output byte): 11.3 vs
+// 10.05 ms -- the kernel is not bound by the bytes it loads either.
+// A persistent, software-pipelined build (64 workgroups per XCD walking tile lists, the next tile's window in flight in 76 registers
+// while the current one is computed; bit-identical) was slower as well: 11.88 vs 10.33 ms per window of config 2, 74.5 vs 49.4 ms of
 // config 3 (C = 80: one workgroup per CU) -- the fourth register-prefetch pipeline on this path that lost to plain occupancy.
 template <int CH, int PP>
 __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const XcdTiles G, const int8_t* __restrict__ offs,
                                                       const uint32_t* __restrict__ w1d, bf16_t* hw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RW = 34, PSB = PP * 16 + 4;      // odd number of dwords per pixel: lanes = pixels hit distinct banks
+    // ... and a row pitch of 16 (mod 32) dwords: a ds_read_u16 serves 32 lanes = 16 pixels of TWO tile rows, whose bank sets {17 px} and
+    // {17 px + pitch} must not meet.  With the natural pitch (34 x 17 = 2 mod 32 dwords) half of the kernel's LDS cycles were bank
+    // conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50, tools/lds_probe_k0.sh).
+    constexpr int ROWP = RW * PSB + (((16 - (RW * PSB / 4) % 32) + 32) % 32) * 4;
     constexpr int PCS = CH / 8;
     int t, ty_, tx_;
     if (!sn_xcd_tile(G, t, ty_, tx_)) return;      // XCD-aware walk: the 34-wide windows of x-neighbours overlap by 18 columns
@@ -82,7 +91,7 @@ __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const Xcd
                 const int ry = pix / RW, rx = pix - ry * RW;
                 const int gy = y0 - 9 + ry, gx = x0 - 9 + rx;
                 const bool in = idx < RW * RW * np && gy >= 0 && gy < U.h && gx >= 0 && gx < U.w;
-                lo[k] = idx < RW * RW * np ? (in ? pix * PSB + pc * 16 : -(pix * PSB + pc * 16) - 1) : 0x7fffffff;
+                lo[k] = idx < RW * RW * np ? (in ? ry * ROWP + rx * PSB + pc * 16 : -(ry * ROWP + rx * PSB + pc * 16) - 1) : 0x7fffffff;
                 v[k] = *(const uint4*)(src + (in ? ((size_t)gy * U.w + gx) * sstr + (pc0 + pc) * 8 : 0));
             }
             if (pc0) __syncthreads();                             // every wave is done reading the previous pass
@@ -102,13 +111,13 @@ __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const Xcd
                 for (int j = 0; j < 8; ++j) {
                     const int k = kc * 8 + j;
                     const int dy = offs[2 * k], dx = offs[2 * k + 1];
-                    const char* base = smem + ((py + 8 + dy) * RW + (px + 8 + dx)) * PSB + (k - pc0 * 8) * 2;
+                    const char* base = smem + (py + 8 + dy) * ROWP + (px + 8 + dx) * PSB + (k - pc0 * 8) * 2;
                     float acc = 0.f;
 #pragma unroll
                     for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
                         for (int tx = 0; tx < 3; ++tx)
-                            acc = dot2bf((uint32_t)(*(const bf16_t*)(base + (ty * RW + tx) * PSB)), w1d[k * 9 + ty * 3 + tx], acc);
+                            acc = dot2bf((uint32_t)(*(const bf16_t*)(base + ty * ROWP + tx * PSB)), w1d[k * 9 + ty * 3 + tx], acc);
                     o[j] = acc;
                 }
                 *(uint4*)(hw + (((size_t)t * U.h + oy) * U.w + ox) * CH + kc * 8) = pack8(o);
@@ -128,13 +137,13 @@ __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const Xcd
                 for (int j = 0; j < 8; ++j) {
                     const int k = kc * 8 + j;
                     const int dy = offs[2 * k], dx = offs[2 * k + 1];
-                    const char* base = smem + ((py + 8 + dy) * RW + (px + 8 + dx)) * PSB + (k - pc0 * 8) * 2;
+                    const char* base = smem + (py + 8 + dy) * ROWP + (px + 8 + dx) * PSB + (k - pc0 * 8) * 2;
                     float acc = 0.f;
 #pragma unroll
                     for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
                         for (int tx = 0; tx < 3; ++tx) {
-                            const float v = m[ty * 3 + tx] * bf_to_f(*(const bf16_t*)(base + (ty * RW + tx) * PSB));
+                            const float v = m[ty * 3 + tx] * bf_to_f(*(const bf16_t*)(base + ty * ROWP + tx * PSB));
                             acc = dot2bf(__float_as_uint(v) >> 16, w1d[k * 9 + ty * 3 + tx], acc);   // same bf16 weights as the fast path
                         }
                     o[j] = acc;
@@ -258,12 +267,12 @@ int sn_gsts_shiftconv(const sn_unit_src* s, const int8_t* offs, const uint32_t* 
     const dim3 grid = sn_xcd_grid(G);
     if (s->C == 64) {
         constexpr int PP = 4;
-        const size_t lds = 34 * 34 * (PP * 16 + 4);
+        const size_t lds = 34 * (34 * (PP * 16 + 4) + 56);           // rows padded to 16 (mod 32) dwords
         if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)shiftconv_kernel<32, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH;
         hipLaunchKernelGGL((shiftconv_kernel<32, PP>), grid, dim3(256), lds, (hipStream_t)stream, to_k(s), G, offs, w1, (bf16_t*)hw);
     } else {
         constexpr int PP = 5;
-        const size_t lds = 34 * 34 * (PP * 16 + 4);
+        const size_t lds = 34 * (34 * (PP * 16 + 4) + 24);
         if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)shiftconv_kernel<40, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH;
         hipLaunchKernelGGL((shiftconv_kernel<40, PP>), grid, dim3(256), lds, (hipStream_t)stream, to_k(s), G, offs, w1, (bf16_t*)hw);
     }
