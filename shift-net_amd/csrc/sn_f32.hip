@@ -190,6 +190,9 @@ __global__ __launch_bounds__(256) void conv32m_kernel(const Conv32K P) {
         __syncthreads();
         const int m_lo = grouped ? cb : 0, m_hi = grouped ? cb + 1 : mt_n;                // M-tiles this block contributes to
         for (int sb = 0; sb < nsub; ++sb) {
+            // a 16-channel sub-block past the last input channel contributes only zeros: skip its 4 MFMA steps per tap (36 -> 36 channels:
+            // 3 of 4 sub-blocks; 80 input channels: 5 of 6).  Workgroup-uniform.
+            if (!grouped && cbase + 16 * sb >= P.cin_total) break;
             // this lane's A operands: output channel co0 + 16 m + p (A row = lane & 15), input channels 4 g4 + s of the 16-channel sub-block
             const float* wp[MTC];                                                         // address of (tap 0, s = 0), or null: zero operand
 #pragma unroll
