@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 6      /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
+#define SN_ABI_VERSION 7      /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
 
 /* element types of NCHW tensors exchanged with the PyTorch side */
 #define SN_F32 0
@@ -230,6 +230,9 @@ typedef struct sn32_conv_desc {
     void* out; int cs_out;
     int out_mode;        /* 0 NHWC fp32; 1 pixel_shuffle(2) NHWC fp32; 2 NCHW of nchw_dtype + shortcut sc (as sn_conv_desc) */
     int nchw_dtype; const void* sc;
+    const void* wsplit;  /* NULL: exact fp32 products (v_mfma_f32_16x16x4_f32).  Else the weights as bf16 hi / lo A fragments
+                          * (prep.pack_conv32_split): every product is wh xh + wh xl + wl xh on the bf16 matrix cores with fp32 accumulation
+                          * (~2^-16 relative per product), taken for single-input stride-1 dense k = 1 / 3 and grouped-by-8 k = 5 convs */
 } sn32_conv_desc;
 int sn32_conv2d(const sn32_conv_desc* d, void* stream);
 /* channel_shift (gshift_deblur1.py:504-528) materialised in fp32: offs != NULL: u [T][h][w][3C/2] = cat(roll(x), shift(borrowed));

@@ -5,9 +5,11 @@
 // accumulation is a sequential fp32 FMA chain.  Results match the CPU oracle to fp32 round-off, so a wrong tap, slab,
 // gate half or weight row shows up as an error >> 1e-4 instead of hiding inside bf16 noise.
 //
-// Dense and grouped convolutions run as implicit GEMMs on the fp32 matrix-core instruction v_mfma_f32_16x16x4_f32 (conv32m_kernel:
-// exact fp32 products and sums, 157 TFLOP/s peak = the fp32 vector rate without its load / address overhead); depthwise convolutions
-// and the elementwise operators are direct kernels.  The bf16 kernels in sn_conv.hip / sn_gsts*.hip / sn_phase1.hip are the
+// Dense and grouped convolutions run as implicit GEMMs on the matrix cores, in one of two arithmetics chosen per call (sn32_conv_desc.wsplit):
+//   exact : v_mfma_f32_16x16x4_f32 (conv32m_kernel): fp32 products and sums, 157 TFLOP/s peak;
+//   split : every fp32 operand as bf16 hi + lo, three v_mfma_f32_16x16x32_bf16 per k-step with fp32 accumulation (conv32s_kernel): ~2^-16 per
+//           product, 5.3x fewer matrix-core cycles -- the engine's default for the convs it covers; both are within 1e-4 of the CPU oracle.
+// Depthwise convolutions and the elementwise operators are direct kernels.  The bf16 kernels in sn_conv.hip / sn_gsts*.hip / sn_phase1.hip are the
 // throughput path.
 #include "sn_common.h"
 #include "../../include/shiftnet_hip.h"
@@ -23,6 +25,7 @@ struct Conv32K {
     const float* oscale; int oscale_stride;
     const float* res; int cs_res;
     void* out; int cs_out, out_mode, nchw_dtype; const void* sc;
+    const uint4* wsplit;
 };
 
 __device__ __forceinline__ float ld_bilinear32(const float* src, int hs, int ws, int cs, int c, int gy, int gx) {
@@ -125,6 +128,63 @@ __global__ __launch_bounds__(256) void conv32_kernel(const Conv32K P) {
 //   weights straight from global memory (L1 / L2 resident), one float per lane and MFMA, fetched one tap ahead;
 //   grouped convs: an M-tile = two groups of 8 outputs whose inputs are the SAME 16 channels: block-diagonal A (half of it zero).
 constexpr int C32_CB = 32, C32_PSL = C32_CB + 8;      // input channels staged per barrier; LDS floats per pixel (40: conflict-free ds_read_b128 lane groups)
+// Epilogue shared by the two matrix-core conv kernels: lane (g4, p) holds output channels co0 + 16 m + 4 g4 + r of pixel p of each N-tile
+// (same arithmetic as conv32_kernel: bias, PReLU, per-frame scale, residual; NHWC / pixel-shuffle / NCHW + shortcut outputs).
+template <int MTC, int NTW, int XB>
+__device__ __forceinline__ void conv32_epilogue(const Conv32K& P, const f32x4_t (&acc)[MTC][NTW], int t, int oy0, int ox0, int co0, int mt_n, int wv, int g4, int p) {
+    const bool vout = P.out_mode == 0 && (P.cout & 3) == 0 && (P.cs_out & 3) == 0 && ((size_t)P.out & 15) == 0 &&
+                      (!P.res || ((P.cs_res & 3) == 0 && ((size_t)P.res & 15) == 0));
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        const int nn = wv * NTW + n, row = nn / XB, xb = nn - row * XB;
+        const int oy = oy0 + row, ox = ox0 + xb * 16 + p;
+        if (oy >= P.hout || ox >= P.wout) continue;
+        const size_t pix = ((size_t)t * P.hout + oy) * P.wout + ox;
+#pragma unroll
+        for (int m = 0; m < MTC; ++m) {
+            if (m >= mt_n) continue;
+            const int c0 = co0 + 16 * m + 4 * g4;
+            if (c0 >= P.cout) continue;
+            if (vout) {                                                                    // four consecutive channels: 16-byte residual load and store
+                float a[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
+                if (P.bias) { const float4 bb = *(const float4*)(P.bias + c0); a[0] += bb.x; a[1] += bb.y; a[2] += bb.z; a[3] += bb.w; }
+                if (P.act == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[r] = a[r] >= 0.f ? a[r] : a[r] * P.prelu;
+                }
+                if (P.oscale) {
+                    const float* os = P.oscale + (size_t)t * P.oscale_stride + c0;
+                    a[0] *= os[0]; a[1] *= os[1]; a[2] *= os[2]; a[3] *= os[3];
+                }
+                if (P.res) { const float4 rr = *(const float4*)(P.res + pix * P.cs_res + c0); a[0] += rr.x; a[1] += rr.y; a[2] += rr.z; a[3] += rr.w; }
+                *(float4*)((float*)P.out + pix * P.cs_out + c0) = make_float4(a[0], a[1], a[2], a[3]);
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = c0 + r;
+                if (c >= P.cout) continue;
+                float a = acc[m][n][r];
+                if (P.bias) a += P.bias[c];
+                if (P.act == 1) a = a >= 0.f ? a : a * P.prelu;
+                if (P.oscale) a *= P.oscale[(size_t)t * P.oscale_stride + c];
+                if (P.res) a += P.res[pix * P.cs_res + c];
+                if (P.out_mode == 0) {
+                    ((float*)P.out)[pix * P.cs_out + c] = a;
+                } else if (P.out_mode == 1) {
+                    const int cc = c >> 2, i = (c >> 1) & 1, jj = c & 1;
+                    ((float*)P.out)[(((size_t)t * 2 * P.hout + 2 * oy + i) * (2 * P.wout) + 2 * ox + jj) * P.cs_out + cc] = a;
+                } else {
+                    const size_t oi = (((size_t)t * P.cout + c) * P.hout + oy) * P.wout + ox;
+                    if (P.nchw_dtype == SN_F32) ((float*)P.out)[oi] = a + ((const float*)P.sc)[oi];
+                    else if (P.nchw_dtype == SN_F16) ((__half*)P.out)[oi] = __float2half(a + __half2float(((const __half*)P.sc)[oi]));
+                    else ((bf16_t*)P.out)[oi] = f_to_bf(a + bf_to_f(((const bf16_t*)P.sc)[oi]));
+                }
+            }
+        }
+    }
+}
+
 template <int MTC, int TH, int TW>
 __global__ __launch_bounds__(256) void conv32m_kernel(const Conv32K P) {
     extern __shared__ __attribute__((aligned(16))) float smem32[];
@@ -289,6 +349,126 @@ __global__ __launch_bounds__(256) void conv32m_kernel(const Conv32K P) {
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Split-precision convolution: fp32 in, fp32 out, the products on the BF16 matrix-core instruction.  Every fp32 operand is written as
+// hi + lo with hi = bf16(v), lo = bf16(v - hi) (16 significant bits together) and the product as  w x ~ wh xh + wh xl + wl xh : three
+// v_mfma_f32_16x16x32_bf16 (K = 32, fp32 accumulation) replace EIGHT v_mfma_f32_16x16x4_f32 of twice their issue time each, i.e. 5.3x
+// fewer matrix-core cycles for an error of ~2^-16 per product (the dropped wl xl term) -- an order of magnitude finer than the TF32
+// convolutions PyTorch runs by default on the reference's GPUs.  Activations are split ONCE per staged element (when the tile goes to
+// LDS: hi image | lo image per pixel, the same 4 bytes per value as fp32), the weights on the host (prep.pack_conv32_split: A fragments).
+//   dense (k = 1 / 3, stride 1): a channel block of 32 input channels is ONE k-step; k-step index = tap * blocks + block.
+//   grouped (the "+" RepConv, 8 -> 8 per group, k = 5): block = M-tile = 16 channels (two groups, block-diagonal A); a k-step covers the
+//   taps 2s, 2s + 1 (13 k-steps for k = 5, 5 for k = 3; lane group g reads tap 2s + (g >> 1), channel half g & 1), as sn_grp5_gemm_gate
+//   does in bf16.
+template <int MTC, int KSZ, bool GROUPED>
+__global__ __launch_bounds__(256, MTC <= 3 ? 3 : 2) void conv32s_kernel(const Conv32K P) {
+    extern __shared__ __attribute__((aligned(16))) float smem32[];
+    char* const lds = (char*)smem32;
+    constexpr int TH = 8, TW = 32, NTW = (TH * TW) / 64, XB = TW / 16;
+    constexpr int RH = TH + KSZ - 1, RW = TW + KSZ - 1, NPATCH = RH * RW, NTAP = KSZ * KSZ;
+    constexpr int NCH = GROUPED ? 16 : 32;                          // channels of a staged block
+    constexpr int PS = GROUPED ? 80 : 160;                          // LDS bytes per pixel: hi | lo | pad (5 / 10 slots of 16 B)
+    constexpr int LO = NCH * 2;                                     // byte offset of the lo image inside a pixel
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), g4 = lane >> 4, p = lane & 15;
+    const int tiles_y = (P.hout + TH - 1) / TH;
+    const int t = blockIdx.y / tiles_y, ty = blockIdx.y - t * tiles_y, tx = blockIdx.x;
+    const int oy0 = ty * TH, ox0 = tx * TW, co0 = blockIdx.z * MTC * 16;
+    const int iy0 = oy0 - P.pad, ix0 = ox0 - P.pad;
+    const int mt_all = (P.cout + 15) / 16;
+    const int mt_n = min(MTC, mt_all - blockIdx.z * MTC);
+    const int ncb = GROUPED ? mt_n : (P.cin_total + 31) / 32;
+    constexpr int KSG = (NTAP + 1) / 2;                             // grouped: two taps per k-step
+    const int ks_all = GROUPED ? KSG : NTAP * ncb;                  // k-steps per M-tile in the weight array
+
+    f32x4_t acc[MTC][NTW];
+#pragma unroll
+    for (int m = 0; m < MTC; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    int pixbase[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        const int nn = wv * NTW + n, row = nn / XB, xb = nn - row * XB;
+        pixbase[n] = (row * RW + xb * 16 + p) * PS;
+    }
+    const uint4* const wh = P.wsplit;                               // [2 parts][mt_all][ks_all][64 lanes]
+    const uint4* const wl = P.wsplit + (size_t)mt_all * ks_all * 64;
+    for (int cb = 0; cb < ncb; ++cb) {
+        const int cbase = GROUPED ? co0 + 16 * cb : cb * 32;
+        __syncthreads();                                            // everybody is done reading the previous block
+        constexpr int Q = NCH / 4;                                  // float4 quads per pixel
+        for (int e = tid; e < NPATCH * Q; e += 256) {
+            const int pix = e / Q, q = e - pix * Q, ci = cbase + 4 * q;
+            const int ry = pix / RW, rx = pix - ry * RW, gy = iy0 + ry, gx = ix0 + rx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ci < P.cin_total && gy >= 0 && gy < P.hin && gx >= 0 && gx < P.win)
+                v = *(const float4*)(P.in0 + (((size_t)t * P.hin + gy) * P.win + gx) * P.cs0 + ci);
+            const uint32_t h01 = pack_bf2(v.x, v.y), h23 = pack_bf2(v.z, v.w);
+            const uint32_t l01 = pack_bf2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
+            const uint32_t l23 = pack_bf2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
+            *(uint2*)(lds + pix * PS + 8 * q) = make_uint2(h01, h23);
+            *(uint2*)(lds + pix * PS + LO + 8 * q) = make_uint2(l01, l23);
+        }
+        __syncthreads();
+        if constexpr (GROUPED) {
+            const int m = cb;                                        // this block feeds M-tile cb only
+            const size_t wbase = ((size_t)(blockIdx.z * MTC + m) * KSG) * 64 + lane;
+#pragma unroll 1
+            for (int s2 = 0; s2 < KSG; ++s2) {
+                const int tap = min(2 * s2 + (g4 >> 1), NTAP - 1);   // (tap NTAP does not exist: its weights are zero)
+                const int dy = tap / KSZ, dx = tap - dy * KSZ;
+                const int toff = (dy * RW + dx) * PS + (g4 & 1) * 16;
+                const bf16x8_t ah = as_frag(wh[wbase + (size_t)s2 * 64]), al = as_frag(wl[wbase + (size_t)s2 * 64]);
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) {
+                    const bf16x8_t bh = as_frag(*(const uint4*)(lds + pixbase[n] + toff)), bl = as_frag(*(const uint4*)(lds + pixbase[n] + toff + LO));
+#pragma unroll
+                    for (int mm = 0; mm < MTC; ++mm) {
+                        if (mm != m) continue;                       // workgroup-uniform
+                        acc[mm][n] = mfma16(al, bh, acc[mm][n]);
+                        acc[mm][n] = mfma16(ah, bl, acc[mm][n]);
+                        acc[mm][n] = mfma16(ah, bh, acc[mm][n]);
+                    }
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int tap = 0; tap < NTAP; ++tap) {
+                const int dy = tap / KSZ, dx = tap - dy * KSZ;
+                const int toff = (dy * RW + dx) * PS + g4 * 16;
+                // M-tile outermost: one pair of A fragments live at a time (all MTC pairs at once cost 40 registers and spilled at two waves
+                // per SIMD); the B fragments are re-read from LDS per M-tile, 8 ds_read_b128 against 12 MFMAs
+#pragma unroll
+                for (int m = 0; m < MTC; ++m) {
+                    if (m >= mt_n) continue;                         // workgroup-uniform
+                    const size_t wi = ((size_t)(blockIdx.z * MTC + m) * ks_all + (size_t)tap * ncb + cb) * 64 + lane;
+                    const bf16x8_t ah = as_frag(wh[wi]), al = as_frag(wl[wi]);
+#pragma unroll
+                    for (int n = 0; n < NTW; ++n) {
+                        const bf16x8_t bh = as_frag(*(const uint4*)(lds + pixbase[n] + toff)), bl = as_frag(*(const uint4*)(lds + pixbase[n] + toff + LO));
+                        acc[m][n] = mfma16(al, bh, acc[m][n]);
+                        acc[m][n] = mfma16(ah, bl, acc[m][n]);
+                        acc[m][n] = mfma16(ah, bh, acc[m][n]);
+                    }
+                }
+            }
+        }
+    }
+    conv32_epilogue<MTC, NTW, XB>(P, acc, t, oy0, ox0, co0, mt_n, wv, g4, p);
+}
+
+template <int MTC, int KSZ, bool GROUPED>
+int launch_conv32s(const Conv32K& K, hipStream_t st) {
+    constexpr int TH = 8, TW = 32;
+    const size_t lds = (size_t)(TH + KSZ - 1) * (TW + KSZ - 1) * (GROUPED ? 80 : 160);
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv32s_kernel<MTC, KSZ, GROUPED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return SN_ELAUNCH;
+    const int mt = (K.cout + 15) / 16;
+    dim3 grid((K.wout + TW - 1) / TW, ((K.hout + TH - 1) / TH) * K.T, (mt + MTC - 1) / MTC);
+    hipLaunchKernelGGL((conv32s_kernel<MTC, KSZ, GROUPED>), grid, dim3(256), lds, st, K);
+    return sn_check_launch();
 }
 
 template <int MTC, int TH, int TW>
@@ -460,9 +640,22 @@ int sn32_conv2d(const sn32_conv_desc* d, void* stream) {
     K.res = d->res; K.cs_res = d->cs_res; K.out = d->out; K.cs_out = d->cs_out; K.out_mode = d->out_mode; K.nchw_dtype = d->nchw_dtype; K.sc = d->sc;
     const size_t n = (size_t)d->T * d->h_out * d->w_out * d->c_out;
     const int cin_g = K.cin_total / d->groups, cout_g = d->c_out / d->groups;
+    K.wsplit = (const uint4*)d->wsplit;
     if (d->groups == 1 || (cin_g == 8 && cout_g == 8 && d->c_out % 16 == 0)) {          // matrix cores: dense convs and the "+" RepConv
         hipStream_t st = (hipStream_t)stream;
         const int mt = (d->c_out + 15) / 16;
+        // split-precision path (bf16 hi + lo operands, three bf16 MFMAs per k-step): single float4-addressable input, stride 1, NHWC out
+        if (d->wsplit && d->n_in == 1 && d->in_mode == 0 && d->stride == 1 && (d->cs_in[0] & 3) == 0 && (K.cin_total & 3) == 0 &&
+            ((size_t)d->in[0] & 15) == 0 && ((size_t)d->wsplit & 15) == 0) {
+            if (d->groups == 1 && d->k == 1 && d->pad == 0)
+                return mt == 1 ? launch_conv32s<1, 1, false>(K, st) : (mt <= 3 ? launch_conv32s<3, 1, false>(K, st) : launch_conv32s<4, 1, false>(K, st));
+            if (d->groups == 1 && d->k == 3 && d->pad == 1)
+                return mt == 1 ? launch_conv32s<1, 3, false>(K, st) : (mt <= 3 ? launch_conv32s<3, 3, false>(K, st) : launch_conv32s<4, 3, false>(K, st));
+            if (d->groups > 1 && d->k == 5 && d->pad == 2)
+                return mt <= 3 ? launch_conv32s<3, 5, true>(K, st) : launch_conv32s<4, 5, true>(K, st);
+            if (d->groups > 1 && d->k == 3 && d->pad == 1)
+                return mt <= 3 ? launch_conv32s<3, 3, true>(K, st) : launch_conv32s<4, 3, true>(K, st);
+        }
         if (d->stride == 2) return mt <= 2 ? launch_conv32m<2, 4, 16>(K, st) : launch_conv32m<5, 4, 16>(K, st);
         return mt == 1 ? launch_conv32m<1, 8, 32>(K, st) : (mt <= 3 ? launch_conv32m<3, 8, 32>(K, st) : launch_conv32m<5, 8, 32>(K, st));
     }

@@ -36,6 +36,7 @@ class Plan32(Plan):
         self.cas: Dict[str, Dict[str, object]] = {}
         self.units: Dict[str, Dict[str, object]] = {}
         self._wt: Dict[str, torch.Tensor] = {}
+        self._ws: Dict[str, torch.Tensor] = {}
         self.offs = prep.shift_offsets_i8(shift_table(V.c1)).to(device)
         self._build()
 
@@ -64,12 +65,22 @@ class Plan32(Plan):
         return self._wt[key]
 
 
+    def wsplit(self, key: str, groups: int) -> torch.Tensor:
+        """bf16 hi / lo A fragments of a conv weight for the split-precision path (prep.pack_conv32_split), built on first use."""
+        if key not in self._ws:
+            self._ws[key] = prep.pack_conv32_split(self.sd[key], groups).to(self.device)
+        return self._ws[key]
+
+
 class Engine32(Engine):
     def __init__(self, plan: Plan32) -> None:
         super().__init__(plan, torch.float32)
 
     act_dtype = torch.float32
     fused_cab_tail = False
+    # Dense k = 1 / 3 and grouped-by-8 k = 5 convs with their operands split into bf16 hi + lo parts (three bf16 MFMAs per k-step instead of
+    # eight fp32 ones; ~2^-16 per product, fp32 accumulation).  False: exact fp32 products everywhere -- the validation build of the tests.
+    split_bf16 = True
 
     # ---- leaf operators ------------------------------------------------------------------------------------
     def _conv32(self, wkey: str, bkey: Optional[str], ins: Sequence[torch.Tensor], cins: Sequence[int], *, k: int, stride: int = 1,
@@ -94,6 +105,11 @@ class Engine32(Engine):
         d.n_in, d.T, d.h_in, d.w_in, d.in_mode = len(ins), T, h_in, w_in, in_mode
         d.k, d.stride, d.pad, d.groups, d.h_out, d.w_out, d.c_out = k, stride, pad, groups, h_out, w_out, co
         d.w = w.data_ptr()
+        cin = sum(cins)
+        if (self.split_bf16 and len(ins) == 1 and in_mode == 0 and out_mode == 0 and stride == 1 and cin % 4 == 0 and ins[0].stride(2) % 4 == 0
+                and ((groups == 1 and k in (1, 3) and pad == k // 2) or (groups > 1 and k in (3, 5) and pad == k // 2 and cin // groups == 8 and co // groups == 8 and co % 16 == 0))
+                and c_out is None):
+            d.wsplit = P.wsplit(wkey, groups).data_ptr()
         d.bias = P.dsd[bkey].data_ptr() if bkey is not None and bkey in P.dsd else None
         d.act, d.prelu = (1, prelu) if prelu is not None else (0, 0.0)
         if oscale is not None:

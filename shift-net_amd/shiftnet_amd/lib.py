@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libshiftnet_hip.so")
 
 SN_F32, SN_F16, SN_BF16 = 0, 1, 2
 
-ABI_VERSION = 6      # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so from before a struct / signature change fails the check in load()
+ABI_VERSION = 7      # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so from before a struct / signature change fails the check in load()
 
 SYMBOLS = [          # include/shiftnet_hip.h, production ABI
     "sn_abi_version", "sn_selftest_mfma", "sn_ingest", "sn_conv2d", "sn_conv_pool_blocks", "sn_ca_mlp",
@@ -66,6 +66,7 @@ class Conv32Desc(C.Structure):
         ("w", C.c_void_p), ("bias", C.c_void_p), ("act", C.c_int), ("prelu", C.c_float),
         ("oscale", C.c_void_p), ("oscale_stride", C.c_int), ("res", C.c_void_p), ("cs_res", C.c_int),
         ("out", C.c_void_p), ("cs_out", C.c_int), ("out_mode", C.c_int), ("nchw_dtype", C.c_int), ("sc", C.c_void_p),
+        ("wsplit", C.c_void_p),
     ]
 
 

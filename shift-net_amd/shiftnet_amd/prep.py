@@ -275,3 +275,42 @@ def pack_phase1(w1: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, w_dw3:
     wp[rows_gate(c), :c] = w2n
     return {"wfrag1": g["wfrag"], "wfragx": torch.from_numpy(wx.reshape(mt, 16, 8)).to(torch.bfloat16),
             "w3": torch.from_numpy(t3.view(np.int32).copy()), "w5": torch.from_numpy(t5.view(np.int32).copy()), "wfrag2": pack_frag_f16(wp)}
+
+
+def pack_conv32_split(w: torch.Tensor, groups: int = 1) -> torch.Tensor:
+    """fp32 conv weight [co][ci/groups][k][k] -> bf16 A fragments [2 (hi | lo)][MT][KS][64][8] of the split-precision fp32 conv
+    (csrc/sn_f32.hip: conv32s_kernel): hi = bf16(w), lo = bf16(w - hi); rows in natural order (M-tile m = output channels 16 m ..).
+      dense   (groups == 1): k-step s = tap * ceil(ci / 32) + block, slot kk = input channel 32 block + kk (zero beyond ci);
+      grouped (8 in / 8 out per group, k = 5 / 3): KS = 13 / 5, k-step s, slot 8 g + j = tap 2 s + (g >> 1), input channel 16 m + (g & 1) * 8 + j of the
+              M-tile's own two groups; a row only sees its own group (block-diagonal), tap 25 does not exist (zeros)."""
+    wn = w.detach().float().cpu().numpy()
+    co, cig, k, _ = wn.shape
+    ntap = k * k
+    mt = (co + 15) // 16
+    if groups == 1:
+        ncb = (cig + 31) // 32
+        ks = ntap * ncb
+        wp = np.zeros((16 * mt, 32 * ks), np.float32)
+        for tap in range(ntap):
+            ty, tx = divmod(tap, k)
+            for cb in range(ncb):
+                c0, c1 = 32 * cb, min(32 * cb + 32, cig)
+                s0 = (tap * ncb + cb) * 32
+                wp[:co, s0:s0 + (c1 - c0)] = wn[:, c0:c1, ty, tx]
+    else:
+        assert cig == 8 and co % 16 == 0 and co // groups == 8 and k in (3, 5)
+        ks = (ntap + 1) // 2
+        wp = np.zeros((16 * mt, 32 * ks), np.float32)
+        for m in range(mt):
+            for r in range(16):
+                o = 16 * m + r
+                for s_ in range(ks):
+                    for g in range(4):
+                        tap = 2 * s_ + (g >> 1)
+                        if tap >= ntap or (r >> 3) != (g & 1):
+                            continue
+                        ty, tx = divmod(tap, k)
+                        wp[o, 32 * s_ + 8 * g: 32 * s_ + 8 * g + 8] = wn[o, :, ty, tx]
+    hi = torch.from_numpy(wp).to(torch.bfloat16).float().numpy()
+    lo = wp - hi
+    return torch.stack([pack_frag(hi), pack_frag(lo)], 0).contiguous()

@@ -1,8 +1,10 @@
 """-m gpu: the fp32 engine (csrc/sn_f32.hip + shiftnet_amd/engine32.py) against the CPU oracle and the reference fixtures.
 
-fp32 storage, fp32 weights, fp32 FMA chains: the only differences from the oracle are summation order and the
-exp / rsqrt implementations, so the tolerance is max-abs <= 1e-4 * scale (SURVEY.md 8c "HIP fp32 vs oracle"), four
-orders of magnitude below what a wrong tap / slab / gate half / weight row would produce.  ``Engine32`` shares every line
+fp32 storage, fp32 weights, fp32 accumulation: the only differences from the oracle are summation order, the exp / rsqrt
+implementations and -- in the default "split" mode -- the ~2^-16 of a product whose fp32 operands are split into bf16 hi + lo parts for
+the bf16 matrix cores (csrc/sn_f32.hip: conv32s_kernel); the "exact" mode multiplies in fp32 (v_mfma_f32_16x16x4_f32).  EVERY test runs in
+BOTH modes at the same tolerance, max-abs <= 1e-4 * scale (SURVEY.md 8c "HIP fp32 vs oracle"), four orders of magnitude below what a
+wrong tap / slab / gate half / weight row would produce.  ``Engine32`` shares every line
 of control flow with the bf16 engine (it only overrides the leaf operators), so these tests pin the logic of both; they
 also are the float32 path upstream's denoise CLI uses for the "+" model (inference/test_denoise.py:83-85).
 """
@@ -38,8 +40,18 @@ def close(name, got, ref, tol=TOL):
     assert np.isfinite(err) and err <= tol * scale, f"{name}: max-abs {err:.3g} > {tol} * {scale:.3g}"
 
 
+@pytest.fixture(scope="module", params=["exact", "split"], autouse=True)
+def conv_mode(request):
+    """Engine32.split_bf16: False = exact fp32 products, True (the product default) = bf16 hi / lo operands on the bf16 MFMA."""
+    from shiftnet_amd.engine32 import Engine32
+    old = Engine32.split_bf16
+    Engine32.split_bf16 = request.param == "split"
+    yield request.param
+    Engine32.split_bf16 = old
+
+
 @pytest.fixture(scope="module")
-def engines():
+def engines(conv_mode):
     from shiftnet_amd.engine import make_engine
     cache = {}
 

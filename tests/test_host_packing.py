@@ -271,3 +271,38 @@ def test_packed_fp16_weight_words():
     ref = w.to(torch.float16).numpy()
     assert np.array_equal(lo, ref[:, 0::2]) and np.array_equal(hi, ref[:, 1::2])
     assert lo[0, 0] == np.float16(1.0) and hi[0, 0] == np.float16(-65504.0)
+
+
+def test_conv32_split_packing_reconstructs_the_weights():
+    """prep.pack_conv32_split (A fragments of the split-precision fp32 conv, csrc/sn_f32.hip: conv32s_kernel): decoding the fragments exactly as
+    the kernel addresses them -- M-tile, k-step, lane (row l & 15, k-slots 8 (l >> 4) ..), hi + lo -- gives the weights back to 2^-16, zeros in
+    every padding slot and, for the grouped conv, in the other group's half of the block-diagonal."""
+    g = torch.Generator().manual_seed(11)
+    w = torch.randn(36, 36, 3, 3, generator=g)
+    f = prep.pack_conv32_split(w).float().numpy()                      # [2][MT][KS][64][8]
+    full = f[0] + f[1]
+    co, ci, k = 36, 36, 3
+    ncb = (ci + 31) // 32
+    assert f.shape == (2, 3, 9 * ncb, 64, 8)
+    rec = np.zeros((48, 64, 3, 3), np.float32)
+    for m in range(3):
+        for tap in range(9):
+            for cb in range(ncb):
+                for lane in range(64):
+                    for j in range(8):
+                        rec[16 * m + (lane & 15), 32 * cb + 8 * (lane >> 4) + j, tap // 3, tap % 3] = full[m, tap * ncb + cb, lane, j]
+    wn = w.numpy()
+    assert np.abs(rec[:co, :ci] - wn).max() <= 2.0 ** -15 * np.abs(wn).max()
+    assert not rec[co:].any() and not rec[:, ci:].any()
+    wg = torch.randn(32, 8, 5, 5, generator=g)                           # 4 groups of 8 -> 2 M-tiles
+    fg = prep.pack_conv32_split(wg, 4).float().numpy()
+    fullg = fg[0] + fg[1]
+    assert fg.shape == (2, 2, 13, 64, 8)
+    for m in range(2):
+        for s_ in range(13):
+            for lane in range(64):
+                r, gq = lane & 15, lane >> 4
+                tap = 2 * s_ + (gq >> 1)
+                for j in range(8):
+                    want = wg[16 * m + r, j, tap // 5, tap % 5].item() if (tap < 25 and (r >> 3) == (gq & 1)) else 0.0
+                    assert abs(fullg[m, s_, lane, j] - want) <= 2.0 ** -15 * max(1.0, abs(want)), (m, s_, lane, j)
