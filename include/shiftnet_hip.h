@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 7      /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
+#define SN_ABI_VERSION 8      /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
 
 /* element types of NCHW tensors exchanged with the PyTorch side */
 #define SN_F32 0
@@ -232,7 +232,9 @@ typedef struct sn32_conv_desc {
     int nchw_dtype; const void* sc;
     const void* wsplit;  /* NULL: exact fp32 products (v_mfma_f32_16x16x4_f32).  Else the weights as bf16 hi / lo A fragments
                           * (prep.pack_conv32_split): every product is wh xh + wh xl + wl xh on the bf16 matrix cores with fp32 accumulation
-                          * (~2^-16 relative per product), taken for single-input stride-1 dense k = 1 / 3 and grouped-by-8 k = 5 convs */
+                          * (~2^-16 relative per product), taken for single-input stride-1 dense k = 1 / 3 and grouped-by-8 k = 3 / 5 convs */
+    const float* iscale; int iscale_stride;   /* NULL or [T][iscale_stride] f32: the input is multiplied by iscale[t][ci] while it is loaded (the
+                          * CALayer scale of the producer, gshift_deblur1.py:69-70, without a pass of its own); single-input dense / grouped-by-8 convs */
 } sn32_conv_desc;
 int sn32_conv2d(const sn32_conv_desc* d, void* stream);
 /* channel_shift (gshift_deblur1.py:504-528) materialised in fp32: offs != NULL: u [T][h][w][3C/2] = cat(roll(x), shift(borrowed));
@@ -242,6 +244,9 @@ int sn32_gsts_gather(const sn_unit_src* s, const int8_t* offs, float* u, void* s
 int sn32_layernorm(const float* x, int cs_x, int K, const float* w, const float* b, float* out, int cs_out, long long npix, void* stream);
 /* SimpleGate (mode 0, :175-178) / SimpleGate2 (mode 1, :179-182): a:[npix][2C] -> out:[npix][C]. */
 int sn32_gate(const float* a, int C, int mode, float* out, long long npix, void* stream);
+/* SimpleGate / SimpleGate2 plus the channel sums of the result in one pass (the CALayer2 after it): out:[T][hw][C], partial as
+ * sn32_chan_sum would compute from out. */
+int sn32_gate_sum(const float* a, int C, int cpad, int mode, float* out, int T, int hw, int nblk, float* partial, void* stream);
 /* AdaptiveAvgPool2d(1) first half: partial:[T][nblk][cpad] sums (cpad >= C, <= 256), finished by sn_ca_mlp. */
 int sn32_chan_sum(const float* x, int cs, int C, int cpad, int T, int hw, int nblk, float* partial, void* stream);
 /* out = r * ca[t][c] (+ x if x != NULL). */

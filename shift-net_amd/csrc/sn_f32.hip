@@ -26,6 +26,7 @@ struct Conv32K {
     const float* res; int cs_res;
     void* out; int cs_out, out_mode, nchw_dtype; const void* sc;
     const uint4* wsplit;
+    const float* iscale; int iscale_stride;      // NULL or [T][iscale_stride]: the input is multiplied by iscale[t][ci] while it is staged
 };
 
 __device__ __forceinline__ float ld_bilinear32(const float* src, int hs, int ws, int cs, int c, int gy, int gx) {
@@ -231,6 +232,10 @@ __global__ __launch_bounds__(256) void conv32m_kernel(const Conv32K P) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ci < P.cin_total && gy >= 0 && gy < P.hin && gx >= 0 && gx < P.win)
                     v = *(const float4*)(P.in0 + (((size_t)t * hs + gy) * ws + gx) * P.cs0 + ci);
+                if (P.iscale && ci < P.cin_total) {
+                    const float4 sc4 = *(const float4*)(P.iscale + (size_t)t * P.iscale_stride + ci);
+                    v.x *= sc4.x; v.y *= sc4.y; v.z *= sc4.z; v.w *= sc4.w;
+                }
                 *(float4*)(smem32 + pix * C32_PSL + c) = v;
             }
         } else {
@@ -399,15 +404,31 @@ __global__ __launch_bounds__(256, MTC <= 3 ? 3 : 2) void conv32s_kernel(const Co
         const int cbase = GROUPED ? co0 + 16 * cb : cb * 32;
         __syncthreads();                                            // everybody is done reading the previous block
         constexpr int Q = NCH / 4;                                  // float4 quads per pixel
-        for (int e = tid; e < NPATCH * Q; e += 256) {
-            const int pix = e / Q, q = e - pix * Q, ci = cbase + 4 * q;
+        constexpr int NIT = (NPATCH * Q + 255) / 256;
+        // all loads of the block first (one memory round trip, not one per iteration), then split and write
+        float4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + it * 256, ec = e < NPATCH * Q ? e : 0;
+            const int pix = ec / Q, q = ec - pix * Q, ci = cbase + 4 * q;
             const int ry = pix / RW, rx = pix - ry * RW, gy = iy0 + ry, gx = ix0 + rx;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ci < P.cin_total && gy >= 0 && gy < P.hin && gx >= 0 && gx < P.win)
-                v = *(const float4*)(P.in0 + (((size_t)t * P.hin + gy) * P.win + gx) * P.cs0 + ci);
-            const uint32_t h01 = pack_bf2(v.x, v.y), h23 = pack_bf2(v.z, v.w);
-            const uint32_t l01 = pack_bf2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
-            const uint32_t l23 = pack_bf2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
+            const bool in = e < NPATCH * Q && ci < P.cin_total && gy >= 0 && gy < P.hin && gx >= 0 && gx < P.win;
+            v[it] = *(const float4*)(P.in0 + (in ? (((size_t)t * P.hin + gy) * P.win + gx) * P.cs0 + ci : 0));
+            if (!in) v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + it * 256;
+            if (e >= NPATCH * Q) continue;
+            const int pix = e / Q, q = e - pix * Q, ci = cbase + 4 * q;
+            float4 x = v[it];
+            if (P.iscale && ci < P.cin_total) {                       // CALayer scale of the producer, applied here instead of in a pass of its own
+                const float4 sc4 = *(const float4*)(P.iscale + (size_t)t * P.iscale_stride + ci);
+                x.x *= sc4.x; x.y *= sc4.y; x.z *= sc4.z; x.w *= sc4.w;
+            }
+            const uint32_t h01 = pack_bf2(x.x, x.y), h23 = pack_bf2(x.z, x.w);
+            const uint32_t l01 = pack_bf2(x.x - __uint_as_float(h01 << 16), x.y - __uint_as_float(h01 & 0xffff0000u));
+            const uint32_t l23 = pack_bf2(x.z - __uint_as_float(h23 << 16), x.w - __uint_as_float(h23 & 0xffff0000u));
             *(uint2*)(lds + pix * PS + 8 * q) = make_uint2(h01, h23);
             *(uint2*)(lds + pix * PS + LO + 8 * q) = make_uint2(l01, l23);
         }
@@ -469,6 +490,103 @@ int launch_conv32s(const Conv32K& K, hipStream_t st) {
     dim3 grid((K.wout + TW - 1) / TW, ((K.hout + TH - 1) / TH) * K.T, (mt + MTC - 1) / MTC);
     hipLaunchKernelGGL((conv32s_kernel<MTC, KSZ, GROUPED>), grid, dim3(256), lds, st, K);
     return sn_check_launch();
+}
+
+// Split-precision 1x1 convolution = a plain GEMM over the flat pixel list: a workgroup takes 128 consecutive pixels, stages ALL their input
+// channels once (hi | lo images, 32-channel blocks side by side) and then walks the output M-tiles in groups of four from that one
+// staged tile -- conv32s_kernel stages the input again for every group of M-tiles (three times for 160 output channels).
+// NHWC fp32 output only, cout / pixel strides multiples of 4 (the caller checks).
+template <int NCB>
+__global__ __launch_bounds__(256, 2) void conv32s_1x1_kernel(const Conv32K P, const long long npix) {
+    constexpr int ncb = NCB;                                         // compile-time: the k-loop unrolls and a group's weight fragments load up front
+    extern __shared__ __attribute__((aligned(16))) float smem32[];
+    char* const lds = (char*)smem32;
+    constexpr int NPX = 128, NTW = 2, MTC = 4;
+    const int PSK = ncb * 160 + ((ncb & 1) ? 0 : 32);               // LDS bytes per pixel: ncb blocks of (hi 64 | lo 64 | pad 32); 2 (mod 4) 16-byte slots
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), g4 = lane >> 4, p = lane & 15;
+    const long long pix0 = (long long)blockIdx.x * NPX;
+    const int hw = P.hout * P.wout;
+    const int t0 = (int)(pix0 / hw), prem = (int)(pix0 - (long long)t0 * hw);     // frame of the first pixel (a workgroup spans at most two: hw >= 128)
+#pragma unroll
+    for (int cb = 0; cb < ncb; ++cb) {
+        float4 v[NPX * 8 / 256], sc[NPX * 8 / 256];
+#pragma unroll
+        for (int it = 0; it < NPX * 8 / 256; ++it) {                 // the block's loads (data and input scale) first, then split and write
+            const int e = tid + it * 256, pl = e >> 3, q = e & 7, ci = cb * 32 + 4 * q;
+            const long long pg = pix0 + pl;
+            const bool in = ci < P.cin_total && pg < npix;
+            v[it] = *(const float4*)(P.in0 + (in ? (size_t)pg * P.cs0 + ci : 0));
+            if (!in) v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            sc[it] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (P.iscale && in) sc[it] = *(const float4*)(P.iscale + (size_t)(t0 + (prem + pl >= hw ? 1 : 0)) * P.iscale_stride + ci);
+        }
+#pragma unroll
+        for (int it = 0; it < NPX * 8 / 256; ++it) {
+            const int e = tid + it * 256, pl = e >> 3, q = e & 7;
+            const float4 x = make_float4(v[it].x * sc[it].x, v[it].y * sc[it].y, v[it].z * sc[it].z, v[it].w * sc[it].w);
+            const uint32_t h01 = pack_bf2(x.x, x.y), h23 = pack_bf2(x.z, x.w);
+            const uint32_t l01 = pack_bf2(x.x - __uint_as_float(h01 << 16), x.y - __uint_as_float(h01 & 0xffff0000u));
+            const uint32_t l23 = pack_bf2(x.z - __uint_as_float(h23 << 16), x.w - __uint_as_float(h23 & 0xffff0000u));
+            *(uint2*)(lds + pl * PSK + cb * 160 + 8 * q) = make_uint2(h01, h23);
+            *(uint2*)(lds + pl * PSK + cb * 160 + 64 + 8 * q) = make_uint2(l01, l23);
+        }
+    }
+    __syncthreads();
+    const int mt_all = (P.cout + 15) / 16;
+    const uint4* const wh = P.wsplit;                               // [2 parts][mt_all][ncb][64 lanes]
+    const uint4* const wl = P.wsplit + (size_t)mt_all * ncb * 64;
+    for (int m0 = 0; m0 < mt_all; m0 += MTC) {
+        f32x4_t acc[MTC][NTW];
+#pragma unroll
+        for (int m = 0; m < MTC; ++m)
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cb = 0; cb < ncb; ++cb) {
+            bf16x8_t bh[NTW], bl[NTW];
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const char* bp = lds + ((wv * NTW + n) * 16 + p) * PSK + cb * 160 + g4 * 16;
+                bh[n] = as_frag(*(const uint4*)bp); bl[n] = as_frag(*(const uint4*)(bp + 64));
+            }
+#pragma unroll
+            for (int m = 0; m < MTC; ++m) {
+                if (m0 + m >= mt_all) continue;                      // workgroup-uniform
+                const size_t wi = ((size_t)(m0 + m) * ncb + cb) * 64 + lane;
+                const bf16x8_t ah = as_frag(wh[wi]), al = as_frag(wl[wi]);
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) {
+                    acc[m][n] = mfma16(al, bh[n], acc[m][n]);
+                    acc[m][n] = mfma16(ah, bl[n], acc[m][n]);
+                    acc[m][n] = mfma16(ah, bh[n], acc[m][n]);
+                }
+            }
+        }
+        // epilogue of this group of M-tiles: lane (g4, p) holds output channels 16 (m0 + m) + 4 g4 + r of pixel (wv * NTW + n) * 16 + p
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            const long long pg = pix0 + (wv * NTW + n) * 16 + p;
+            if (pg >= npix) continue;
+            const int t = t0 + (prem + (wv * NTW + n) * 16 + p >= hw ? 1 : 0);
+#pragma unroll
+            for (int m = 0; m < MTC; ++m) {
+                const int c0 = 16 * (m0 + m) + 4 * g4;
+                if (m0 + m >= mt_all || c0 >= P.cout) continue;
+                float a[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
+                if (P.bias) { const float4 bb = *(const float4*)(P.bias + c0); a[0] += bb.x; a[1] += bb.y; a[2] += bb.z; a[3] += bb.w; }
+                if (P.act == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[r] = a[r] >= 0.f ? a[r] : a[r] * P.prelu;
+                }
+                if (P.oscale) {
+                    const float* os = P.oscale + (size_t)t * P.oscale_stride + c0;
+                    a[0] *= os[0]; a[1] *= os[1]; a[2] *= os[2]; a[3] *= os[3];
+                }
+                if (P.res) { const float4 rr = *(const float4*)(P.res + (size_t)pg * P.cs_res + c0); a[0] += rr.x; a[1] += rr.y; a[2] += rr.z; a[3] += rr.w; }
+                *(float4*)((float*)P.out + (size_t)pg * P.cs_out + c0) = make_float4(a[0], a[1], a[2], a[3]);
+            }
+        }
+    }
 }
 
 template <int MTC, int TH, int TW>
@@ -592,6 +710,33 @@ __global__ __launch_bounds__(256) void chan_sum32_kernel(const float* x, int cs,
     }
 }
 
+// SimpleGate / SimpleGate2 AND the per-(frame, block) channel sums of its result in one pass (the CALayer2 that follows every gate of the
+// denoisers, and SimpleGate2 of all variants): same pixel walk and summation order as chan_sum32_kernel, so the sums are the ones
+// sn32_gate + sn32_chan_sum produce, without reading the gated tensor back.
+__global__ __launch_bounds__(256) void gate_sum32_kernel(const float* a, int C, int cpad, int mode, int hw, float* out, float* partial) {
+    __shared__ float acc[256];
+    const int t = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x, tid = threadIdx.x;
+    const int nsplit = 256 / cpad, ch = tid % cpad, part = tid / cpad;
+    float s = 0.f;
+    if (part < nsplit && ch < C) {
+        const float* at = a + (size_t)t * hw * 2 * C + ch;
+        float* ot = out + (size_t)t * hw * C + ch;
+        for (int i = blk * nsplit + part; i < hw; i += nblk * nsplit) {
+            const float x1 = at[(size_t)i * 2 * C], x2 = at[(size_t)i * 2 * C + C];
+            const float g = mode ? x1 / (1.0f + expf(-x2)) : x1 * x2;
+            ot[(size_t)i * C] = g;
+            s += g;
+        }
+    }
+    acc[tid] = s;
+    __syncthreads();
+    if (tid < cpad) {
+        float m = 0.f;
+        for (int q = 0; q < nsplit; ++q) m += acc[q * cpad + tid];
+        partial[((size_t)t * nblk + blk) * cpad + tid] = m;
+    }
+}
+
 // out = r * ca[t][c] (+ x): CALayer scale with or without the CAB residual (gshift_deblur1.py:69-70,155-157)
 __global__ void scale_res32_kernel(const float* r, const float* x, const float* ca, int ca_stride, float* out, int C, int hw, size_t n) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
@@ -641,12 +786,29 @@ int sn32_conv2d(const sn32_conv_desc* d, void* stream) {
     const size_t n = (size_t)d->T * d->h_out * d->w_out * d->c_out;
     const int cin_g = K.cin_total / d->groups, cout_g = d->c_out / d->groups;
     K.wsplit = (const uint4*)d->wsplit;
+    K.iscale = d->iscale; K.iscale_stride = d->iscale_stride;
+    // the input scale is implemented by the matrix-core kernels' 16-byte staging path only
+    if (d->iscale && !((d->groups == 1 || (cin_g == 8 && cout_g == 8 && d->c_out % 16 == 0)) && d->n_in == 1 && d->in_mode == 0 && (d->cs_in[0] & 3) == 0 &&
+                       (K.cin_total & 3) == 0 && ((size_t)d->in[0] & 15) == 0 && (d->iscale_stride & 3) == 0 && ((size_t)d->iscale & 15) == 0)) return SN_EINVAL;
     if (d->groups == 1 || (cin_g == 8 && cout_g == 8 && d->c_out % 16 == 0)) {          // matrix cores: dense convs and the "+" RepConv
         hipStream_t st = (hipStream_t)stream;
         const int mt = (d->c_out + 15) / 16;
         // split-precision path (bf16 hi + lo operands, three bf16 MFMAs per k-step): single float4-addressable input, stride 1, NHWC out
         if (d->wsplit && d->n_in == 1 && d->in_mode == 0 && d->stride == 1 && (d->cs_in[0] & 3) == 0 && (K.cin_total & 3) == 0 &&
             ((size_t)d->in[0] & 15) == 0 && ((size_t)d->wsplit & 15) == 0) {
+            const int ncb1 = (K.cin_total + 31) / 32;
+            if (d->groups == 1 && d->k == 1 && d->pad == 0 && d->out_mode == 0 && ncb1 <= 3 && d->h_out * d->w_out >= 128 && (d->c_out & 3) == 0 && (d->cs_out & 3) == 0 &&
+                ((size_t)d->out & 15) == 0 && (!d->res || ((d->cs_res & 3) == 0 && ((size_t)d->res & 15) == 0)) && mt > 1) {
+                const long long npix = (long long)d->T * d->h_out * d->w_out;
+                const size_t lds = (size_t)128 * (ncb1 * 160 + ((ncb1 & 1) ? 0 : 32));
+                const dim3 grid((unsigned)((npix + 127) / 128));
+#define SN_1X1_CASE(N) case N: \
+                    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv32s_1x1_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH; \
+                    hipLaunchKernelGGL(conv32s_1x1_kernel<N>, grid, dim3(256), lds, st, K, npix); break;
+                switch (ncb1) { SN_1X1_CASE(1) SN_1X1_CASE(2) SN_1X1_CASE(3) SN_1X1_CASE(4) }
+#undef SN_1X1_CASE
+                return sn_check_launch();
+            }
             if (d->groups == 1 && d->k == 1 && d->pad == 0)
                 return mt == 1 ? launch_conv32s<1, 1, false>(K, st) : (mt <= 3 ? launch_conv32s<3, 1, false>(K, st) : launch_conv32s<4, 1, false>(K, st));
             if (d->groups == 1 && d->k == 3 && d->pad == 1)
@@ -692,6 +854,13 @@ int sn32_gate(const float* a, int C, int mode, float* out, long long npix, void*
     sn_clear_error();
     if (!a || !out || C < 1 || npix < 1 || mode < 0 || mode > 1) return SN_EINVAL;
     hipLaunchKernelGGL(gate32_kernel, dim3(grid_for((size_t)npix * C)), dim3(256), 0, (hipStream_t)stream, a, C, mode, out, (size_t)npix);
+    return sn_check_launch();
+}
+
+int sn32_gate_sum(const float* a, int C, int cpad, int mode, float* out, int T, int hw, int nblk, float* partial, void* stream) {
+    sn_clear_error();
+    if (!a || !out || !partial || C < 1 || cpad < C || cpad > 256 || nblk < 1 || T < 1 || hw < 1 || mode < 0 || mode > 1) return SN_EINVAL;
+    hipLaunchKernelGGL(gate_sum32_kernel, dim3(nblk, T), dim3(256), 0, (hipStream_t)stream, a, C, cpad, mode, hw, out, partial);
     return sn_check_launch();
 }
 

@@ -85,7 +85,8 @@ class Engine32(Engine):
     # ---- leaf operators ------------------------------------------------------------------------------------
     def _conv32(self, wkey: str, bkey: Optional[str], ins: Sequence[torch.Tensor], cins: Sequence[int], *, k: int, stride: int = 1,
                 pad: Optional[int] = None, groups: int = 1, prelu: Optional[float] = None, res: Optional[torch.Tensor] = None,
-                oscale: Optional[torch.Tensor] = None, oscale_stride: int = 0, out: Optional[torch.Tensor] = None, out_mode: int = 0,
+                oscale: Optional[torch.Tensor] = None, oscale_stride: int = 0, iscale: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None, out_mode: int = 0,
                 in_mode: int = 0, c_out: Optional[int] = None, nchw_out: Optional[torch.Tensor] = None,
                 nchw_sc: Optional[torch.Tensor] = None, label: str = "") -> torch.Tensor:
         """ins: NHWC fp32 tensors (possibly channel-slice views of wider tensors: the pixel stride is taken from .stride(2))."""
@@ -114,6 +115,8 @@ class Engine32(Engine):
         d.act, d.prelu = (1, prelu) if prelu is not None else (0, 0.0)
         if oscale is not None:
             d.oscale, d.oscale_stride = oscale.data_ptr(), oscale_stride
+        if iscale is not None:                     # [T][stride] per-frame input scale (CALayer of the producer)
+            d.iscale, d.iscale_stride = iscale.data_ptr(), iscale.stride(0)
         if res is not None:
             d.res, d.cs_res = res.data_ptr(), res.stride(2)
         if out_mode == 2:
@@ -153,6 +156,15 @@ class Engine32(Engine):
         nblk = 64
         part = torch.empty((T, nblk, cpad), dtype=torch.float32, device=self.dev)
         self._call("sn32_chan_sum", "sn32_chan_sum", x.data_ptr(), x.stride(2), c, cpad, T, h * w, nblk, part.data_ptr(), self._stream())
+        return part
+
+    def _gate_sum(self, a: torch.Tensor, out: torch.Tensor, mode: int) -> torch.Tensor:
+        """out = SimpleGate(a) (mode 0) / SimpleGate2(a) (mode 1) and the partial channel sums of out for the CALayer2 behind it, in one pass."""
+        T, h, w, c = out.shape
+        cpad = max(16, prep.ceil8(c))
+        nblk = 64
+        part = torch.empty((T, nblk, cpad), dtype=torch.float32, device=self.dev)
+        self._call("sn32_gate_sum", "sn32_gate_sum", a.data_ptr(), c, cpad, mode, out.data_ptr(), T, h * w, nblk, part.data_ptr(), self._stream())
         return part
 
     def scale_residual(self, r: Act, x: Optional[Act], ca: torch.Tensor, extra: Optional[Act] = None) -> Act:
@@ -207,20 +219,21 @@ class Engine32(Engine):
         a = self._conv32(pre + "body.0.weight", None, [v], [kk], k=1)                                             # 1x1 -> 2C
         a = self._conv32(pre + "body.1.conv_2.weight", None, [a], [2 * c], k=3, groups=2 * c, res=a)              # RepConv2
         g1 = self._new(T, h, w, c)
-        self._call("sn32_gate", "sn32_gate", a.data_ptr(), c, 0, g1.data_ptr(), npix, st)                         # SimpleGate
-        if V.denoise:                                                                                               # CALayer2 on g1
-            g1 = self.scale_residual(Act(g1, c), None, self._ca(f"{pre}ca1", g1)).t
+        if V.denoise:                                                                                               # SimpleGate + CALayer2 on g1
+            g1 = self.scale_residual(Act(g1, c), None, self.ca_mlp(f"{pre}ca1", self._gate_sum(a, g1, 0), h * w)).t
+        else:
+            self._call("sn32_gate", "sn32_gate", a.data_ptr(), c, 0, g1.data_ptr(), npix, st)                     # SimpleGate
         grp = c // 8 if V.grouped_rep else c
         rp = f"{pre}body.{u['rep']}."
         r = self._conv32(rp + "conv_1.weight", None, [g1], [c], k=5, groups=grp, res=g1)                           # RepConv: 5x5 + id
         r = self._conv32(rp + "conv_2.weight", None, [g1], [c], k=3, groups=grp, res=r)                            #          + 3x3
         b = self._conv32(f"{pre}body.{u['gate']}.weight", None, [r], [c], k=1)                                     # 1x1 -> 2C
         g2 = self._new(T, h, w, c)
-        self._call("sn32_gate", "sn32_gate", b.data_ptr(), c, 1, g2.data_ptr(), npix, st)                         # SimpleGate2
-        g2 = self.scale_residual(Act(g2, c), None, self._ca(f"{pre}ca2", g2)).t                                    # CALayer2
+        ca2 = self.ca_mlp(f"{pre}ca2", self._gate_sum(b, g2, 1), h * w)                                             # SimpleGate2; CALayer2's scale ...
         ok = f"{pre}body.{u['out']}."
         beta = dsd[pre + "beta"].reshape(1, c)
-        y = self._conv32(ok + "weight", ok + "bias", [g2], [c], k=1, oscale=beta, oscale_stride=0, res=shortcut)  # shortcut + res * beta
+        y = self._conv32(ok + "weight", ok + "bias", [g2], [c], k=1, oscale=beta, oscale_stride=0, res=shortcut,  # shortcut + res * beta
+                         iscale=ca2)                                                                                # ... is applied by this conv's loader
         return Act(y, c)
 
     def _ingest(self, x: torch.Tensor, noise_map: Optional[torch.Tensor]) -> Act:
