@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void conv32m_kernel(const Conv32K P) {
 //   taps 2s, 2s + 1 (13 k-steps for k = 5, 5 for k = 3; lane group g reads tap 2s + (g >> 1), channel half g & 1), as sn_grp5_gemm_gate
 //   does in bf16.
 template <int MTC, int KSZ, bool GROUPED>
-__global__ __launch_bounds__(256, MTC <= 3 ? 3 : 2) void conv32s_kernel(const Conv32K P) {
+__global__ __launch_bounds__(256, 2) void conv32s_kernel(const Conv32K P) {
     extern __shared__ __attribute__((aligned(16))) float smem32[];
     char* const lds = (char*)smem32;
     constexpr int TH = 8, TW = 32, NTW = (TH * TW) / 64, XB = TW / 16;
@@ -436,12 +436,15 @@ __global__ __launch_bounds__(256, MTC <= 3 ? 3 : 2) void conv32s_kernel(const Co
         if constexpr (GROUPED) {
             const int m = cb;                                        // this block feeds M-tile cb only
             const size_t wbase = ((size_t)(blockIdx.z * MTC + m) * KSG) * 64 + lane;
+            bf16x8_t ahx = as_frag(wh[wbase]), alx = as_frag(wl[wbase]);
 #pragma unroll 1
             for (int s2 = 0; s2 < KSG; ++s2) {
                 const int tap = min(2 * s2 + (g4 >> 1), NTAP - 1);   // (tap NTAP does not exist: its weights are zero)
                 const int dy = tap / KSZ, dx = tap - dy * KSZ;
                 const int toff = (dy * RW + dx) * PS + (g4 & 1) * 16;
-                const bf16x8_t ah = as_frag(wh[wbase + (size_t)s2 * 64]), al = as_frag(wl[wbase + (size_t)s2 * 64]);
+                const bf16x8_t ah = ahx, al = alx;
+                const int sn = s2 + 1 < KSG ? s2 + 1 : s2;           // next k-step's fragments in flight during this one's MFMAs
+                ahx = as_frag(wh[wbase + (size_t)sn * 64]); alx = as_frag(wl[wbase + (size_t)sn * 64]);
 #pragma unroll
                 for (int n = 0; n < NTW; ++n) {
                     const bf16x8_t bh = as_frag(*(const uint4*)(lds + pixbase[n] + toff)), bl = as_frag(*(const uint4*)(lds + pixbase[n] + toff + LO));
@@ -455,25 +458,36 @@ __global__ __launch_bounds__(256, MTC <= 3 ? 3 : 2) void conv32s_kernel(const Co
                 }
             }
         } else {
+            // The A fragments of tap + 1 are fetched while tap's MFMAs run: loaded at the point of use, every tap waited for an L2 round trip
+            // (nine per block and workgroup for a 3x3, against ~1.6 us of MFMAs).
+            bf16x8_t ahc[MTC], alc[MTC], ahn[MTC], aln[MTC];
+            auto wload = [&](int tap, bf16x8_t (&h)[MTC], bf16x8_t (&l)[MTC]) {
+#pragma unroll
+                for (int m = 0; m < MTC; ++m) {
+                    const int mg = min((int)blockIdx.z * MTC + m, mt_all - 1);
+                    const size_t wi = ((size_t)mg * ks_all + (size_t)tap * ncb + cb) * 64 + lane;
+                    h[m] = as_frag(wh[wi]); l[m] = as_frag(wl[wi]);
+                }
+            };
+            wload(0, ahc, alc);
 #pragma unroll 1
             for (int tap = 0; tap < NTAP; ++tap) {
                 const int dy = tap / KSZ, dx = tap - dy * KSZ;
                 const int toff = (dy * RW + dx) * PS + g4 * 16;
-                // M-tile outermost: one pair of A fragments live at a time (all MTC pairs at once cost 40 registers and spilled at two waves
-                // per SIMD); the B fragments are re-read from LDS per M-tile, 8 ds_read_b128 against 12 MFMAs
+                wload(tap + 1 < NTAP ? tap + 1 : tap, ahn, aln);
 #pragma unroll
                 for (int m = 0; m < MTC; ++m) {
                     if (m >= mt_n) continue;                         // workgroup-uniform
-                    const size_t wi = ((size_t)(blockIdx.z * MTC + m) * ks_all + (size_t)tap * ncb + cb) * 64 + lane;
-                    const bf16x8_t ah = as_frag(wh[wi]), al = as_frag(wl[wi]);
 #pragma unroll
                     for (int n = 0; n < NTW; ++n) {
                         const bf16x8_t bh = as_frag(*(const uint4*)(lds + pixbase[n] + toff)), bl = as_frag(*(const uint4*)(lds + pixbase[n] + toff + LO));
-                        acc[m][n] = mfma16(al, bh, acc[m][n]);
-                        acc[m][n] = mfma16(ah, bl, acc[m][n]);
-                        acc[m][n] = mfma16(ah, bh, acc[m][n]);
+                        acc[m][n] = mfma16(alc[m], bh, acc[m][n]);
+                        acc[m][n] = mfma16(ahc[m], bl, acc[m][n]);
+                        acc[m][n] = mfma16(ahc[m], bh, acc[m][n]);
                     }
                 }
+#pragma unroll
+                for (int m = 0; m < MTC; ++m) { ahc[m] = ahn[m]; alc[m] = aln[m]; }
             }
         }
     }
