@@ -510,12 +510,15 @@ int launch_conv32s(const Conv32K& K, hipStream_t st) {
 // channels once (hi | lo images, 32-channel blocks side by side) and then walks the output M-tiles in groups of four from that one
 // staged tile -- conv32s_kernel stages the input again for every group of M-tiles (three times for 160 output channels).
 // NHWC fp32 output only, cout / pixel strides multiples of 4 (the caller checks).
+#ifndef SN_1X1_NPX
+#define SN_1X1_NPX 64         // pixels per workgroup: 64 (30 KB of LDS at 80 input channels: 5 workgroups per CU) or 128
+#endif
 template <int NCB>
 __global__ __launch_bounds__(256, 2) void conv32s_1x1_kernel(const Conv32K P, const long long npix) {
     constexpr int ncb = NCB;                                         // compile-time: the k-loop unrolls and a group's weight fragments load up front
     extern __shared__ __attribute__((aligned(16))) float smem32[];
     char* const lds = (char*)smem32;
-    constexpr int NPX = 128, NTW = 2, MTC = 4;
+    constexpr int NPX = SN_1X1_NPX, NTW = NPX / 64, MTC = 4;
     const int PSK = ncb * 160 + ((ncb & 1) ? 0 : 32);               // LDS bytes per pixel: ncb blocks of (hi 64 | lo 64 | pad 32); 2 (mod 4) 16-byte slots
     const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), g4 = lane >> 4, p = lane & 15;
     const long long pix0 = (long long)blockIdx.x * NPX;
@@ -811,11 +814,11 @@ int sn32_conv2d(const sn32_conv_desc* d, void* stream) {
         if (d->wsplit && d->n_in == 1 && d->in_mode == 0 && d->stride == 1 && (d->cs_in[0] & 3) == 0 && (K.cin_total & 3) == 0 &&
             ((size_t)d->in[0] & 15) == 0 && ((size_t)d->wsplit & 15) == 0) {
             const int ncb1 = (K.cin_total + 31) / 32;
-            if (d->groups == 1 && d->k == 1 && d->pad == 0 && d->out_mode == 0 && ncb1 <= 3 && d->h_out * d->w_out >= 128 && (d->c_out & 3) == 0 && (d->cs_out & 3) == 0 &&
+            if (d->groups == 1 && d->k == 1 && d->pad == 0 && d->out_mode == 0 && ncb1 <= 4 && d->h_out * d->w_out >= SN_1X1_NPX && (d->c_out & 3) == 0 && (d->cs_out & 3) == 0 &&
                 ((size_t)d->out & 15) == 0 && (!d->res || ((d->cs_res & 3) == 0 && ((size_t)d->res & 15) == 0)) && mt > 1) {
                 const long long npix = (long long)d->T * d->h_out * d->w_out;
-                const size_t lds = (size_t)128 * (ncb1 * 160 + ((ncb1 & 1) ? 0 : 32));
-                const dim3 grid((unsigned)((npix + 127) / 128));
+                const size_t lds = (size_t)SN_1X1_NPX * (ncb1 * 160 + ((ncb1 & 1) ? 0 : 32));
+                const dim3 grid((unsigned)((npix + SN_1X1_NPX - 1) / SN_1X1_NPX));
 #define SN_1X1_CASE(N) case N: \
                     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv32s_1x1_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH; \
                     hipLaunchKernelGGL(conv32s_1x1_kernel<N>, grid, dim3(256), lds, st, K, npix); break;
