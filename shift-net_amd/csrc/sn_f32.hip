@@ -367,11 +367,14 @@ __global__ __launch_bounds__(256) void conv32m_kernel(const Conv32K P) {
 //   grouped (the "+" RepConv, 8 -> 8 per group, k = 5): block = M-tile = 16 channels (two groups, block-diagonal A); a k-step covers the
 //   taps 2s, 2s + 1 (13 k-steps for k = 5, 5 for k = 3; lane group g reads tap 2s + (g >> 1), channel half g & 1), as sn_grp5_gemm_gate
 //   does in bf16.
+#ifndef SN_C32S_TH3         // tile height of the dense 3x3 instances: 4 rows = 33 KB of LDS (4 workgroups per CU) or 8 rows = 54 KB (2)
+#define SN_C32S_TH3 4
+#endif
 template <int MTC, int KSZ, bool GROUPED>
 __global__ __launch_bounds__(256, 2) void conv32s_kernel(const Conv32K P) {
     extern __shared__ __attribute__((aligned(16))) float smem32[];
     char* const lds = (char*)smem32;
-    constexpr int TH = 8, TW = 32, NTW = (TH * TW) / 64, XB = TW / 16;
+    constexpr int TH = (KSZ == 3 && !GROUPED) ? SN_C32S_TH3 : 8, TW = 32, NTW = (TH * TW) / 64, XB = TW / 16;
     constexpr int RH = TH + KSZ - 1, RW = TW + KSZ - 1, NPATCH = RH * RW, NTAP = KSZ * KSZ;
     constexpr int NCH = GROUPED ? 16 : 32;                          // channels of a staged block
     constexpr int PS = GROUPED ? 80 : 160;                          // LDS bytes per pixel: hi | lo | pad (5 / 10 slots of 16 B)
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void conv32s_kernel(const Conv32K P) {
 
 template <int MTC, int KSZ, bool GROUPED>
 int launch_conv32s(const Conv32K& K, hipStream_t st) {
-    constexpr int TH = 8, TW = 32;
+    constexpr int TH = (KSZ == 3 && !GROUPED) ? SN_C32S_TH3 : 8, TW = 32;
     const size_t lds = (size_t)(TH + KSZ - 1) * (TW + KSZ - 1) * (GROUPED ? 80 : 160);
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv32s_kernel<MTC, KSZ, GROUPED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return SN_ELAUNCH;
