@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 8      /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
+#define SN_ABI_VERSION 9      /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
 
 /* element types of NCHW tensors exchanged with the PyTorch side */
 #define SN_F32 0
@@ -238,8 +238,9 @@ typedef struct sn32_conv_desc {
 } sn32_conv_desc;
 int sn32_conv2d(const sn32_conv_desc* d, void* stream);
 /* channel_shift (gshift_deblur1.py:504-528) materialised in fp32: offs != NULL: u [T][h][w][3C/2] = cat(roll(x), shift(borrowed));
- * offs == NULL: the temporal roll alone, [T][h][w][C] (Shift_CAB, gshift_denoise1.py:167-179).  s->x is a float tensor. */
-int sn32_gsts_gather(const sn_unit_src* s, const int8_t* offs, float* u, void* stream);
+ * offs == NULL: the temporal roll alone, [T][h][w][C] (Shift_CAB, gshift_denoise1.py:167-179).  s->x is a float tensor.
+ * u2: NULL, or (offs != NULL) a second [T][h][w][3C/2] tensor whose first C channels receive roll(x) too (CAB2's LayerNorm input is built in it). */
+int sn32_gsts_gather(const sn_unit_src* s, const int8_t* offs, float* u, float* u2, void* stream);
 /* LayerNorm2d (gshift_deblur1.py:19-28,44-53) over K channels per pixel. */
 int sn32_layernorm(const float* x, int cs_x, int K, const float* w, const float* b, float* out, int cs_out, long long npix, void* stream);
 /* SimpleGate (mode 0, :175-178) / SimpleGate2 (mode 1, :179-182): a:[npix][2C] -> out:[npix][C]. */

@@ -659,7 +659,9 @@ __global__ __launch_bounds__(256) void dw32_kernel(const Conv32K P) {
 struct Unit32 { const float* x; const float* halo; int T, h, w, C, mode, wrap, t0; };
 
 // u = cat(roll(x), spatial_shift2(borrowed half)) (gshift_deblur1.py:504-528); CU = 3C/2, or C for the roll alone (Shift_CAB)
-__global__ void gather32_kernel(const Unit32 U, const int8_t* offs, float* u, const int CU) {
+// u2 (optional): a second [T][h][w][CU] tensor that receives the first C channels (the rolled tensor = CAB2's shortcut) as well: the LayerNorm
+// input cat(shortcut, conv1(shifted)) is assembled in it without a second gather pass.
+__global__ void gather32_kernel(const Unit32 U, const int8_t* offs, float* u, const int CU, float* u2) {
     const int t = U.t0 + blockIdx.y, Ch = U.C >> 1, hw = U.h * U.w;
     const SnSlabs<float> s = sn_unit_slabs<float>(U.x, U.halo, U.T, hw, U.C, U.mode, U.wrap, t);      // SURVEY.md 8a-1 table (sn_common.h)
     const size_t n = (size_t)hw * CU;
@@ -674,6 +676,7 @@ __global__ void gather32_kernel(const Unit32 U, const int8_t* offs, float* u, co
             if (sy >= 0 && sy < U.h && sx >= 0 && sx < U.w) v = s.pb[((size_t)sy * U.w + sx) * s.sb + k];
         }
         u[(size_t)t * n + e] = v;
+        if (u2 && c < U.C) u2[(size_t)t * n + e] = v;
     }
 }
 
@@ -853,13 +856,13 @@ int sn32_conv2d(const sn32_conv_desc* d, void* stream) {
     return sn_check_launch();
 }
 
-int sn32_gsts_gather(const sn_unit_src* s, const int8_t* offs, float* u, void* stream) {
+int sn32_gsts_gather(const sn_unit_src* s, const int8_t* offs, float* u, float* u2, void* stream) {
     sn_clear_error();
-    if (!s || !s->x || !u || (s->C & 1) || s->T < 1 || s->mode < 1 || s->mode > 2 || s->wrap < 0 || s->wrap > 2 || (s->wrap == 2 && !s->halo)) return SN_EINVAL;
+    if (!s || !s->x || !u || (u2 && !offs) || (s->C & 1) || s->T < 1 || s->mode < 1 || s->mode > 2 || s->wrap < 0 || s->wrap > 2 || (s->wrap == 2 && !s->halo)) return SN_EINVAL;
     Unit32 U; U.x = (const float*)s->x; U.halo = (const float*)s->halo; U.T = s->T; U.h = s->h; U.w = s->w; U.C = s->C; U.mode = s->mode; U.wrap = s->wrap;
     SN_FRAME_RANGE(s, t0, nt);
     U.t0 = t0;
-    hipLaunchKernelGGL(gather32_kernel, dim3(1024, nt), dim3(256), 0, (hipStream_t)stream, U, offs, u, offs ? s->C + s->C / 2 : s->C);
+    hipLaunchKernelGGL(gather32_kernel, dim3(1024, nt), dim3(256), 0, (hipStream_t)stream, U, offs, u, offs ? s->C + s->C / 2 : s->C, u2);
     return sn_check_launch();
 }
 

@@ -186,7 +186,7 @@ class Engine32(Engine):
         mode = 2 if reverse else 1
         for wrap, halo, t0, nt in self._split_pieces(x, mode, False):
             s = self._unit_src(x, mode, wrap=wrap, halo=halo, t0=t0, nt=nt)
-            self._call("sn32_gsts_gather", "sn32_temporal_roll", C.byref(s), None, y.data_ptr(), self._stream())
+            self._call("sn32_gsts_gather", "sn32_temporal_roll", C.byref(s), None, y.data_ptr(), None, self._stream())
         return Act(y, c)
 
     def _ca(self, name: str, g: torch.Tensor) -> torch.Tensor:
@@ -203,11 +203,10 @@ class Engine32(Engine):
         self._meta = ("naf32", T, h, w, c, mode)
         if mode:
             ug = self._new(T, h, w, c + c // 2)                                   # cat(roll(x), spatial_shift2(borrowed half))
-            vin = self._new(T, h, w, c + c // 2)                                  # cat(shortcut, conv1(shifted)): a second gather fills [:c], conv1 overwrites [c:]
+            vin = self._new(T, h, w, c + c // 2)                                  # cat(shortcut, conv1(shifted)): the gather fills [:c] as well, conv1 writes [c:]
             for wrap, halo, t0, nt in self._split_pieces(x, mode, V.wrap):        # (temporal split: the boundary frame after its halo arrived)
                 s = self._unit_src(x, mode, wrap=wrap, halo=halo, t0=t0, nt=nt)
-                self._call("sn32_gsts_gather", "sn32_gsts_gather", C.byref(s), P.offs.data_ptr(), ug.data_ptr(), self._stream())
-                self._call("sn32_gsts_gather", "sn32_gsts_gather", C.byref(s), P.offs.data_ptr(), vin.data_ptr(), self._stream())
+                self._call("sn32_gsts_gather", "sn32_gsts_gather", C.byref(s), P.offs.data_ptr(), ug.data_ptr(), vin.data_ptr(), self._stream())
             shortcut = ug[..., :c]
             self._conv32(pre + "conv1.weight", None, [ug[..., c:]], [c // 2], k=3, groups=c // 2, out=vin[..., c:])
             kk = c + c // 2

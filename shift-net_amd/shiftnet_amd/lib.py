@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libshiftnet_hip.so")
 
 SN_F32, SN_F16, SN_BF16 = 0, 1, 2
 
-ABI_VERSION = 8      # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so from before a struct / signature change fails the check in load()
+ABI_VERSION = 9      # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so from before a struct / signature change fails the check in load()
 
 SYMBOLS = [          # include/shiftnet_hip.h, production ABI
     "sn_abi_version", "sn_selftest_mfma", "sn_ingest", "sn_conv2d", "sn_conv_pool_blocks", "sn_ca_mlp",
@@ -130,7 +130,7 @@ def load() -> C.CDLL:
     lib.sn_ssim_u8.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci, vp]
     ll = C.c_longlong
     lib.sn32_conv2d.argtypes = [C.POINTER(Conv32Desc), vp]
-    lib.sn32_gsts_gather.argtypes = [C.POINTER(UnitSrc), vp, vp, vp]
+    lib.sn32_gsts_gather.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp]
     lib.sn32_layernorm.argtypes = [vp, ci, ci, vp, vp, vp, ci, ll, vp]
     lib.sn32_gate.argtypes = [vp, ci, ci, vp, ll, vp]
     lib.sn32_gate_sum.argtypes = [vp, ci, ci, ci, vp, ci, ci, ci, vp, vp]
