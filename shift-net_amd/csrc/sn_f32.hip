@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void conv32s_1x1_kernel(const Conv32K P, co
     constexpr int ncb = NCB;                                         // compile-time: the k-loop unrolls and a group's weight fragments load up front
     extern __shared__ __attribute__((aligned(16))) float smem32[];
     char* const lds = (char*)smem32;
-    constexpr int NPX = SN_1X1_NPX, NTW = NPX / 64, MTC = 4;
+    constexpr int NPX = SN_1X1_NPX;
     const int PSK = ncb * 160 + ((ncb & 1) ? 0 : 32);               // LDS bytes per pixel: ncb blocks of (hi 64 | lo 64 | pad 32); 2 (mod 4) 16-byte slots
     const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), g4 = lane >> 4, p = lane & 15;
     const long long pix0 = (long long)blockIdx.x * NPX;
@@ -552,48 +552,49 @@ __global__ __launch_bounds__(256, 2) void conv32s_1x1_kernel(const Conv32K P, co
         }
     }
     __syncthreads();
+    // The four waves share the workgroup's pixels (NTW N-tiles each of them reads from LDS) and SPLIT THE M-TILES: wave w takes M-tiles
+    // w, w + 4, ...  With the pixels split instead, every wave fetched the fragments of ALL M-tiles -- 4 x 60 KB per 64 pixels for 80 -> 160
+    // channels, four times the bytes of the activations themselves, through one L1.  The next M-tile's fragments load during this one's MFMAs.
+    constexpr int NT = NPX / 16;
     const int mt_all = (P.cout + 15) / 16;
     const uint4* const wh = P.wsplit;                               // [2 parts][mt_all][ncb][64 lanes]
     const uint4* const wl = P.wsplit + (size_t)mt_all * ncb * 64;
-    for (int m0 = 0; m0 < mt_all; m0 += MTC) {
-        f32x4_t acc[MTC][NTW];
-#pragma unroll
-        for (int m = 0; m < MTC; ++m)
-#pragma unroll
-            for (int n = 0; n < NTW; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    bf16x8_t ahc[NCB], alc[NCB], ahn[NCB], aln[NCB];
+    auto wload = [&](int m, bf16x8_t (&h)[NCB], bf16x8_t (&l)[NCB]) {
+        const int mc = m < mt_all ? m : mt_all - 1;
 #pragma unroll
         for (int cb = 0; cb < ncb; ++cb) {
-            bf16x8_t bh[NTW], bl[NTW];
-#pragma unroll
-            for (int n = 0; n < NTW; ++n) {
-                const char* bp = lds + ((wv * NTW + n) * 16 + p) * PSK + cb * 160 + g4 * 16;
-                bh[n] = as_frag(*(const uint4*)bp); bl[n] = as_frag(*(const uint4*)(bp + 64));
-            }
-#pragma unroll
-            for (int m = 0; m < MTC; ++m) {
-                if (m0 + m >= mt_all) continue;                      // workgroup-uniform
-                const size_t wi = ((size_t)(m0 + m) * ncb + cb) * 64 + lane;
-                const bf16x8_t ah = as_frag(wh[wi]), al = as_frag(wl[wi]);
-#pragma unroll
-                for (int n = 0; n < NTW; ++n) {
-                    acc[m][n] = mfma16(al, bh[n], acc[m][n]);
-                    acc[m][n] = mfma16(ah, bl[n], acc[m][n]);
-                    acc[m][n] = mfma16(ah, bh[n], acc[m][n]);
-                }
-            }
+            const size_t wi = ((size_t)mc * ncb + cb) * 64 + lane;
+            h[cb] = as_frag(wh[wi]); l[cb] = as_frag(wl[wi]);
         }
-        // epilogue of this group of M-tiles: lane (g4, p) holds output channels 16 (m0 + m) + 4 g4 + r of pixel (wv * NTW + n) * 16 + p
+    };
+    wload(wv, ahc, alc);
+    for (int m = wv; m < mt_all; m += 4) {                          // wave-uniform; no barrier inside
+        wload(m + 4, ahn, aln);
+        f32x4_t acc[NT];
 #pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-            const long long pg = pix0 + (wv * NTW + n) * 16 + p;
-            if (pg >= npix) continue;
-            const int t = t0 + (prem + (wv * NTW + n) * 16 + p >= hw ? 1 : 0);
+        for (int n = 0; n < NT; ++n) acc[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int m = 0; m < MTC; ++m) {
-                const int c0 = 16 * (m0 + m) + 4 * g4;
-                if (m0 + m >= mt_all || c0 >= P.cout) continue;
-                float a[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
-                if (P.bias) { const float4 bb = *(const float4*)(P.bias + c0); a[0] += bb.x; a[1] += bb.y; a[2] += bb.z; a[3] += bb.w; }
+        for (int cb = 0; cb < ncb; ++cb)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const char* bp = lds + (n * 16 + p) * PSK + cb * 160 + g4 * 16;
+                const bf16x8_t bh = as_frag(*(const uint4*)bp), bl = as_frag(*(const uint4*)(bp + 64));
+                acc[n] = mfma16(alc[cb], bh, acc[n]);
+                acc[n] = mfma16(ahc[cb], bl, acc[n]);
+                acc[n] = mfma16(ahc[cb], bh, acc[n]);
+            }
+        // epilogue: lane (g4, p) holds output channels 16 m + 4 g4 + r of pixel n * 16 + p
+        const int c0 = 16 * m + 4 * g4;
+        if (c0 < P.cout) {
+            float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (P.bias) bb = *(const float4*)(P.bias + c0);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const long long pg = pix0 + n * 16 + p;
+                if (pg >= npix) continue;
+                const int t = t0 + (prem + n * 16 + p >= hw ? 1 : 0);
+                float a[4] = {acc[n][0] + bb.x, acc[n][1] + bb.y, acc[n][2] + bb.z, acc[n][3] + bb.w};
                 if (P.act == 1) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) a[r] = a[r] >= 0.f ? a[r] : a[r] * P.prelu;
@@ -606,6 +607,8 @@ __global__ __launch_bounds__(256, 2) void conv32s_1x1_kernel(const Conv32K P, co
                 *(float4*)((float*)P.out + (size_t)pg * P.cs_out + c0) = make_float4(a[0], a[1], a[2], a[3]);
             }
         }
+#pragma unroll
+        for (int cb = 0; cb < ncb; ++cb) { ahc[cb] = ahn[cb]; alc[cb] = aln[cb]; }
     }
 }
 
