@@ -306,3 +306,24 @@ def test_conv32_split_packing_reconstructs_the_weights():
                 for j in range(8):
                     want = wg[16 * m + r, j, tap // 5, tap % 5].item() if (tap < 25 and (r >> 3) == (gq & 1)) else 0.0
                     assert abs(fullg[m, s_, lane, j] - want) <= 2.0 ** -15 * max(1.0, abs(want)), (m, s_, lane, j)
+
+
+def test_split_precision_product_error_bound():
+    """The arithmetic claim of the split-precision fp32 conv (csrc/sn_f32.hip: conv32s_kernel): with hi = bf16(v), lo = bf16(v - hi), the three
+    kept products wh xh + wh xl + wl xh differ from w x by the dropped wl xl (~2^-16 |w x|) plus the residual of the two-term splits (~2^-17
+    each): a dot product of 720 terms (3x3 conv over 80 channels) stays within 3e-5 of sum |w x| -- here against float64."""
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(64, 720, generator=g)
+    x = torch.randn(720, 256, generator=g) * 3.0
+
+    def split(v):
+        hi = v.to(torch.bfloat16).float()
+        return hi, (v - hi).to(torch.bfloat16).float()
+    wh, wl = split(w)
+    xh, xl = split(x)
+    assert ((w - wh - wl).abs() <= 2.0 ** -16 * w.abs() + 1e-30).all()          # a two-term bf16 split carries 16 significant bits
+    got = (wh.double() @ xh.double()) + (wh.double() @ xl.double()) + (wl.double() @ xh.double())
+    ref = w.double() @ x.double()
+    bound = w.abs().double() @ x.abs().double()
+    assert ((got - ref).abs() <= 3e-5 * bound).all()
+    assert (got - ref).abs().max() > 0                                            # (it is an approximation, not an identity)
