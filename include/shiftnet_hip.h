@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 9      /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
+#define SN_ABI_VERSION 10     /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
 
 /* element types of NCHW tensors exchanged with the PyTorch side */
 #define SN_F32 0
@@ -168,23 +168,33 @@ int sn_dw5m_gemm_gate(const void* g1p, const float* ca_in, const void* ttab, con
  * The global average pool of CALayer2 (gshift_deblur1.py:76-87) is the one grid-wide dependency inside CAB2 / CAB1, so a block is two
  * passes over the frame: phase 1 up to g2 and its channel sums, [sn_ca_mlp on the sums], phase 2 from g2 to the block's output.
  *
- * PHASE 1, fused, depthwise variants without the inner CALayer2 (C = 64: Shift-Net-s deblur), csrc/sn_phase1.hip:
- *   g2 = SimpleGate2(body[4](RepConv(SimpleGate(RepConv2(body[0](norm(u)))))))   (gshift_deblur2.py:186-214 CAB1, :215-258 CAB2)
- * in ONE kernel: u is read once, g2 written once; `a`, g1 and r never reach HBM.  (The other variants run phase 1 as sn_ln_gemm_gate +
- * sn_dw5m_gemm_gate / sn_grp5_gemm_gate with g1 in HBM.)  sn_gsts_cab2_phase1: s->mode 1 / 2, hw = sn_gsts_shiftconv's output;
- * sn_cab1_phase1: s->mode 0.  Weights: prep.pack_phase1 --
- *   wfrag1  bf16 A fragments of body[0] (LayerNorm affine folded, gate-paired rows) [8][K/32][64][8];
- *   wfragx  bf16 [8][16][8]: k-slots 0..7 of the LayerNorm k-step of every row: (W1 hi, W1 lo, W1 hi, W1 lo, b hi, b lo, b hi, b lo), W1 = the
- *           row sum of the bf16 weights, b = the folded bias: the kernel feeds the RAW input to the MFMA and normalises afterwards;
- *   w3 / w5 packed-fp16 stencil tables in accumulator-lane order; wfrag2: fp16 A fragments of body[4] (sigmoid rows times -log2 e).
- * g2: [T][h][w][C] NHWC bf16.  pool: NULL or [T][sn_phase1_pool_blocks(T,h,w)][C] f32 partial channel sums of g2 (CALayer2, finished by
- * sn_ca_mlp).  sn_phase1_pool_blocks queries the current device (the work split depends on its CU count); < 0 on error. */
+ * PHASE 1, fused (the variants without the inner CALayer2: both deblur models), two kernels behind the same entry points:
+ *   g2 = SimpleGate2(body[4](RepConv(SimpleGate(RepConv2(body[0](norm(u)))))))   (gshift_deblur1.py:183-211 CAB1, :212-255 CAB2; gshift_deblur2.py:186-258)
+ * in ONE kernel: u is read once, g2 written once; `a`, g1 and r never reach HBM.  (The denoisers, whose inner CALayer2 needs the global pool
+ * of g1, run phase 1 as sn_ln_gemm_gate + sn_dw5m_gemm_gate / sn_grp5_gemm_gate with g1 in HBM.)  sn_gsts_cab2_phase1: s->mode 1 / 2, hw =
+ * sn_gsts_shiftconv's output; sn_cab1_phase1: s->mode 0.
+ *   layout 0 (csrc/sn_phase1.hip, C = 64 depthwise RepConv on the VALU), weights prep.pack_phase1 --
+ *     wfrag1  bf16 A fragments of body[0] (LayerNorm affine folded, gate-paired rows) [8][K/32][64][8];
+ *     wfragx  bf16 [8][16][8]: k-slots 0..7 of the LayerNorm k-step of every row: (W1 hi, W1 lo, W1 hi, W1 lo, b hi, b lo, b hi, b lo), W1 = the
+ *             row sum of the bf16 weights, b = the folded bias: the kernel feeds the RAW input to the MFMA and normalises afterwards;
+ *     w3 / w5 packed-fp16 stencil tables in accumulator-lane order; wfrag2: fp16 A fragments of body[4] (sigmoid rows times -log2 e).
+ *   layout 1 (csrc/sn_phase1r.hip, role-split, C = 64 or 80, RepConv depthwise or grouped 8 -> 8 ON THE MATRIX CORES), weights prep.pack_phase1r --
+ *     wfrag1  bf16 [C/8][KS1][64][8]: body[0] with the LayerNorm scale folded, wave-paired rows (M-tiles 2q, 2q+1 = channels 16q.. and their gate
+ *             partners), the folded bias as bf16 hi + lo in the columns of k-slots K, K+1 (the kernel feeds the normalised input and a constant 1);
+ *     w3      uint32 [C/16][4][9][4] packed-fp16 taps of RepConv2 (+identity) per (wave, lane group, tap, packed register);
+ *     wgrp    fp16 [C/16][2][8][64][8]: RepConv (5x5 + 3x3 + identity) of every group as an x-pair Toeplitz GEMM (row = output channel + 8 * pixel of a
+ *             pair; k = kernel row, input column 0..5 relative to the pair, input channel);
+ *     wfrag2  fp16 [C/8][KS2][64][8]: body[4], wave-paired rows, sigmoid rows times -log2 e;   wfragx / w5 unused (NULL).
+ * g2: [T][h][w][C] NHWC bf16.  pool: NULL or [T][sn_phase1_pool_blocks(T,h,w,layout)][C] f32 partial channel sums of g2 (CALayer2, finished by
+ * sn_ca_mlp or by the sn_se_fold tail).  sn_phase1_pool_blocks queries the current device (the work split depends on its CU count); < 0 on error. */
 typedef struct sn_phase1_weights {
     const void* wfrag1;
     const void* wfragx;
     const uint32_t* w3;
     const uint32_t* w5;
     const void* wfrag2;
+    const void* wgrp;
+    int layout;          /* 0: csrc/sn_phase1.hip (C = 64), 1: csrc/sn_phase1r.hip (C = 64 / 80) */
 } sn_phase1_weights;
 /* Optional fold of CALayer2's squeeze-excite MLP (gshift_deblur1.py:76-87) into phase 1: the LAST workgroup of a frame to finish reduces
  * the frame's partial sums in a fixed order (bit-reproducible whichever workgroup that is) and writes ca[t][C] = sigmoid(wb relu(wa mean)),
@@ -197,7 +207,7 @@ typedef struct sn_se_fold {
     unsigned* ticket;
     float* ca;
 } sn_se_fold;
-int sn_phase1_pool_blocks(int T, int h, int w);
+int sn_phase1_pool_blocks(int T, int h, int w, int layout);
 int sn_gsts_cab2_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se, void* stream);
 int sn_cab1_phase1(const sn_unit_src* s, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se, void* stream);
 

@@ -443,9 +443,15 @@ constexpr int P1_NX = 3, P1_VWMAX = 16 * P1_NX - 6;      // NX = 4 needs ~300 re
 
 }  // namespace
 
+// layout 1 of sn_phase1_weights: the role-split kernel (csrc/sn_phase1r.hip)
+int sn_p1r_pool_blocks(int T, int h, int w);
+int sn_p1r_launch(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se, void* stream);
+
 extern "C" {
 
-int sn_phase1_pool_blocks(int T, int h, int w) {
+int sn_phase1_pool_blocks(int T, int h, int w, int layout) {
+    if (layout == 1) return sn_p1r_pool_blocks(T, h, w);
+    if (layout != 0) return SN_EINVAL;
     const int ncu = p1_ncu();
     if (ncu < 1 || T < 1 || h < 1 || w < 1) return SN_EINVAL;
     int nsx, vw, nsy, seg;
@@ -455,7 +461,8 @@ int sn_phase1_pool_blocks(int T, int h, int w) {
 
 static int cab_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se, void* stream) {
     sn_clear_error();
-    if (!s || !s->x || s->C != 64 || s->mode < 0 || s->mode > 2 || s->T < 1 || s->h < 1 || s->w < 1 || !wt || !wt->wfrag1 || !wt->wfragx || !wt->w3 ||
+    if (wt && wt->layout == 1) return sn_p1r_launch(s, hw, wt, g2, pool, se, stream);
+    if (!s || !s->x || s->C != 64 || (wt && wt->layout != 0) || s->mode < 0 || s->mode > 2 || s->T < 1 || s->h < 1 || s->w < 1 || !wt || !wt->wfrag1 || !wt->wfragx || !wt->w3 ||
         !wt->w5 || !wt->wfrag2 || !g2 || (s->mode != 0 && !hw) || s->wrap < 0 || s->wrap > 2 || (s->wrap == 2 && s->mode != 0 && !s->halo)) return SN_EINVAL;
     const int ncu = p1_ncu();
     if (ncu < 1) return SN_ELAUNCH;

@@ -1,0 +1,513 @@
+// Role-split fused phase 1 of a CAB1 / CAB2 block of a GSTS unit (gfx950), C = 64 and C = 80, depthwise or grouped RepConv:
+//     g2 = SimpleGate2(body[4](RepConv(SimpleGate(RepConv2(body[0](LayerNorm2d(u)))))))      (gshift_deblur1.py:183-255, gshift_deblur2.py:186-258)
+// in ONE kernel, with the RepConv (grouped 8 -> 8 per group in the "+" models, gshift_deblur1.py:157-165; depthwise in Shift-Net-s) on the
+// MATRIX CORES.  u is read once, g2 written once; `a`, g1 and r never leave the CU.
+//
+// One workgroup per CU walks a 64-pixel wide column strip (58 own columns + 3 halo columns per side) top to bottom, one image row per
+// step, ONE workgroup barrier per step.  Its waves have three roles that form a pipeline through LDS rings:
+//
+//   S (2 waves)   stagers.  Global loads of the virtual input u (two half-channel slabs of x, the shift-conv output hw),
+//                 two rows ahead; TWO-PASS LayerNorm statistics in registers (mean, then sum (x - mean)^2: no E[x^2] - mean^2 cancellation);
+//                 the NORMALISED operand (bf16) goes to the x ring together with a constant 1 in two spare k-slots, whose weight columns
+//                 carry the folded LayerNorm bias (bf16 hi + lo) -- out-of-image pixels are all-zero operands, so `a` is exactly 0 there,
+//                 the zero padding of the 3x3.  They also move finished g2 rows from the out ring to HBM as whole pixels (16-byte stores).
+//                 Only these waves ever wait for HBM.
+//   A (C/16 waves) wave q owns a-channels 16q .. 16q+15 and their gate partners: first 1x1 (bf16 MFMA, weights resident in registers) ->
+//                 packed fp16 -> depthwise 3x3 (+identity) in scatter form on the accumulator layout (v_pk_fma_f16; rows above / below are the
+//                 wave's own registers, horizontal neighbours are the same lane's registers of the other N-tiles because the four tiles
+//                 INTERLEAVE: region column = 4 p + n) -> SimpleGate -> g1 row (fp16, 16 channels = two whole RepConv groups) -> g1 ring.
+//   B (C/16 waves) wave q owns RepConv groups 2q, 2q+1 and gate pair q of the second 1x1.  RepConv as an x-PAIR TOEPLITZ GEMM: one MFMA row
+//                 is (output channel oc of the group, pixel xp of a PAIR of neighbouring pixels), one column a pixel pair, k = (kernel row dy,
+//                 input column dx6 in 0..5 relative to the pair, input channel): K = 5 x 6 x 8 = 240 in 8 k-steps, 5/6 of the matrix is real
+//                 work -- the block-diagonal form of sn_grp5_gemm_gate (two groups per M-tile, half of every fragment zero) needs 13 k-steps
+//                 per 16 pixels, this one 8 per 32.  A depthwise RepConv runs through the same code with diagonal 8 x 8 blocks (the matrix
+//                 cores are otherwise idle; the packed-fp16 VALU form costs 4x the issue slots).  r (fp16) -> r ring; one step later
+//                 every B wave reads all C channels of the row back as the B operand of the second 1x1 (fp16 MFMA), SimpleGate2, channel
+//                 sums for CALayer2, g2 row -> out ring.
+//
+// Step j of a segment [Y0, Y1):   S stages input row Y0-2+j and stores g2 row Y0-9+j;  A turns input row Y0-3+j into g1 row Y0-4+j;
+// B computes r row Y0-7+j from g1 rows Y0-9+j .. Y0-5+j and g2 row Y0-8+j from the r row of the step before.  seg + 9 steps per segment.
+//
+// LDS (C = 80, CAB2: 149 KB, one workgroup per CU): x ring 2 rows, g1 ring 6 rows (5 being read + 1 being written), r ring 2, out ring 2.
+// Every ring is laid out [N-tile n][lane p] so that the 16 lanes of a ds_read_b128 lane group hit 16 distinct 16-byte slots; the g1 ring is
+// [ring row][wave][group][column mod 4][column / 4] with a row pitch that is a multiple of 256 bytes: the four lane groups of a RepConv
+// B fragment read the same columns of four different ring rows (prep.p1r_tap), conflict free.
+//
+// Numerics: `a` and the 3x3 in fp16 as in sn_ln_gemm_gate; g1 and r in fp16 with the factor 2^-4 carried by g1 (exact power of two, undone
+// in the second 1x1's weights), RepConv and the second 1x1 accumulate in fp32 on the matrix cores (the VALU kernel accumulated 25 taps in fp16).
+#include "sn_common.h"
+#include "../../include/shiftnet_hip.h"
+
+namespace {
+
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+struct P1RArgs {
+    const bf16_t* x; const bf16_t* halo; const bf16_t* hwb;
+    int T, h, w, mode, wrap, t0;
+    const uint4* wfrag1; const uint4* w3; const uint4* wgrp; const uint4* wfrag2;
+    bf16_t* g2; float* pool;
+    int nsx, nsy, seg, vw;
+    SeFold se;
+};
+
+__device__ __forceinline__ f32x4_t mfma16h(const uint4 a, const uint4 b, const f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t cvt_pk_h2(float lo, float hi) {           // v_cvt_pk_f16_f32, round to nearest even
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h2_t));
+}
+__device__ __forceinline__ h2_t as_h2(uint32_t u) { return __builtin_bit_cast(h2_t, u); }
+__device__ __forceinline__ uint32_t as_u(h2_t h) { return __builtin_bit_cast(uint32_t, h); }
+__device__ __forceinline__ uint32_t lane_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }   // lane p <- p - 1 (row_shr:1), 0 at p = 0
+__device__ __forceinline__ uint32_t lane_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true); }   // lane p <- p + 1 (row_shl:1), 0 at p = 15
+
+#ifndef P1R_LDS_PAD      // measurement builds only
+#define P1R_LDS_PAD 0
+#endif
+// how many LDS fragment reads the MFMA loops keep in flight ahead of their consumers (A: first 1x1, B: RepConv, B2: second 1x1)
+#ifndef P1R_DA
+#define P1R_DA 6
+#endif
+#ifndef P1R_DB
+#define P1R_DB 8
+#endif
+#ifndef P1R_DB2
+#define P1R_DB2 6
+#endif
+
+// compile-time geometry shared by the kernel and the launcher
+template <int C, bool HW> struct P1RShape {
+    static constexpr int NGP = C / 16, NW = 2 * NGP + 2, NTHR = 64 * NW;
+    static constexpr int CH = C / 2, K = HW ? C + CH : C, KS1 = (K + 2 + 31) / 32, KS2 = (C + 31) / 32;
+    static constexpr int NX = 4, RWD = 16 * NX, HALO = 3, VWMAX = RWD - 2 * HALO;
+    static constexpr int PSX = KS1 * 64 + 32;                 // bytes per pixel of a staged row: 4 KS1 + 2 slots of 16 B (2 mod 4)
+    static constexpr int XSLOT = RWD * PSX;
+    static constexpr int GPL = 18 * 16;                       // bytes per g1 plane: 16 columns + one pad column on each side, 16 B each
+    static constexpr int GROW = NGP * 2 * 4 * GPL;            // bytes per g1 ring row: [wave][group][column mod 4][18]; 11520 / 9216: multiples of 256
+    static constexpr int GRING = 6;
+    static constexpr int PSR = 160;                           // bytes per pixel of an r row (10 slots: 2 mod 4), also for C = 64
+    static constexpr int RSLOT = RWD * PSR + 64;              // + pad: the last k-step of the second 1x1 reads past a pixel's C channels (zero weights)
+    static constexpr int PSO = C * 2 + 16;
+    static constexpr int OSLOT = RWD * PSO;
+    static constexpr int OFF_X = 0, OFF_G = OFF_X + 2 * XSLOT, OFF_R = OFF_G + GRING * GROW, OFF_O = OFF_R + 2 * RSLOT;
+    static constexpr int LDS = OFF_O + 2 * OSLOT + P1R_LDS_PAD;
+    static constexpr int WARM = 9;                            // steps per segment beyond its rows
+    static_assert(GROW % 256 == 0, "the four lane groups of a RepConv B fragment read four ring rows: the pitch must keep their bank phase");
+    static_assert(LDS <= 160 * 1024, "LDS");
+    static_assert((16 + NTHR + 256) * 4 <= 2 * OSLOT, "sn_se_tail scratch lives in the out ring");
+};
+
+template <int C, bool HW>
+__global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(const P1RArgs A) {
+    using SH = P1RShape<C, HW>;
+    constexpr int NGP = SH::NGP, NTHR = SH::NTHR, CH = SH::CH, K = SH::K, KS1 = SH::KS1, KS2 = SH::KS2, NX = SH::NX;
+    constexpr int PSX = SH::PSX, XSLOT = SH::XSLOT, GPL = SH::GPL, GROW = SH::GROW, PSR = SH::PSR, RSLOT = SH::RSLOT, PSO = SH::PSO, OSLOT = SH::OSLOT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const lds_x = smem + SH::OFF_X;
+    char* const lds_g = smem + SH::OFF_G;
+    char* const lds_r = smem + SH::OFF_R;
+    char* const lds_o = smem + SH::OFF_O;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
+    const int b = blockIdx.x, sx = b % A.nsx, sy = (b / A.nsx) % A.nsy, t = A.t0 + b / (A.nsx * A.nsy);
+    const int x0 = sx * A.vw, Y0 = sy * A.seg, Y1 = Y0 + A.seg < A.h ? Y0 + A.seg : A.h;
+    if (Y0 >= A.h) return;                                                    // workgroup-uniform
+    const int h = A.h, w = A.w, hw = h * w;
+    const int seg = Y1 - Y0, NS = (seg + SH::WARM + 1) & ~1;      // even: the stagers rotate two register sets (a padding step only has the barrier)
+
+    // role of this wave.  A workgroup's waves go to the four SIMDs round-robin, so waves wv, wv + 4, wv + 8 share a SIMD: the roles are laid
+    // out so that every SIMD gets one A wave (VALU-heavy), one B wave (MFMA-heavy) and one of {A4, B4, S0, S1}
+    int role, q;                                                              // 0: A, 1: B, 2: S
+    if (wv < 4) { role = 0; q = wv; }
+    else if (wv < 8) { role = 1; q = wv - 4; }
+    else if (wv - 8 < 2 * (NGP - 4)) { role = (wv - 8) & 1; q = 4 + ((wv - 8) >> 1); }
+    else { role = 2; q = wv - 8 - 2 * (NGP - 4); }
+
+    // ---- zero all LDS once: ring pads, unused k-slots and the rows B reads before A has produced them must be finite ----
+    for (int e = tid; e < SH::LDS / 16; e += NTHR) ((uint4*)smem)[e] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+
+    if (role == 2) {
+        // =================================================== S: stagers ===================================================
+        const int stid = q * 64 + lane, spx = stid >> 1, half = stid & 1;     // two lanes per region pixel
+        constexpr int NPC = K / 8, NP0 = (NPC + 1) / 2;                      // 16-byte pieces of a pixel's K channels; pieces per lane
+        const SnSlabs<bf16_t> sl = sn_unit_slabs<bf16_t>(A.x, A.halo, A.T, hw, C, A.mode, A.wrap, t);
+        const bf16_t* sp[NP0];
+        int sst[NP0];
+        bool sval[NP0];
+#pragma unroll
+        for (int i = 0; i < NP0; ++i) {
+            const int pi = half * NP0 + i;
+            sval[i] = pi < NPC;
+            const int pc = sval[i] ? pi : 0;
+            if (pc < CH / 8) { sp[i] = sl.p0 + 8 * pc; sst[i] = sl.s0; }
+            else if (pc < C / 8) { sp[i] = sl.p1 + 8 * (pc - CH / 8); sst[i] = sl.s1; }
+            else { sp[i] = A.hwb + (size_t)t * hw * CH + 8 * (pc - C / 8); sst[i] = CH; }
+        }
+        const int sgx = x0 - SH::HALO + spx, sgxc = (sgx >= 0 && sgx < w) ? sgx : 0;
+        const int xoff = ((spx & 3) * 16 + (spx >> 2)) * PSX + half * NP0 * 16;
+        uint4 XA[NP0], XB[NP0];
+        auto issue_row = [&](int y, uint4* X) {
+            const int yc = (y >= 0 && y < h) ? y : 0;
+            const int ii = yc * w + sgxc;
+#pragma unroll
+            for (int i = 0; i < NP0; ++i) X[i] = *(const uint4*)(sp[i] + ii * sst[i]);
+        };
+        auto stage_row = [&](int slot, const uint4* X, int y) {
+            const bool inimg = y >= 0 && y < h && sgx >= 0 && sgx < w;
+            float s1 = 0.f;
+            uint32_t wd[NP0][4];
+#pragma unroll
+            for (int i = 0; i < NP0; ++i) {
+                wd[i][0] = sval[i] ? X[i].x : 0u; wd[i][1] = sval[i] ? X[i].y : 0u; wd[i][2] = sval[i] ? X[i].z : 0u; wd[i][3] = sval[i] ? X[i].w : 0u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s1 = dot2bf(wd[i][k], 0x3f803f80u, s1);
+            }
+            s1 += dpp_mov<0xB1>(s1);                                          // the pixel's other lane (quad_perm [1,0,3,2])
+            const float mean = s1 * (1.0f / K);
+            const f32x2_t mean2 = {mean, mean};
+            f32x2_t d[NP0][4];
+            f32x2_t sq2 = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NP0; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x2_t v = {bf_lo(wd[i][k]), bf_hi(wd[i][k])};
+                    d[i][k] = sval[i] ? v - mean2 : (f32x2_t){0.f, 0.f};
+                    sq2 = __builtin_elementwise_fma(d[i][k], d[i][k], sq2);
+                }
+            float sq = sq2[0] + sq2[1];
+            sq += dpp_mov<0xB1>(sq);
+            const float rstd = inimg ? __builtin_amdgcn_rsqf(sq * (1.0f / K) + 1e-6f) : 0.f;      // 0: an all-zero operand outside the image
+            const f32x2_t rstd2 = {rstd, rstd};
+            char* xs = lds_x + slot * XSLOT + xoff;
+#pragma unroll
+            for (int i = 0; i < NP0; ++i) {
+                uint4 o;
+                f32x2_t e0 = d[i][0] * rstd2, e1 = d[i][1] * rstd2, e2 = d[i][2] * rstd2, e3 = d[i][3] * rstd2;
+                o.x = pack_bf2(e0[0], e0[1]); o.y = pack_bf2(e1[0], e1[1]); o.z = pack_bf2(e2[0], e2[1]); o.w = pack_bf2(e3[0], e3[1]);
+                if (sval[i]) *(uint4*)(xs + i * 16) = o;
+            }
+            // the constant-one slots K, K + 1 (the bias columns of the weights); the rest of that piece stays zero
+            if (half) *(uint32_t*)(lds_x + slot * XSLOT + ((spx & 3) * 16 + (spx >> 2)) * PSX + K * 2) = inimg ? 0x3f803f80u : 0u;
+        };
+        auto store_row = [&](int j) {                                         // g2 row Y0 - 9 + j, written to out slot (j - 1) & 1 by the B waves in step j - 1
+            const int yo = Y0 - 9 + j;
+            const char* os = lds_o + ((j - 1) & 1) * OSLOT;
+            bf16_t* const g2row = A.g2 + ((size_t)t * h + yo) * w * C;
+            constexpr int NPO = C / 8, NIT = (SH::VWMAX * NPO + 127) / 128;
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int e = stid + 128 * k, px = e / NPO, pc = e - px * NPO, rc = SH::HALO + px, gx = x0 + px;
+                const bool ok = px < A.vw && gx < w;
+                const uint4 v = *(const uint4*)(os + ((rc & 3) * 16 + (rc >> 2)) * PSO + pc * 16);
+                if (ok) *(uint4*)(g2row + (gx * C + pc * 8)) = v;
+            }
+        };
+        issue_row(Y0 - 3, XA);
+        issue_row(Y0 - 2, XB);
+        stage_row(0, XA, Y0 - 3);
+        issue_row(Y0 - 1, XA);
+        __syncthreads();
+        // step j: stage row Y0 - 2 + j (loaded two steps ago) into slot (j + 1) & 1, refill that register set with row Y0 + j, store a g2 row
+        // (The loads are issued on EVERY path, past the segment's last row from a clamped row that hits in cache: the compiler's s_waitcnt
+        //  counts assume the path with the fewest younger operations, and a path without the refill degrades every wait to "everything landed".)
+        const int ylast = Y1 + 2;
+        auto step = [&](const int j, uint4* X) {
+            if (j <= seg + 4) stage_row((j + 1) & 1, X, Y0 - 2 + j);
+            issue_row(Y0 + j < ylast ? Y0 + j : ylast, X);
+            __builtin_amdgcn_sched_barrier(0);                                // the loads stay in front of the stores (vmcnt retires in order)
+            if (j >= 9 && j <= seg + 8) store_row(j);                        // (NS may contain one padding step)
+            __syncthreads();
+        };
+#pragma unroll 1
+        for (int j = 0; j < NS; j += 2) {
+            step(j, XB);
+            step(j + 1, XA);
+        }
+    } else if (role == 0) {
+        // =================================================== A: first 1x1, 3x3, gate ===================================================
+        bf16x8_t W1[2][KS1];
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) {
+            W1[0][s] = as_frag(A.wfrag1[((2 * q) * KS1 + s) * 64 + lane]);
+            W1[1][s] = as_frag(A.wfrag1[((2 * q + 1) * KS1 + s) * 64 + lane]);
+        }
+        h2_t w3r[9][4];                                                       // packed-fp16 taps of the lane's four packed registers
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            const uint4 v = A.w3[(q * 4 + g) * 9 + tp];
+            w3r[tp][0] = as_h2(v.x); w3r[tp][1] = as_h2(v.y); w3r[tp][2] = as_h2(v.z); w3r[tp][3] = as_h2(v.w);
+        }
+        bool colin[NX];
+#pragma unroll
+        for (int n = 0; n < NX; ++n) { const int gx = x0 - SH::HALO + NX * p + n; colin[n] = gx >= 0 && gx < w; }
+        h2_t P0[NX][4], P1[NX][4];                   // pending rows of the 3x3: when row y arrives P1 = row y-1 (lacks row y), P0 = row y (lacks y, y+1)
+        const h2_t hz = {(_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+        for (int n = 0; n < NX; ++n)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { P0[n][k] = hz; P1[n][k] = hz; }
+        const int xrd = p * PSX + g * 16;                                     // + slot, + n * 16 PSX + 64 s (immediates)
+        const int gwr = ((2 * q + (g >> 1)) * 4) * GPL + (p + 1) * 16 + (g & 1) * 8;      // + ring row, + n * GPL
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the weights have landed (no conservative waits inside the loop)
+        __syncthreads();
+        int gslot = 0;                                                        // j mod 6
+#pragma unroll 1
+        for (int j = 0; j < NS; ++j) {
+            if (j <= seg + 5) {
+                const int yin = Y0 - 3 + j;
+                const char* xs = lds_x + (j & 1) * XSLOT + xrd;
+                uint32_t ah[NX][4];
+                {
+                    // B fragments are read P1R_DA items AHEAD of the MFMAs that consume them (item = (tile n, k-step s), two MFMAs each): left to
+                    // itself the compiler issues every ds_read right in front of its MFMA and the wave waits out one LDS latency per fragment
+                    constexpr int NI = NX * KS1, DA = P1R_DA < NI ? P1R_DA : NI;
+                    uint4 bq[NI];
+#pragma unroll
+                    for (int i = 0; i < DA; ++i) bq[i] = *(const uint4*)(xs + (i / KS1) * 16 * PSX + 64 * (i % KS1));
+                    __builtin_amdgcn_sched_group_barrier(0x100, DA, 0);
+                    f32x4_t acc[NX][2];
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        const int n = i / KS1, s_ = i % KS1;
+                        if (i + DA < NI) bq[i + DA] = *(const uint4*)(xs + ((i + DA) / KS1) * 16 * PSX + 64 * ((i + DA) % KS1));
+                        if (s_ == 0) { acc[n][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[n][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+                        acc[n][0] = mfma16(W1[0][s_], as_frag(bq[i]), acc[n][0]); acc[n][1] = mfma16(W1[1][s_], as_frag(bq[i]), acc[n][1]);
+                        if (i + DA < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    }
+#pragma unroll
+                    for (int n = 0; n < NX; ++n) {
+                        ah[n][0] = cvt_pk_h2(acc[n][0][0], acc[n][0][1]); ah[n][1] = cvt_pk_h2(acc[n][0][2], acc[n][0][3]);
+                        ah[n][2] = cvt_pk_h2(acc[n][1][0], acc[n][1][1]); ah[n][3] = cvt_pk_h2(acc[n][1][2], acc[n][1][3]);
+                    }
+                }
+                // depthwise 3x3 (+identity), scatter form: input row yin completes output row yin - 1, feeds row yin, opens row yin + 1
+                h2_t F[NX][4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t Lw = lane_prev(ah[NX - 1][k]), Rw = lane_next(ah[0][k]);      // the two operands that cross the lane boundary
+#pragma unroll
+                    for (int ti = 0; ti < 3; ++ti) {                          // ty = 2 first: it reads P1 before ty = 1 overwrites it (from P0), then ty = 0 reopens P0
+                        const int ty = 2 - ti;
+#pragma unroll
+                        for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                            for (int n = 0; n < NX; ++n) {
+                                const uint32_t src = tx == 0 ? (n > 0 ? ah[n - 1][k] : Lw) : (tx == 1 ? ah[n][k] : (n + 1 < NX ? ah[n + 1][k] : Rw));
+                                const h2_t v = as_h2(src), wk = w3r[ty * 3 + tx][k];
+                                if (ty == 2) F[n][k] = __builtin_elementwise_fma(v, wk, tx == 0 ? P1[n][k] : F[n][k]);
+                                else if (ty == 1) P1[n][k] = __builtin_elementwise_fma(v, wk, tx == 0 ? P0[n][k] : P1[n][k]);
+                                else P0[n][k] = tx == 0 ? v * wk : __builtin_elementwise_fma(v, wk, P0[n][k]);
+                            }
+                    }
+                }
+                // SimpleGate -> g1 row yin - 1 (zero outside the image: the zero padding of the RepConv) -> ring row j mod 6
+                const bool rin = (yin - 1) >= 0 && (yin - 1) < h;
+                char* gs = lds_g + gslot * GROW + gwr;
+#pragma unroll
+                for (int n = 0; n < NX; ++n) {
+                    const uint32_t m = (rin && colin[n]) ? 0xffffffffu : 0u;
+                    *(uint2*)(gs + n * GPL) = make_uint2(as_u(F[n][0] * F[n][2]) & m, as_u(F[n][1] * F[n][3]) & m);
+                }
+            }
+            gslot = gslot == SH::GRING - 1 ? 0 : gslot + 1;
+            __syncthreads();
+        }
+    } else {
+        // =================================================== B: RepConv, second 1x1, gate2 ===================================================
+        uint4 Wg[2][8];
+#pragma unroll
+        for (int G = 0; G < 2; ++G)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) Wg[G][s] = A.wgrp[((q * 2 + G) * 8 + s) * 64 + lane];
+        uint4 W2[2][KS2];
+#pragma unroll
+        for (int s = 0; s < KS2; ++s) {
+            W2[0][s] = A.wfrag2[((2 * q) * KS2 + s) * 64 + lane];
+            W2[1][s] = A.wfrag2[((2 * q + 1) * KS2 + s) * 64 + lane];
+        }
+        float own[NX];
+#pragma unroll
+        for (int n = 0; n < NX; ++n) {
+            const int rc = NX * p + n, gx = x0 - SH::HALO + rc;
+            own[n] = (rc >= SH::HALO && rc < SH::HALO + A.vw && gx < w) ? 1.f : 0.f;
+        }
+        float psum[4] = {0.f, 0.f, 0.f, 0.f};
+        // RepConv B fragments.  Pair-tile u, lane p = pixels (4p + 2u, 4p + 2u + 1) of the region; tap (dy, dx6) reads column 4p + 2u + dx6 - 2 of
+        // g1 row yr - 2 + dy.  Ring column = column + 4: plane (column mod 4), position p + 1 + floor((2u + dx6 - 2) / 4).
+        // steps 0..5: dy = lane group, dx6 = step  -> per-lane ring row, compile-time plane / position
+        // steps 6, 7: dy = 4, dx6 = lane group (+ 4)   -> uniform ring row, per-lane plane / position
+        const int gq0 = q * 2 * 4 * GPL + p * 16;
+        int off67[2][2];                                                      // [u][step - 6], without the ring row
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int s7 = 0; s7 < 2; ++s7) {
+                const int dx6 = s7 ? 4 + (g & 1) : g, e = 2 * u + dx6 - 2 + 4;                   // + 4: non-negative
+                off67[u][s7] = gq0 + (e & 3) * GPL + (e >> 2) * 16;
+            }
+        const int rwr = p * PSR + (16 * q + 4 * (g & 1)) * 2;                // + slot, + (2u + (g >> 1)) * 16 PSR, + 16 G
+        const int rrd = p * PSR + g * 16;                                     // + slot, + n * 16 PSR + 64 s
+        const int owr = p * PSO + (16 * q + 4 * g) * 2;                       // + slot, + n * 16 PSO
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        int jm = 1;                                                           // (j - 5) mod 6
+#pragma unroll 1
+        for (int j = 0; j < NS; ++j) {
+            // ---- second 1x1 + SimpleGate2 on the r row of the previous step: g2 row Y0 - 8 + j -> out slot j & 1 ----
+            if (j >= 8 && j <= seg + 7) {
+                const char* rs = lds_r + ((j - 1) & 1) * RSLOT + rrd;
+                char* os = lds_o + (j & 1) * OSLOT + owr;
+                constexpr int NI = NX * KS2, DB = P1R_DB2 < NI ? P1R_DB2 : NI;      // item = (tile n, k-step s): one fragment, two MFMAs
+                uint4 bq[NI];
+#pragma unroll
+                for (int i = 0; i < DB; ++i) bq[i] = *(const uint4*)(rs + (i / KS2) * 16 * PSR + 64 * (i % KS2));
+                __builtin_amdgcn_sched_group_barrier(0x100, DB, 0);
+                f32x4_t c[NX][2];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int n = i / KS2, s_ = i % KS2;
+                    if (i + DB < NI) bq[i + DB] = *(const uint4*)(rs + ((i + DB) / KS2) * 16 * PSR + 64 * ((i + DB) % KS2));
+                    if (s_ == 0) { c[n][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; c[n][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+                    c[n][0] = mfma16h(W2[0][s_], bq[i], c[n][0]); c[n][1] = mfma16h(W2[1][s_], bq[i], c[n][1]);
+                    if (i + DB < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                }
+#pragma unroll
+                for (int n = 0; n < NX; ++n) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {                             // b1 * sigmoid(b2); the gate rows carry -log2(e) (prep.pack_phase1r)
+                        v[r] = c[n][0][r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(c[n][1][r]));
+                        psum[r] = fmaf(v[r], own[n], psum[r]);
+                    }
+                    *(uint2*)(os + n * 16 * PSO) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                }
+            }
+            // ---- RepConv: r row Y0 - 7 + j from g1 ring rows (j - 5 + dy) mod 6 -> r slot j & 1 ----
+            if (j >= 7 && j <= seg + 6) {
+                int r6 = jm + g;
+                r6 = r6 >= SH::GRING ? r6 - SH::GRING : r6;
+                const char* gb = lds_g + r6 * GROW + gq0;                     // steps 0..5: this lane group's ring row
+                const int r4 = jm + 4 >= SH::GRING ? jm + 4 - SH::GRING : jm + 4;
+                const char* g4 = lds_g + r4 * GROW;                           // steps 6, 7: ring row of dy = 4
+                char* rs = lds_r + (j & 1) * RSLOT + rwr;
+                // item i = (G, s, u): one fragment, one MFMA; fragments are read P1R_DB items ahead (see the A waves)
+                auto rd = [&](const int i) -> uint4 {
+                    const int G = i >> 4, s_ = (i >> 1) & 7, u = i & 1;
+                    if (s_ < 6) {
+                        const int e = 2 * u + s_ - 2 + 4;
+                        return *(const uint4*)(gb + (G * 4 + (e & 3)) * GPL + (e >> 2) * 16);
+                    }
+                    return *(const uint4*)(g4 + off67[u][s_ - 6] + G * 4 * GPL);
+                };
+                constexpr int NI = 32, DB = P1R_DB;
+                uint4 bq[NI];
+#pragma unroll
+                for (int i = 0; i < DB; ++i) bq[i] = rd(i);
+                __builtin_amdgcn_sched_group_barrier(0x100, DB, 0);
+                f32x4_t acc[2][2];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int G = i >> 4, s_ = (i >> 1) & 7, u = i & 1;
+                    if (i + DB < NI) bq[i + DB] = rd(i + DB);
+                    if (s_ == 0) acc[G][u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                    acc[G][u] = mfma16h(Wg[G][s_], bq[i], acc[G][u]);
+                    if (i + DB < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+#pragma unroll
+                for (int G = 0; G < 2; ++G)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)                               // D row 4g + r = (oc = 4 (g & 1) + r, xp = g >> 1): pixel 4p + 2u + xp = N-tile 2u + xp
+                        *(uint2*)(rs + (2 * u + (g >> 1)) * 16 * PSR + 16 * G) =
+                            make_uint2(cvt_pk_h2(acc[G][u][0], acc[G][u][1]), cvt_pk_h2(acc[G][u][2], acc[G][u][3]));
+            }
+            jm = jm == SH::GRING - 1 ? 0 : jm + 1;
+            __syncthreads();
+        }
+        // channel sums of this (frame, strip, segment) for CALayer2: lane group g owns channels 16 q + 4 g + r
+        if (A.pool) {
+            const int nblk = A.nsx * A.nsy, blk = sy * A.nsx + sx;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sm = row_sum16(psum[r]);
+                if (p == 0) sn_pool_store(&A.pool[((size_t)t * nblk + blk) * C + 16 * q + 4 * g + r], sm);
+            }
+        }
+    }
+    // the last workgroup of the frame finishes CALayer2 (the out ring is free: its last reader is behind the final barrier of the walk)
+    if (A.pool && A.se.ca) {
+        const int nblk = A.nsx * A.nsy;
+        sn_se_tail(A.se, A.pool + (size_t)t * nblk * C, nblk, C, t, (float*)lds_o, tid, NTHR);
+    }
+}
+
+// row segments per column strip: as few rounds of resident workgroups (ONE per CU) as possible, each (segment + warm-up) steps long
+void p1r_partition(int T, int h, int w, int ncu, int vwmax, int warm, int& nsx, int& vw, int& nsy, int& seg) {
+    nsx = (w + vwmax - 1) / vwmax;
+    vw = (w + nsx - 1) / nsx;
+    long best = -1;
+    nsy = 1;
+    for (int cand = 1; cand <= (h + 7) / 8; ++cand) {
+        const int sg = (h + cand - 1) / cand;
+        if ((sg * (cand - 1)) >= h) continue;                                 // the last segment would be empty
+        const long items = (long)T * nsx * cand, rounds = (items + ncu - 1) / ncu;
+        const long cost = rounds * (sg + warm);
+        if (best < 0 || cost < best) { best = cost; nsy = cand; }
+    }
+    seg = (h + nsy - 1) / nsy;
+}
+
+int p1r_ncu() {
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) return -1;
+    return ncu;
+}
+
+template <int C, bool HW>
+int p1r_launch(P1RArgs& A, int nt, hipStream_t st) {
+    using SH = P1RShape<C, HW>;
+    if (hipFuncSetAttribute((const void*)cab_phase1r_kernel<C, HW>, hipFuncAttributeMaxDynamicSharedMemorySize, SH::LDS) != hipSuccess) return SN_ELAUNCH;
+    sn_clear_error();
+    hipLaunchKernelGGL((cab_phase1r_kernel<C, HW>), dim3((unsigned)(nt * A.nsx * A.nsy)), dim3(SH::NTHR), SH::LDS, st, A);
+    return sn_check_launch();
+}
+
+}  // namespace
+
+// ---- entry points shared with csrc/sn_phase1.hip (which owns the C symbols): layout 1 of sn_phase1_weights ----
+int sn_p1r_pool_blocks(int T, int h, int w) {
+    const int ncu = p1r_ncu();
+    if (ncu < 1 || T < 1 || h < 1 || w < 1) return SN_EINVAL;
+    int nsx, vw, nsy, seg;
+    p1r_partition(T, h, w, ncu, P1RShape<80, true>::VWMAX, P1RShape<80, true>::WARM, nsx, vw, nsy, seg);
+    return nsx * nsy;
+}
+
+int sn_p1r_launch(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se, void* stream) {
+    sn_clear_error();
+    if (!s || !s->x || (s->C != 64 && s->C != 80) || s->mode < 0 || s->mode > 2 || s->T < 1 || s->h < 1 || s->w < 1 || !wt || !wt->wfrag1 || !wt->w3 ||
+        !wt->wgrp || !wt->wfrag2 || !g2 || (s->mode != 0 && !hw) || s->wrap < 0 || s->wrap > 2 || (s->wrap == 2 && s->mode != 0 && !s->halo)) return SN_EINVAL;
+    const int ncu = p1r_ncu();
+    if (ncu < 1) return SN_ELAUNCH;
+    P1RArgs A;
+    A.x = (const bf16_t*)s->x; A.halo = (const bf16_t*)s->halo; A.hwb = (const bf16_t*)hw; A.T = s->T; A.h = s->h; A.w = s->w; A.mode = s->mode; A.wrap = s->wrap;
+    A.wfrag1 = (const uint4*)wt->wfrag1; A.w3 = (const uint4*)wt->w3; A.wgrp = (const uint4*)wt->wgrp; A.wfrag2 = (const uint4*)wt->wfrag2;
+    A.g2 = (bf16_t*)g2; A.pool = pool;
+    A.se.ca = nullptr;
+    if (se) {
+        if (!pool || !se->wa || !se->wb || !se->ticket || !se->ca || se->c != s->C || se->cr < 1 || se->cr > 128) return SN_EINVAL;
+        A.se.wa = se->wa; A.se.wb = se->wb; A.se.ca = se->ca; A.se.ticket = se->ticket; A.se.inv_hw = 1.0f / ((float)s->h * (float)s->w);
+        A.se.c = se->c; A.se.cr = se->cr;
+    }
+    p1r_partition(s->T, s->h, s->w, ncu, P1RShape<80, true>::VWMAX, P1RShape<80, true>::WARM, A.nsx, A.vw, A.nsy, A.seg);   // from the WHOLE unit: it fixes the pool layout
+    SN_FRAME_RANGE(s, t0, nt);
+    A.t0 = t0;
+    hipStream_t st = (hipStream_t)stream;
+    if (s->C == 80) return s->mode ? p1r_launch<80, true>(A, nt, st) : p1r_launch<80, false>(A, nt, st);
+    return s->mode ? p1r_launch<64, true>(A, nt, st) : p1r_launch<64, false>(A, nt, st);
+}

@@ -121,12 +121,16 @@ class Plan:
             u["w_toep5"] = self._dev(prep.pack_toeplitz(w5, 5))           # K3m: 5x5 on the matrix cores
         i += 1
         u["w_gate"] = self._dev(prep.pack_gate_gemm(sd[f"{pre}body.{i}.weight"], c))
-        if c == 64 and not V.grouped_rep and not V.denoise:      # fused phase 1 (sn_gsts_cab2_phase1 / sn_cab1_phase1): Shift-Net-s deblur
-            p1 = prep.pack_phase1(sd[f"{pre}body.0.weight"], sd[pre + "norm.weight"], sd[pre + "norm.bias"], sd[f"{pre}body.1.conv_2.weight"],
-                                  sd[f"{pre}body.{i - 1}.conv_1.weight"], sd[f"{pre}body.{i - 1}.conv_2.weight"], sd[f"{pre}body.{i}.weight"], c)
-            d = {k: self._dev(v) for k, v in p1.items()}
-            d["desc"] = L.Phase1Weights(*(d[k].data_ptr() for k in ("wfrag1", "wfragx", "w3", "w5", "wfrag2")))   # the tensors stay referenced in d
-            u["p1"] = d
+        if not V.denoise:      # fused phase 1 (sn_gsts_cab2_phase1 / sn_cab1_phase1): the deblur models (the denoisers' inner CALayer2 needs the global pool of g1)
+            args = (sd[f"{pre}body.0.weight"], sd[pre + "norm.weight"], sd[pre + "norm.bias"], sd[f"{pre}body.1.conv_2.weight"],
+                    sd[f"{pre}body.{i - 1}.conv_1.weight"], sd[f"{pre}body.{i - 1}.conv_2.weight"], sd[f"{pre}body.{i}.weight"], c)
+            if c == 64 and not V.grouped_rep:      # layout 0: csrc/sn_phase1.hip, depthwise stencils on the VALU
+                d = {k: self._dev(v) for k, v in prep.pack_phase1(*args).items()}
+                d["desc"] = L.Phase1Weights(*(d[k].data_ptr() for k in ("wfrag1", "wfragx", "w3", "w5", "wfrag2")), None, 0)   # the tensors stay referenced in d
+                u["p1"] = d
+            d = {k: self._dev(v) for k, v in prep.pack_phase1r(*args).items()}   # layout 1: csrc/sn_phase1r.hip, role-split, RepConv on the matrix cores
+            d["desc"] = L.Phase1Weights(d["wfrag1"].data_ptr(), None, d["w3"].data_ptr(), None, d["wfrag2"].data_ptr(), d["wgrp"].data_ptr(), 1)
+            u["p1r"] = d
         i += 1
         i += 1
         self.add_ca(f"{pre}ca2", f"{pre}body.{i}."); i += 1
@@ -303,7 +307,12 @@ class Engine:
 
     # ---- blocks (oracle/shiftnet_oracle.py has the same names) ----------------------------------------------
     fold_se = True             # fused phase 1: CALayer2's MLP is finished by the frame's last workgroup (sn_se_fold) instead of an sn_ca_mlp launch
-    fused_phase1 = True        # Shift-Net-s deblur: sn_gsts_cab2_phase1 / sn_cab1_phase1 instead of sn_ln_gemm_gate + sn_dw5m_gemm_gate (tests switch it off for A/B)
+    # Phase 1 of CAB2 / CAB1 of the deblur models.  "r": role-split fused kernel (csrc/sn_phase1r.hip, C = 64 / 80, RepConv on the matrix cores);
+    # "v": fused kernel with the stencils on the VALU (csrc/sn_phase1.hip, C = 64 only); "0": the two-kernel chain sn_ln_gemm_gate + sn_dw5m_gemm_gate /
+    # sn_grp5_gemm_gate (g1 through HBM; what the denoisers always run).  SN_PHASE1 overrides it, e.g. for a checkpoint whose activations leave
+    # the fp16 range the fused kernels carry `a`, g1 and r in (the chain keeps g1 in bf16).
+    phase1 = os.environ.get("SN_PHASE1", "auto")
+    PHASE1_AUTO = {64: "v", 80: "r"}
     fused_cab_tail = True      # Engine32 (one kernel per reference module) runs conv, conv, pool, MLP, scale + residual instead
 
     def cab(self, pre: str, x: Act, extra: Optional[Act] = None) -> Act:
@@ -395,14 +404,19 @@ class Engine:
         u = P.units[pre]
         T, h, w, c = x.dims
         self._meta = ("naf", T, h, w, c, mode)
-        fused = "p1" in u and self.fused_phase1          # phase 1 in ONE kernel: neither a, g1 nor r leave the CU (csrc/sn_phase1.hip)
+        mode1 = self.PHASE1_AUTO.get(c, "0") if self.phase1 == "auto" else self.phase1
+        p1key = {"r": "p1r", "v": "p1"}.get(mode1)
+        if p1key == "p1" and "p1" not in u:
+            p1key = "p1r"                                # the VALU kernel exists for C = 64 depthwise only
+        fused = p1key is not None and p1key in u         # phase 1 in ONE kernel: neither a, g1 nor r leave the CU
+        layout = 1 if p1key == "p1r" else 0
         mstencil = not V.grouped_rep                     # depthwise RepConv (C = 64): Toeplitz-MFMA 5x5 on a channel-planar g1
         hwb = self._new(T, h, w, c // 2) if mode else None
         g2 = self._new(T, h, w, c)
         y = self._new(T, h, w, c)
         g1 = pool1 = ca1 = None
         if fused:
-            nb2 = lib.sn_phase1_pool_blocks(T, h, w)
+            nb2 = lib.sn_phase1_pool_blocks(T, h, w, layout)
             if nb2 < 1:
                 raise L.ShiftNetLibError(f"sn_phase1_pool_blocks failed with code {nb2}")
         else:
@@ -433,7 +447,7 @@ class Engine:
                 self._call("sn_gsts_shiftconv", "sn_gsts_shiftconv", C.byref(src), P.offs.data_ptr(), u["w1"].data_ptr(), hwb.data_ptr(), st)
             hw_ptr = hwb.data_ptr() if mode else None
             if fused:
-                wt = C.byref(u["p1"]["desc"])
+                wt = C.byref(u[p1key]["desc"])
                 sep = None
                 if self.fold_se and T <= self.MAX_TICKETS:
                     if self._tickets is None:

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libshiftnet_hip.so")
 
 SN_F32, SN_F16, SN_BF16 = 0, 1, 2
 
-ABI_VERSION = 9      # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so from before a struct / signature change fails the check in load()
+ABI_VERSION = 10     # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so from before a struct / signature change fails the check in load()
 
 SYMBOLS = [          # include/shiftnet_hip.h, production ABI
     "sn_abi_version", "sn_selftest_mfma", "sn_ingest", "sn_conv2d", "sn_conv_pool_blocks", "sn_ca_mlp",
@@ -28,8 +28,9 @@ SYMBOLS = [          # include/shiftnet_hip.h, production ABI
 
 
 class Phase1Weights(C.Structure):
-    """sn_phase1_weights (prep.pack_phase1; device pointers)."""
-    _fields_ = [("wfrag1", C.c_void_p), ("wfragx", C.c_void_p), ("w3", C.c_void_p), ("w5", C.c_void_p), ("wfrag2", C.c_void_p)]
+    """sn_phase1_weights (device pointers): layout 0 = prep.pack_phase1 (csrc/sn_phase1.hip), layout 1 = prep.pack_phase1r (csrc/sn_phase1r.hip)."""
+    _fields_ = [("wfrag1", C.c_void_p), ("wfragx", C.c_void_p), ("w3", C.c_void_p), ("w5", C.c_void_p), ("wfrag2", C.c_void_p),
+                ("wgrp", C.c_void_p), ("layout", C.c_int)]
 
 
 class SeFold(C.Structure):
@@ -118,7 +119,7 @@ def load() -> C.CDLL:
     lib.sn_lngate_blocks.argtypes = [ci, ci]
     lib.sn_grp5_gemm_gate.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.sn_grp5_blocks.argtypes = [ci, ci]
-    lib.sn_phase1_pool_blocks.argtypes = [ci, ci, ci]
+    lib.sn_phase1_pool_blocks.argtypes = [ci, ci, ci, ci]
     lib.sn_gsts_cab2_phase1.argtypes = [C.POINTER(UnitSrc), vp, C.POINTER(Phase1Weights), vp, vp, C.POINTER(SeFold), vp]
     lib.sn_cab1_phase1.argtypes = [C.POINTER(UnitSrc), C.POINTER(Phase1Weights), vp, vp, C.POINTER(SeFold), vp]
     lib.sn_gsts_cab2_phase2.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp, vp]

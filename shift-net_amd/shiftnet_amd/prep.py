@@ -314,3 +314,113 @@ def pack_conv32_split(w: torch.Tensor, groups: int = 1) -> torch.Tensor:
     hi = torch.from_numpy(wp).to(torch.bfloat16).float().numpy()
     lo = wp - hi
     return torch.stack([pack_frag(hi), pack_frag(lo)], 0).contiguous()
+
+
+# ---- role-split fused phase 1 (csrc/sn_phase1r.hip): C = 64 / 80, depthwise or grouped RepConv on the matrix cores --------------------------
+def rows_pair(c: int) -> np.ndarray:
+    """row index (into the 2C-row padded matrix, M-tile 2q + half) of output channel o in [0, 2C) for the WAVE-paired order of the
+    role-split kernel: wave q owns M-tiles (2q, 2q+1) = channels 16q .. 16q+15 and their gate partners C + 16q .., so that a wave's
+    16 gated channels are two whole RepConv groups of 8.  Row inside the tile = channel - 16q (lane group g = 4 consecutive channels)."""
+    o = np.arange(2 * c)
+    half, cc = o // c, o % c
+    return (2 * (cc // 16) + half) * 16 + cc % 16
+
+
+def p1r_ks1(c: int, with_hw: bool) -> int:
+    """k-steps of the first 1x1: K data slots + 2 bias slots (a constant-one operand, bias as bf16 hi + lo), rounded up to 32."""
+    return ((c + c // 2 if with_hw else c) + 2 + 31) // 32
+
+
+def rep_dense_group(w5: torch.Tensor, w3: torch.Tensor, c: int) -> np.ndarray:
+    """RepConv (conv_1 5x5 + conv_2 3x3 + identity; gshift_deblur1.py:157-165 grouped [C,8,5,5], gshift_deblur2.py:159-168 depthwise [C,1,5,5])
+    as per-group dense kernels [C/8 groups][8 oc][8 ic][5][5] (depthwise: diagonal)."""
+    a5 = w5.detach().float().cpu().numpy()
+    a3 = w3.detach().float().cpu().numpy()
+    ng = c // 8
+    out = np.zeros((ng, 8, 8, 5, 5), np.float32)
+    if a5.shape[1] == 8:
+        k = a5.copy()
+        k[:, :, 1:4, 1:4] += a3
+        out[:] = k.reshape(ng, 8, 8, 5, 5)
+        for o in range(8):
+            out[:, o, o, 2, 2] += 1.0
+    else:
+        assert a5.shape[1] == 1
+        k = a5[:, 0].copy()
+        k[:, 1:4, 1:4] += a3[:, 0]
+        k[:, 2, 2] += 1.0
+        k = k.reshape(ng, 8, 5, 5)
+        for o in range(8):
+            out[:, o, o] = k[:, o]
+    return out
+
+
+def p1r_tap(s: int, gq: int) -> Tuple[int, int]:
+    """(dy, dx6) of k-step s, lane group gq of the x-pair Toeplitz RepConv, or (-1, -1) for the two unused slots.  dx6 in 0..5 is the input
+    column relative to (pair's first pixel - 2): output position xp in {0, 1} of the pair sees tap dx = dx6 - xp.  Steps 0..5 hold rows
+    dy = 0..3 (lane group = dy: the four groups read the SAME columns of four ring rows, whose pitch is a multiple of the 64 LDS banks, so
+    the reads are conflict free), steps 6 / 7 row dy = 4 (lane group = dx6 resp. dx6 - 4)."""
+    if s < 6:
+        return gq, s
+    if s == 6:
+        return 4, gq
+    return (4, 4 + gq) if gq < 2 else (-1, -1)
+
+
+def pack_phase1r(w1: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, w_dw3: torch.Tensor, w_rep5: torch.Tensor, w_rep3: torch.Tensor,
+                 w2: torch.Tensor, c: int) -> Dict[str, torch.Tensor]:
+    """Operands of the role-split fused phase 1 (csrc/sn_phase1r.hip) for one CAB1 / CAB2, C in {64, 80}, RepConv grouped or depthwise.
+
+    * wfrag1 bf16 [2 NGP][KS1][64][8] (NGP = C/16 wave pairs): body[0] with the LayerNorm scale folded, rows in rows_pair order; the kernel
+      feeds the NORMALISED input (two-pass statistics by the stager waves) and a constant 1 in k-slots K, K+1, whose A columns carry the folded
+      bias W ln_b as bf16 hi + lo.  Out-of-image pixels are all-zero operands (incl. the constant), so `a` is exactly 0 there: the zero
+      padding of the 3x3.
+    * w3 uint32 [NGP q][4 g][9 taps][4]: packed-fp16 taps of RepConv2 (+identity) for the lane's four packed registers: word k = channels
+      (16q + 4g + 2k, +1) for k = 0, 1 (scaled by P1_G1_SCALE), their gate partners for k = 2, 3.
+    * wgrp fp16 [NGP q][2 G][8 s][64][8]: RepConv of group 2q + G as the x-pair Toeplitz GEMM: row m = oc + 8 xp (output channel oc of the
+      group at pixel xp of a pair), k-slot (gq, j) of step s = tap p1r_tap(s, gq), input channel j; value = w[oc][j][dy][dx6 - xp].
+    * wfrag2 fp16 [2 NGP][KS2][64][8]: body[4] / P1_G1_SCALE, rows_pair order, natural K, the sigmoid rows times -log2(e)."""
+    assert c in (64, 80)
+    ngp = c // 16
+    w = w1.detach().float().cpu().numpy().reshape(2 * c, -1)
+    kdim = w.shape[1]
+    ks1 = (kdim + 2 + 31) // 32
+    wf = w * ln_w.detach().float().cpu().numpy()[None, :]
+    b = w @ ln_b.detach().float().cpu().numpy()
+    b_hi = torch.from_numpy(b.astype(np.float32)).to(torch.bfloat16).float().numpy()
+    wp = np.zeros((32 * ngp, 32 * ks1), np.float32)
+    rp = rows_pair(c)
+    wp[rp, :kdim] = wf
+    wp[rp, kdim] = b_hi
+    wp[rp, kdim + 1] = b - b_hi
+    d3 = w_dw3.detach().float().cpu().numpy().reshape(2 * c, 9).copy()
+    d3[:, 4] += 1.0
+    d3[:c] *= P1_G1_SCALE
+    t3 = np.zeros((ngp, 4, 9, 4), np.uint32)
+    for q in range(ngp):
+        for g in range(4):
+            c0 = 16 * q + 4 * g
+            for k in range(4):
+                o = (k >> 1) * c + c0 + 2 * (k & 1)
+                t3[q, g, :, k] = _h2_words(d3[o], d3[o + 1])
+    dg = rep_dense_group(w_rep5, w_rep3, c)                   # [C/8][oc][ic][dy][dx]
+    wg = np.zeros((ngp, 2, 16, 8 * 32), np.float32)
+    for q in range(ngp):
+        for G in range(2):
+            k5 = dg[2 * q + G]
+            for s in range(8):
+                for gq in range(4):
+                    dy, dx6 = p1r_tap(s, gq)
+                    if dy < 0:
+                        continue
+                    for xp in range(2):
+                        dx = dx6 - xp
+                        if 0 <= dx <= 4:
+                            wg[q, G, 8 * xp: 8 * xp + 8, 32 * s + 8 * gq: 32 * s + 8 * gq + 8] = k5[:, :, dy, dx]
+    wgf = torch.stack([torch.stack([pack_frag_f16(wg[q, G])[0] for G in range(2)]) for q in range(ngp)])     # [NGP][2][8][64][8]
+    w2n = w2.detach().float().cpu().numpy().reshape(2 * c, c) / P1_G1_SCALE
+    w2n[c:] *= -np.log2(np.e)
+    ks2 = (c + 31) // 32
+    wp2 = np.zeros((32 * ngp, 32 * ks2), np.float32)
+    wp2[rp, :c] = w2n
+    return {"wfrag1": pack_frag(wp), "w3": torch.from_numpy(t3.view(np.int32).copy()), "wgrp": wgf.contiguous(), "wfrag2": pack_frag_f16(wp2)}

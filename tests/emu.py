@@ -399,3 +399,107 @@ def cab_phase1(x, hwb, pk, mode, wrap):
                     c0 = 16 * g + 4 * q
                     g2[t, i0 + p, c0:c0 + 4] = b1 / (1.0 + np.exp2(b2))          # the gate rows carry -log2(e)
     return g2.reshape(T, h, w, C), g2.sum(1)
+
+
+def cab_phase1r(x, hwb, pk, mode, wrap):
+    """Role-split fused phase 1 (csrc/sn_phase1r.hip) on whole frames, C = 64 / 80: the stager's two-pass LayerNorm + constant-one bias slots,
+    first 1x1 with wave-paired rows (wave q, lane group g, register r <-> channel 16 q + 4 g + r), packed-fp16 3x3 table addressed by
+    (wave, lane group, tap, word), RepConv as the x-pair Toeplitz GEMM (row = oc + 8 xp, k-slot -> tap through prep.p1r_tap), fp16 second
+    1x1.  Strips, rings and lane <-> pixel maps are index arithmetic of the kernel and not emulated; everything the HOST prepares
+    (prep.pack_phase1r) is decoded exactly as the kernel addresses it.  x [T,h,w,C], hwb [T,h,w,C/2] or None -> (g2 [T,h,w,C], sums [T,C])."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "shift-net_amd"))
+    from shiftnet_amd import prep
+    w1 = frag_to_np(pk["wfrag1"]); MT, KS = w1.shape[:2]
+    w2 = pk["wfrag2"].float().numpy(); KS2 = w2.shape[1]
+    t3 = pk["w3"].numpy().view(np.uint32)
+    wg = pk["wgrp"].float().numpy()                       # [NGP][2][8][64][8]
+    T, h, w, C = x.shape; Ch = C // 2; NGP = C // 16
+    K = C + Ch if hwb is not None else C
+    assert MT == 2 * NGP and KS == (K + 2 + 31) // 32
+    bf = lambda v: torch.tensor(v, dtype=torch.float32).to(torch.bfloat16).float().numpy()      # noqa: E731
+    xf = x.reshape(T, h * w, C)
+    hf = hwb.reshape(T, h * w, Ch) if hwb is not None else None
+    a = np.zeros((T, h * w, 2 * C), np.float32)
+    for t in range(T):
+        f0, o0, f1, o1, _, _ = unit_slabs(T, C, t, mode, wrap)
+        for i0 in range(0, h * w, 16):
+            bfrag = np.zeros((KS, 64, 8), np.float32)
+            for p in range(16):
+                i = min(i0 + p, h * w - 1)
+                u = np.concatenate([xf[f0, i, o0:o0 + Ch], xf[f1, i, o1:o1 + Ch]] + ([hf[t, i]] if hf is not None else []))
+                mean = np.float32(u.sum() / K); d = (u - mean).astype(np.float32)
+                rstd = np.float32(1.0) / np.sqrt(np.float32((d * d).sum() / K) + np.float32(1e-6))
+                kv = np.zeros(KS * 32, np.float32)
+                kv[:K] = bf(d * rstd); kv[K] = 1.0; kv[K + 1] = 1.0
+                for g in range(4):
+                    for s in range(KS):
+                        bfrag[s, g * 16 + p] = kv[s * 32 + g * 8: s * 32 + g * 8 + 8]
+            regs = mfma_tiles(w1, bfrag)
+            for lane in range(64):
+                g, p = lane >> 4, lane & 15
+                if i0 + p >= h * w:
+                    continue
+                for q in range(NGP):
+                    for half in range(2):
+                        c0 = half * C + 16 * q + 4 * g
+                        a[t, i0 + p, c0:c0 + 4] = regs[2 * q + half, lane].astype(np.float16).astype(np.float32)
+    a = a.reshape(T, h, w, 2 * C)
+    k3 = np.zeros((2 * C, 9), np.float32)
+    for q in range(NGP):
+        for g in range(4):
+            for k in range(4):
+                o = (k >> 1) * C + 16 * q + 4 * g + 2 * (k & 1)
+                lo, hi = _h2(t3[q, g, :, k])
+                k3[o] = lo; k3[o + 1] = hi
+    ap = np.zeros((T, h + 2, w + 2, 2 * C), np.float32); ap[:, 1:-1, 1:-1] = a
+    o = np.zeros_like(a)
+    for ty in range(3):
+        for tx in range(3):
+            o += k3[:, ty * 3 + tx][None, None, None, :] * ap[:, ty:ty + h, tx:tx + w]
+    o = o.astype(np.float16).astype(np.float32)
+    g1 = (o[..., :C] * o[..., C:]).astype(np.float16).astype(np.float32)          # carries P1_G1_SCALE
+    # RepConv: pairs of pixels (cx, cx + 1), cx = -3, -1, 1, ... (region column 0 is image column x0 - 3)
+    npair = (w + 3 + 1) // 2 + 1
+    gp = np.zeros((T, h + 4, 2 * npair + 8, C), np.float32)
+    X0 = 5                                                    # gp column of image column 0:  gp col = gx + X0, pair i starts at gx = 2 i - 3 -> gp col 2 i + 2
+    gp[:, 2:2 + h, X0:X0 + w] = g1
+    r = np.zeros((T, h, 2 * npair + 8, C), np.float32)
+    for grp in range(C // 8):
+        fr = wg[grp // 2, grp % 2].reshape(8, 4, 16, 8)       # [s][gq][m][j]
+        for s in range(8):
+            for gq in range(4):
+                dy, dx6 = prep.p1r_tap(s, gq)
+                if dy < 0:
+                    assert not fr[s, gq].any()
+                    continue
+                for i in range(npair):
+                    cx = 2 * i + 2                             # gp column of the pair's first pixel
+                    src = gp[:, dy:dy + h, cx + dx6 - 2, 8 * grp:8 * grp + 8]           # [T,h,8 j]
+                    contrib = np.einsum("mj,thj->thm", fr[s, gq], src)                  # [T,h,16 m]
+                    r[:, :, cx, 8 * grp:8 * grp + 8] += contrib[..., :8]
+                    r[:, :, cx + 1, 8 * grp:8 * grp + 8] += contrib[..., 8:]
+    rf = r[:, :, X0:X0 + w].astype(np.float16).astype(np.float32).reshape(T, h * w, C)
+    g2 = np.zeros((T, h * w, C), np.float32)
+    for t in range(T):
+        for i0 in range(0, h * w, 16):
+            bfrag = np.zeros((KS2, 64, 8), np.float32)
+            for lane in range(64):
+                g, p = lane >> 4, lane & 15
+                i = min(i0 + p, h * w - 1)
+                for s in range(KS2):
+                    kk0 = s * 32 + g * 8
+                    if kk0 < C:
+                        bfrag[s, lane] = rf[t, i, kk0:kk0 + 8]
+                    else:
+                        bfrag[s, lane] = 7.0                  # the kernel reads the next pixel's values there: the weights must be zero
+            regs = mfma_tiles(w2, bfrag)
+            for lane in range(64):
+                g, p = lane >> 4, lane & 15
+                if i0 + p >= h * w:
+                    continue
+                for q in range(NGP):
+                    b1, b2 = regs[2 * q, lane], regs[2 * q + 1, lane]
+                    c0 = 16 * q + 4 * g
+                    g2[t, i0 + p, c0:c0 + 4] = b1 / (1.0 + np.exp2(b2))
+    return g2.reshape(T, h, w, C), g2.sum(1)

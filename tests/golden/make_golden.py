@@ -64,9 +64,43 @@ def bf16_run(mod, name, pf, x, nm):
     return (nb(x.bfloat16(), nm.bfloat16()) if nm is not None else nb(x.bfloat16())).float()
 
 
+def quadrant_case(name="gshift_denoise1", T=6, H=96, W=128, sigma=30.0 / 255.0):
+    """G. The denoise CLI's four overlapping quadrants (inference/test_denoise.py:153-173) with a FIXED noise tensor: the reference network on
+    the four crops, stitched with the CLI's own slice arithmetic (restated here: the CLI file itself needs imageio / cv2 / skimage)."""
+    mod = load_ref(name)
+    net = mod.GShiftNet(future_frames=2, past_frames=2)
+    net.load_state_dict(synth_state_dict(name, SEED), strict=True)
+    net.eval()
+    _, sharp = synth.blurred_clip(T, H, W, seed=11)
+    noise = torch.from_numpy(synth.unit_noise((1, T, 3, H, W), seed=12)).float() * sigma
+    x = clip_tensor(sharp) + noise
+    B, N = 1, T
+    std_map = torch.FloatTensor([sigma]).view(1, 1, 1, 1, 1)
+    pad_h, pad = 32 - (H // 2 % 16), 32 - (W // 2 % 16)
+    hh, ww = H // 2 + pad_h, W // 2 + pad
+    out = torch.zeros(N - 4, 3, H, W)
+    o1 = net(x[:, :, :, 0:hh, 0:ww], std_map.expand(B, N, 1, hh, ww))
+    o2 = net(x[:, :, :, 0:hh, W // 2 - pad:], std_map.expand(B, N, 1, hh, ww))
+    o3 = net(x[:, :, :, H // 2 - pad_h:, 0:ww], std_map.expand(B, N, 1, hh, ww))
+    o4 = net(x[:, :, :, H // 2 - pad_h:, W // 2 - pad:], std_map.expand(B, N, 1, hh, ww))
+    out[..., 0:H // 2, 0:W // 2] = o1.float()[..., 0:-pad_h, 0:-pad]
+    out[..., 0:H // 2, W // 2:] = o2.float()[..., 0:-pad_h, pad:]
+    out[..., H // 2:, 0:W // 2] = o3.float()[..., pad_h:, 0:-pad]
+    out[..., H // 2:, W // 2:] = o4.float()[..., pad_h:, pad:]
+    # the stitched result must NOT equal one whole-frame forward (the quadrants see their own borders): keep that distance as a guard
+    whole = net(x, std_map.expand(B, N, 1, H, W))
+    np.savez_compressed(f"{HERE}/quadrants_{name}.npz", in_crc=np.uint32(synth.crc(sharp)), noise_crc=np.uint32(synth.crc(noise.numpy())),
+                        dims=np.array([T, H, W], np.int32), sigma=np.float32(sigma), out=out.numpy(),
+                        whole_vs_stitched_maxabs=np.float32((whole - out).abs().max().item()))
+    print("quadrants", name, tuple(out.shape), "whole-frame vs stitched max-abs", (whole - out).abs().max().item())
+
+
 def main():
     torch.set_grad_enabled(False)
     torch.manual_seed(0)
+    if "--only-quadrants" in sys.argv:
+        quadrant_case()
+        return
 
     for name, V in VARIANTS.items():
         mod = load_ref(name)
@@ -167,6 +201,7 @@ def main():
     np.savez_compressed(f"{HERE}/windows_{name}.npz", in_crc=np.uint32(synth.crc(blur)),
                         windows=np.array(win, np.int32), out=np.concatenate(outs, 0),
                         ref_bf16_psnr=np.float32(psnr(torch.from_numpy(np.concatenate(outs_b, 0)), torch.from_numpy(np.concatenate(outs, 0)))))
+    quadrant_case()
     print("all fixtures written to", HERE)
 
 

@@ -261,13 +261,14 @@ def _gsts_pieces(eng_sd, name, tag):
     check(f"unit_fwd_ragged{tag}_{name}", to_cpu(out.t, C), O.gsts_unit(sd, blk + "encoder_level1.", x2, False, V), 1.2e-2)
 
 
+@pytest.mark.parametrize("name,p1key", [("gshift_deblur2", "p1"), ("gshift_deblur2", "p1r"), ("gshift_deblur1", "p1r")])
 @pytest.mark.parametrize("T,h,w", [(3, 7, 21), (2, 5, 9), (2, 13, 70), (3, 40, 200), (2, 97, 130), (1, 64, 42), (1, 3, 40)])
-def test_cab_phase1_fused_kernel(T, h, w, engines):
-    """sn_gsts_cab2_phase1 / sn_cab1_phase1 (fused LayerNorm -> 1x1 -> dw3x3 -> gate -> dw5x5 -> 1x1 -> gate2, csrc/sn_phase1.hip) alone against the reference's
-    g2 and its channel sums, CAB1 and both CAB2 directions: maps smaller than the 6 warm-up rows / the 48-pixel region, one strip, several
-    strips with a ragged last one, several row segments."""
+def test_cab_phase1_fused_kernel(T, h, w, name, p1key, engines):
+    """sn_gsts_cab2_phase1 / sn_cab1_phase1 (fused LayerNorm -> 1x1 -> dw3x3 -> gate -> RepConv -> 1x1 -> gate2) alone against the reference's g2 and its
+    channel sums, CAB1 and both CAB2 directions -- the VALU kernel (csrc/sn_phase1.hip, "p1": C = 64) and the role-split kernel with the RepConv on
+    the matrix cores (csrc/sn_phase1r.hip, "p1r": C = 64 depthwise and C = 80 grouped, gshift_deblur1.py:157-165,183-255): maps smaller than the
+    warm-up rows / the pixel region, one strip, several strips with a ragged last one, several row segments."""
     from shiftnet_amd import lib as L
-    name = "gshift_deblur2"
     eng, sd = engines(name)
     V = O.VARIANTS[name]
     C = V.c1
@@ -280,8 +281,9 @@ def test_cab_phase1_fused_kernel(T, h, w, engines):
         a = O._conv(sd, f"{q}body.0.", v)
         a = O._conv(sd, f"{q}body.1.conv_2.", a, groups=a.shape[1]) + a
         a1, a2 = a.chunk(2, dim=1)
-        b1, b2 = O._conv(sd, f"{q}body.4.", O._rep_conv(sd, f"{q}body.3.", a1 * a2, groups=C)).chunk(2, dim=1)
+        b1, b2 = O._conv(sd, f"{q}body.4.", O._rep_conv(sd, f"{q}body.3.", a1 * a2, groups=(C // 8 if V.grouped_rep else C))).chunk(2, dim=1)
         return b1 * torch.sigmoid(b2)
+    layout = 1 if p1key == "p1r" else 0
     for mode, rev, unit in ((0, False, "encoder_level1.1."), (1, False, "encoder_level1.0."), (2, True, "encoder_level1_1.0.")):
         pre = blk + unit
         with torch.no_grad():
@@ -293,14 +295,14 @@ def test_cab_phase1_fused_kernel(T, h, w, engines):
             else:
                 ref = ref_g2(pre, O.layer_norm_2d(x, sd[pre + "norm.weight"], sd[pre + "norm.bias"]))
                 hwd = None
-        p1 = eng.P.units[pre]["p1"]
+        p1 = eng.P.units[pre][p1key]
         src = L.UnitSrc(xd.data_ptr(), T, h, w, C, mode, 1 if (V.wrap and mode) else 0)
-        nblk = eng.lib.sn_phase1_pool_blocks(T, h, w)
+        nblk = eng.lib.sn_phase1_pool_blocks(T, h, w, layout)
         assert nblk >= 1
         g2 = torch.full((T, h, w, C), float("nan"), dtype=torch.bfloat16, device=DEV)
         pool = torch.full((T, nblk, C), float("nan"), dtype=torch.float32, device=DEV)
         L.check(L.cab_phase1(eng.lib, src, hwd.data_ptr() if hwd is not None else None, p1["desc"], g2.data_ptr(), pool.data_ptr(), st), "phase 1")
-        check(f"phase1_g2_{mode}_{T}x{h}x{w}", to_cpu(g2, C), ref, 1.2e-2)
+        check(f"phase1_g2_{name}_{p1key}_{mode}_{T}x{h}x{w}", to_cpu(g2, C), ref, 1.2e-2)
         sums = pool.sum(1).cpu()
         rs = ref.sum((2, 3))
         assert torch.isfinite(sums).all() and (sums - rs).abs().max().item() <= 1e-2 * max(1.0, rs.abs().max().item())
@@ -520,23 +522,25 @@ def test_denoise_unit_is_reproducible_under_allocator_churn():
                     assert torch.equal(ref, y), (T, h, w, mode)
 
 
-def test_squeeze_excite_fold_matches_ca_mlp_and_is_reproducible(engines):
+@pytest.mark.parametrize("name,p1key", [("gshift_deblur2", "p1"), ("gshift_deblur2", "p1r"), ("gshift_deblur1", "p1r")])
+def test_squeeze_excite_fold_matches_ca_mlp_and_is_reproducible(name, p1key, engines):
     """sn_se_fold: the last workgroup of each frame of the fused phase-1 launch finishes CALayer2 (fixed-order reduction of the partial sums
     + the MLP).  Against sn_ca_mlp on the very same partial sums (another summation order: 1e-6), bit-identical over repeated launches
     whichever workgroup arrives last, counters left at zero -- at a production size (184 workgroups per frame) and a small one."""
     from shiftnet_amd import lib as L
-    eng, sd = engines("gshift_deblur2")
+    eng, sd = engines(name)
     lib, P = eng.lib, eng.P
     st = torch.cuda.current_stream().cuda_stream
-    C_ = 64
+    C_ = O.VARIANTS[name].c1
+    layout = 1 if p1key == "p1r" else 0
     for (T, h, w), reps in (((6, 360, 640), 12), ((3, 20, 44), 4)):
         x = torch.from_numpy(synth.unit_noise((T, h, w, C_), seed=7)).to(torch.bfloat16).to(DEV)
         hwb = torch.from_numpy(synth.unit_noise((T, h, w, C_ // 2), seed=8)).to(torch.bfloat16).to(DEV)
         for mode, unit in ((0, "encoder_level1.1."), (1, "encoder_level1.0.")):
             pre = "stage1.decoder_level1." + unit
-            p1, q = P.units[pre]["p1"], P.cas[pre + "ca2"]
+            p1, q = P.units[pre][p1key], P.cas[pre + "ca2"]
             src = L.UnitSrc(x.data_ptr(), T, h, w, C_, mode, 1 if mode else 0)
-            nblk = lib.sn_phase1_pool_blocks(T, h, w)
+            nblk = lib.sn_phase1_pool_blocks(T, h, w, layout)
             g2 = torch.empty((T, h, w, C_), dtype=torch.bfloat16, device=DEV)
             tickets = torch.zeros((T,), dtype=torch.int32, device=DEV)
             ref = first = None

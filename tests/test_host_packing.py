@@ -327,3 +327,42 @@ def test_split_precision_product_error_bound():
     bound = w.abs().double() @ x.abs().double()
     assert ((got - ref).abs() <= 3e-5 * bound).all()
     assert (got - ref).abs().max() > 0                                            # (it is an approximation, not an identity)
+
+
+@pytest.mark.parametrize("name,reverse", [("gshift_deblur1", False), ("gshift_deblur1", True), ("gshift_deblur2", True)])
+def test_phase1r_emulation_matches_oracle(name, reverse):
+    """prep.pack_phase1r x the conventions of the role-split fused phase-1 kernel (csrc/sn_phase1r.hip, emu.cab_phase1r: normalised operands
+    with the bias in constant-one k-slots, wave-paired rows, packed-fp16 3x3 words, RepConv -- grouped 8 -> 8 for the "+" model, depthwise
+    for Shift-Net-s -- as the x-pair Toeplitz GEMM, fp16 second 1x1) == the reference's g2 for CAB2 and CAB1 (gshift_deblur1.py:183-255)."""
+    V = O.VARIANTS[name]
+    sd = synth_state_dict(name)
+    C, T, h, w = V.c1, 2, 6, 13
+    x = torch.from_numpy(synth.unit_noise((T, C, h, w), seed=29)).bfloat16().float()
+    pre = "stage1.decoder_level1." + ("encoder_level1_1." if reverse else "encoder_level1.")
+    mode = 2 if reverse else 1
+    groups = C // 8 if V.grouped_rep else C
+
+    def ref_g2(q, v):
+        a = O._conv(sd, f"{q}body.0.", v)
+        a = O._conv(sd, f"{q}body.1.conv_2.", a, groups=a.shape[1]) + a
+        a1, a2 = a.chunk(2, dim=1)
+        g = O._rep_conv(sd, f"{q}body.3.", a1 * a2, groups=groups)
+        b1, b2 = O._conv(sd, f"{q}body.4.", g).chunk(2, dim=1)
+        return b1 * torch.sigmoid(b2)
+
+    def pk(q):
+        return prep.pack_phase1r(sd[f"{q}body.0.weight"], sd[q + "norm.weight"], sd[q + "norm.bias"], sd[f"{q}body.1.conv_2.weight"],
+                                 sd[f"{q}body.3.conv_1.weight"], sd[f"{q}body.3.conv_2.weight"], sd[f"{q}body.4.weight"], C)
+    with torch.no_grad():
+        q = pre + "0."
+        u = O.gsts_gather(x, reverse, V.wrap)
+        hw = O._conv(sd, q + "conv1.", u[:, C:], groups=C // 2)
+        ref = ref_g2(q, O.layer_norm_2d(torch.cat((u[:, :C], hw), 1), sd[q + "norm.weight"], sd[q + "norm.bias"]))
+        got, sums = emu.cab_phase1r(nhwc(x), nhwc(hw.bfloat16().float()), pk(q), mode, V.wrap)
+        err = (nchw(got, C) - ref).abs().max().item()
+        assert err < 0.02 * max(1.0, ref.abs().max().item()), ("cab2", reverse, err)
+        q = pre + "1."
+        ref = ref_g2(q, O.layer_norm_2d(x, sd[q + "norm.weight"], sd[q + "norm.bias"]))
+        got, _ = emu.cab_phase1r(nhwc(x), None, pk(q), 0, V.wrap)
+        err = (nchw(got, C) - ref).abs().max().item()
+        assert err < 0.02 * max(1.0, ref.abs().max().item()), ("cab1", err)

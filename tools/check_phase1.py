@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Fused phase-1 kernel (sn_gsts_cab2_phase1 / sn_cab1_phase1) against the oracle, with a breakdown of where any error sits (row / column / channel -> wave q,
 lane group g, register r), then its time at the level-1 and level-2 sizes of config 2 next to sn_ln_gemm_gate + sn_dw5m_gemm_gate.
-usage: check_phase1.py [--no-time]"""
+usage: check_phase1.py [--no-time] [--name gshift_deblur1|gshift_deblur2] [--key p1|p1r] [--sizes T,h,w;T,h,w]
+p1 = csrc/sn_phase1.hip (VALU stencils, C = 64), p1r = csrc/sn_phase1r.hip (role-split, RepConv on the matrix cores, C = 64 / 80)."""
 import ctypes as C
 import os
 import sys
@@ -19,7 +20,11 @@ def main():
     from shiftnet_amd.engine import Act, Engine, Plan
     from shiftnet_amd.spec import VARIANTS
     from shiftnet_amd.weights import synth_state_dict
-    name = "gshift_deblur2"
+    def arg(k, d):
+        return sys.argv[sys.argv.index(k) + 1] if k in sys.argv else d
+    name = arg("--name", "gshift_deblur2")
+    key = arg("--key", "p1" if name == "gshift_deblur2" else "p1r")
+    layout = 1 if key == "p1r" else 0
     dev = torch.device("cuda:0")
     V, OV = VARIANTS[name], O.VARIANTS[name]
     sd = synth_state_dict(name)
@@ -33,23 +38,26 @@ def main():
         a = O._conv(sd, f"{q}body.0.", v)
         a = O._conv(sd, f"{q}body.1.conv_2.", a, groups=a.shape[1]) + a
         a1, a2 = a.chunk(2, dim=1)
-        g = O._rep_conv(sd, f"{q}body.3.", a1 * a2, groups=Cc)
+        g = O._rep_conv(sd, f"{q}body.3.", a1 * a2, groups=(Cc // 8 if V.grouped_rep else Cc))
         b1, b2 = O._conv(sd, f"{q}body.4.", g).chunk(2, dim=1)
         return b1 * torch.sigmoid(b2)
 
     def run_p1(pre, xd, mode, hwb):
-        u = P.units[pre]["p1"]
+        u = P.units[pre][key]
         T, h, w, c = xd.shape
         src = L.UnitSrc(xd.data_ptr(), T, h, w, c, mode, 1 if (V.wrap and mode) else 0)
         g2 = torch.full((T, h, w, c), float("nan"), dtype=torch.bfloat16, device=dev)
-        nblk = lib.sn_phase1_pool_blocks(T, h, w)
+        nblk = lib.sn_phase1_pool_blocks(T, h, w, layout)
         pool = torch.zeros((T, nblk, c), dtype=torch.float32, device=dev)
         L.check(L.cab_phase1(lib, src, hwb.data_ptr() if hwb is not None else None, u["desc"], g2.data_ptr(), pool.data_ptr(), st), "phase 1")
         torch.cuda.synchronize()
         return g2, pool, nblk
 
     bad = 0
-    for (T, h, w) in ((3, 7, 21), (2, 5, 9), (3, 20, 44), (2, 13, 70), (3, 40, 200), (2, 97, 130), (1, 64, 42), (1, 3, 40), (2, 184, 328)):
+    sizes = ((3, 7, 21), (2, 5, 9), (3, 20, 44), (2, 13, 70), (3, 40, 200), (2, 97, 130), (1, 64, 42), (1, 3, 40), (2, 184, 328))
+    if "--sizes" in sys.argv:
+        sizes = tuple(tuple(int(v) for v in t.split(",")) for t in arg("--sizes", "").split(";"))
+    for (T, h, w) in sizes:
         x = torch.from_numpy(synth.unit_noise((T, Cc, h, w), seed=81 + h)).bfloat16().float()
         xd = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev)
         for mode, rev, unit in ((0, False, "encoder_level1.1."), (1, False, "encoder_level1.0."), (2, True, "encoder_level1_1.0.")):
@@ -81,39 +89,44 @@ def main():
                 print("   bad fraction per row   :", " ".join(f"{(em[:, :, y] > thr).float().mean().item():.2f}" for y in range(min(h, 24))))
                 print("   bad fraction per column:", " ".join(f"{(em[:, :, :, xx] > thr).float().mean().item():.2f}" for xx in range(min(w, 64))))
                 pc = (em > thr).float().mean((0, 2, 3))
-                print("   bad fraction per channel (c = 16 g + 4 q + r):", " ".join(f"{v:.2f}" for v in pc.tolist()))
+                print("   bad fraction per channel:", " ".join(f"{v:.2f}" for v in pc.tolist()))
     print("PHASE1", "ALL OK" if bad == 0 else f"{bad} BAD CASES")
     if "--no-time" in sys.argv:
         return
-    for (T, h, w) in ((20, 360, 640), (20, 180, 320)):
+    tsizes = ((20, 360, 640), (20, 180, 320)) if Cc == 64 else ((52, 360, 640), (52, 180, 320), (16, 540, 960))
+    for (T, h, w) in tsizes:
         xd = torch.randn(T, h, w, Cc, device=dev).to(torch.bfloat16)
         hwb = torch.randn(T, h, w, Cc // 2, device=dev).to(torch.bfloat16)
         for mode, unit in ((0, "encoder_level1.1."), (1, "encoder_level1.0.")):
             pre = blk + unit
             u = P.units[pre]
-            src = L.UnitSrc(xd.data_ptr(), T, h, w, Cc, mode, 1 if mode else 0)
+            src = L.UnitSrc(xd.data_ptr(), T, h, w, Cc, mode, 1 if (mode and V.wrap) else 0)
             g2 = torch.empty((T, h, w, Cc), dtype=torch.bfloat16, device=dev)
-            nblk = lib.sn_phase1_pool_blocks(T, h, w)
-            pool = torch.zeros((T, nblk, Cc), dtype=torch.float32, device=dev)
-            p1 = u["p1"]
-            g1 = torch.empty((T, h, Cc, lib.sn_planar_pitch(w)), dtype=torch.bfloat16, device=dev)
-            pool2 = torch.empty((T, lib.sn_dw5m_blocks(h, w), Cc), dtype=torch.float32, device=dev)
             hp = hwb.data_ptr() if mode else None
-            calls = {
-                "phase1 fused": lambda: L.cab_phase1(lib, src, hp, p1["desc"], g2.data_ptr(), pool.data_ptr(), st),
-                "K12": lambda: lib.sn_ln_gemm_gate(C.byref(src), hp, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(), u["w_dw3_h2"].data_ptr(), g1.data_ptr(), None, 2, st),
-                "K3m": lambda: lib.sn_dw5m_gemm_gate(g1.data_ptr(), None, u["w_toep5"].data_ptr(), u["w_gate"].data_ptr(), g2.data_ptr(), pool2.data_ptr(), T, h, w, Cc, st),
-            }
+            mst = not V.grouped_rep
+            g1 = (torch.empty((T, h, Cc, lib.sn_planar_pitch(w)), dtype=torch.bfloat16, device=dev) if mst else torch.empty((T, h, w, Cc), dtype=torch.bfloat16, device=dev))
+            pool2 = torch.empty((T, lib.sn_dw5m_blocks(h, w) if mst else lib.sn_grp5_blocks(h, w), Cc), dtype=torch.float32, device=dev)
+            k3 = lib.sn_dw5m_gemm_gate if mst else lib.sn_grp5_gemm_gate
+            calls = {}
+            pools = {}
+            for kk in ("p1", "p1r"):
+                if kk in u:
+                    lay = 1 if kk == "p1r" else 0
+                    nb = lib.sn_phase1_pool_blocks(T, h, w, lay)
+                    pools[kk] = torch.zeros((T, nb, Cc), dtype=torch.float32, device=dev)
+                    calls[f"phase1 fused {kk}"] = (lambda kk=kk: L.cab_phase1(lib, src, hp, u[kk]["desc"], g2.data_ptr(), pools[kk].data_ptr(), st))
+            calls["K12"] = lambda: lib.sn_ln_gemm_gate(C.byref(src), hp, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(), u["w_dw3_h2"].data_ptr(), g1.data_ptr(), None, 2 if mst else 0, st)
+            calls["K3"] = lambda: k3(g1.data_ptr(), None, u["w_toep5" if mst else "w_grp"].data_ptr(), u["w_gate"].data_ptr(), g2.data_ptr(), pool2.data_ptr(), T, h, w, Cc, st)
             for k, f in calls.items():
                 for _ in range(2):
                     L.check(f(), k)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for _ in range(8):
+                for _ in range(6):
                     f()
                 e1.record(); torch.cuda.synchronize()
-                print(f"TIME {T}x{h}x{w} mode {mode} {k:14s} {e0.elapsed_time(e1) / 8 * 1e3:8.1f} us (blocks {nblk})", flush=True)
+                print(f"TIME {name} {T}x{h}x{w} mode {mode} {k:18s} {e0.elapsed_time(e1) / 6 * 1e3:8.1f} us", flush=True)
 
 
 if __name__ == "__main__":
