@@ -37,6 +37,7 @@
 // in the second 1x1's weights), RepConv and the second 1x1 accumulate in fp32 on the matrix cores (the VALU kernel accumulated 25 taps in fp16).
 #include "sn_common.h"
 #include "../../include/shiftnet_hip.h"
+#include <type_traits>
 
 namespace {
 
@@ -67,11 +68,48 @@ __device__ __forceinline__ uint32_t lane_next(uint32_t v) { return (uint32_t)__b
 #define P1R_LDS_PAD 0
 #endif
 // how many LDS fragment reads the MFMA loops keep in flight ahead of their consumers (A: first 1x1, B: RepConv, B2: second 1x1)
+// measurement builds only (tools/p1r_variants.py): switch off parts of the roles (results are wrong) to see which one paces the step
+//   1: stagers skip the LayerNorm / LDS staging   2: stagers skip the global loads   4: stagers skip the g2 stores
+//   8: A waves idle   16: B waves skip the second 1x1   32: B waves skip the RepConv
+#ifndef P1R_SKIP
+#define P1R_SKIP 0
+#endif
 #ifndef P1R_DA
-#define P1R_DA 6
+#define P1R_DA 4
+#endif
+// measurement builds only: P1R_TIMING = 1 -> every wave accumulates the cycles between the start of a step and its arrival at the step's barrier
+// (s_memtime) and writes (work, total) to pool[(t, blk)][2 wave, 2 wave + 1] instead of the channel sums
+#ifndef P1R_TIMING
+#define P1R_TIMING 0
+#endif
+#if P1R_TIMING
+#define P1R_T0() const unsigned long long tq0_ = __builtin_amdgcn_s_memtime()
+#define P1R_T1() twork_ += __builtin_amdgcn_s_memtime() - tq0_
+#else
+#define P1R_T0()
+#define P1R_T1()
+#endif
+// Issue priority of the three roles (s_setprio, 0..3).  The SIMD's arbiter prefers the OLDEST wave, i.e. the A and B waves of a workgroup; the
+// stagers, launched last and with the longest instruction stream, would run after them and alone (measured with s_memtime: A done after 1850,
+// B after 2700 - 3000, S after 4600 of a step's 4800 cycles).  With the longest stream on top, the others fill its stalls: 2.34 / 2.30 -> 2.04 / 2.25 ms
+// (C = 80, CAB1 / CAB2, 52 x 360 x 640), 0.69 / 0.75 -> 0.56 / 0.70 ms (C = 64, 20 x 360 x 640); S2 B1 A0 measured against 300, 311, 312, 231.
+#ifndef P1R_PRIO_S
+#define P1R_PRIO_S 2
+#endif
+#ifndef P1R_PRIO_B
+#define P1R_PRIO_B 1
+#endif
+#ifndef P1R_PRIO_A
+#define P1R_PRIO_A 0
+#endif
+#ifndef P1R_AV           // VALU instructions (the 3x3 of the first M-tile pass) scheduled behind every MFMA of the second pass of an A wave (0: the compiler's order)
+#define P1R_AV 0
+#endif
+#ifndef P1R_BV           // VALU instructions (SimpleGate2 of the second 1x1) scheduled behind every RepConv MFMA of a B wave (0: the compiler's order)
+#define P1R_BV 0
 #endif
 #ifndef P1R_DB
-#define P1R_DB 8
+#define P1R_DB 6
 #endif
 #ifndef P1R_DB2
 #define P1R_DB2 6
@@ -83,7 +121,9 @@ template <int C, bool HW> struct P1RShape {
     static constexpr int CH = C / 2, K = HW ? C + CH : C, KS1 = (K + 2 + 31) / 32, KS2 = (C + 31) / 32;
     static constexpr int NX = 4, RWD = 16 * NX, HALO = 3, VWMAX = RWD - 2 * HALO;
     static constexpr int PSX = KS1 * 64 + 32;                 // bytes per pixel of a staged row: 4 KS1 + 2 slots of 16 B (2 mod 4)
-    static constexpr int XSLOT = RWD * PSX;
+    static constexpr int XPL = 16 * PSX + 32;                 // bytes per N-tile plane of a staged row: + 32 so that the stagers' ds_write_b128 lane groups (4 pixels
+                                                              // = 4 planes x 2 interleaved pieces) cover all 32 banks; the readers' plane term is an immediate
+    static constexpr int XSLOT = NX * XPL;
     static constexpr int GPL = 18 * 16;                       // bytes per g1 plane: 16 columns + one pad column on each side, 16 B each
     static constexpr int GROW = NGP * 2 * 4 * GPL;            // bytes per g1 ring row: [wave][group][column mod 4][18]; 11520 / 9216: multiples of 256
     static constexpr int GRING = 6;
@@ -103,7 +143,7 @@ template <int C, bool HW>
 __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(const P1RArgs A) {
     using SH = P1RShape<C, HW>;
     constexpr int NGP = SH::NGP, NTHR = SH::NTHR, CH = SH::CH, K = SH::K, KS1 = SH::KS1, KS2 = SH::KS2, NX = SH::NX;
-    constexpr int PSX = SH::PSX, XSLOT = SH::XSLOT, GPL = SH::GPL, GROW = SH::GROW, PSR = SH::PSR, RSLOT = SH::RSLOT, PSO = SH::PSO, OSLOT = SH::OSLOT;
+    constexpr int PSX = SH::PSX, XPL = SH::XPL, XSLOT = SH::XSLOT, GPL = SH::GPL, GROW = SH::GROW, PSR = SH::PSR, RSLOT = SH::RSLOT, PSO = SH::PSO, OSLOT = SH::OSLOT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const lds_x = smem + SH::OFF_X;
     char* const lds_g = smem + SH::OFF_G;
@@ -124,29 +164,35 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
     else if (wv - 8 < 2 * (NGP - 4)) { role = (wv - 8) & 1; q = 4 + ((wv - 8) >> 1); }
     else { role = 2; q = wv - 8 - 2 * (NGP - 4); }
 
+#if P1R_TIMING
+    unsigned long long twork_ = 0;
+    const unsigned long long tbegin_ = __builtin_amdgcn_s_memtime();
+#endif
     // ---- zero all LDS once: ring pads, unused k-slots and the rows B reads before A has produced them must be finite ----
     for (int e = tid; e < SH::LDS / 16; e += NTHR) ((uint4*)smem)[e] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
 
     if (role == 2) {
         // =================================================== S: stagers ===================================================
+        __builtin_amdgcn_s_setprio(P1R_PRIO_S);
         const int stid = q * 64 + lane, spx = stid >> 1, half = stid & 1;     // two lanes per region pixel
         constexpr int NPC = K / 8, NP0 = (NPC + 1) / 2;                      // 16-byte pieces of a pixel's K channels; pieces per lane
+        // lane `half` of a pixel moves pieces half, half + 2, half + 4, ...: the two lanes' 16-byte stores are neighbours, and with the padded
+        // plane stride the 8 lanes of a ds_write_b128 lane group hit 8 distinct 16-byte bank groups (a [half][piece] split put all 8 on one: 48 %
+        // of all LDS cycles of the first version were bank conflicts of these stores)
         const SnSlabs<bf16_t> sl = sn_unit_slabs<bf16_t>(A.x, A.halo, A.T, hw, C, A.mode, A.wrap, t);
         const bf16_t* sp[NP0];
         int sst[NP0];
-        bool sval[NP0];
 #pragma unroll
         for (int i = 0; i < NP0; ++i) {
-            const int pi = half * NP0 + i;
-            sval[i] = pi < NPC;
-            const int pc = sval[i] ? pi : 0;
+            const int pi = 2 * i + half, pc = pi < NPC ? pi : 0;              // (only the last piece of an odd count can be missing)
             if (pc < CH / 8) { sp[i] = sl.p0 + 8 * pc; sst[i] = sl.s0; }
             else if (pc < C / 8) { sp[i] = sl.p1 + 8 * (pc - CH / 8); sst[i] = sl.s1; }
             else { sp[i] = A.hwb + (size_t)t * hw * CH + 8 * (pc - C / 8); sst[i] = CH; }
         }
+        const bool lastv = 2 * (NP0 - 1) + half < NPC;
         const int sgx = x0 - SH::HALO + spx, sgxc = (sgx >= 0 && sgx < w) ? sgx : 0;
-        const int xoff = ((spx & 3) * 16 + (spx >> 2)) * PSX + half * NP0 * 16;
+        const int xpix = (spx & 3) * XPL + (spx >> 2) * PSX;
         uint4 XA[NP0], XB[NP0];
         auto issue_row = [&](int y, uint4* X) {
             const int yc = (y >= 0 && y < h) ? y : 0;
@@ -156,53 +202,62 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
         };
         auto stage_row = [&](int slot, const uint4* X, int y) {
             const bool inimg = y >= 0 && y < h && sgx >= 0 && sgx < w;
-            float s1 = 0.f;
+            float s1[2] = {0.f, 0.f};                                         // two partial sums: half as long dependency chains
             uint32_t wd[NP0][4];
 #pragma unroll
             for (int i = 0; i < NP0; ++i) {
-                wd[i][0] = sval[i] ? X[i].x : 0u; wd[i][1] = sval[i] ? X[i].y : 0u; wd[i][2] = sval[i] ? X[i].z : 0u; wd[i][3] = sval[i] ? X[i].w : 0u;
+                const bool v = i + 1 < NP0 || lastv;
+                wd[i][0] = v ? X[i].x : 0u; wd[i][1] = v ? X[i].y : 0u; wd[i][2] = v ? X[i].z : 0u; wd[i][3] = v ? X[i].w : 0u;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) s1 = dot2bf(wd[i][k], 0x3f803f80u, s1);
+                for (int k = 0; k < 4; ++k) s1[k & 1] = dot2bf(wd[i][k], 0x3f803f80u, s1[k & 1]);
             }
-            s1 += dpp_mov<0xB1>(s1);                                          // the pixel's other lane (quad_perm [1,0,3,2])
-            const float mean = s1 * (1.0f / K);
+            float sm = s1[0] + s1[1];
+            sm += dpp_mov<0xB1>(sm);                                          // the pixel's other lane (quad_perm [1,0,3,2])
+            const float mean = sm * (1.0f / K);
             const f32x2_t mean2 = {mean, mean};
             f32x2_t d[NP0][4];
-            f32x2_t sq2 = {0.f, 0.f};
+            f32x2_t sq2[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
             for (int i = 0; i < NP0; ++i)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const f32x2_t v = {bf_lo(wd[i][k]), bf_hi(wd[i][k])};
-                    d[i][k] = sval[i] ? v - mean2 : (f32x2_t){0.f, 0.f};
-                    sq2 = __builtin_elementwise_fma(d[i][k], d[i][k], sq2);
+                    d[i][k] = (i + 1 < NP0 || lastv) ? v - mean2 : (f32x2_t){0.f, 0.f};
+                    sq2[k & 1] = __builtin_elementwise_fma(d[i][k], d[i][k], sq2[k & 1]);
                 }
-            float sq = sq2[0] + sq2[1];
+            float sq = (sq2[0][0] + sq2[0][1]) + (sq2[1][0] + sq2[1][1]);
             sq += dpp_mov<0xB1>(sq);
             const float rstd = inimg ? __builtin_amdgcn_rsqf(sq * (1.0f / K) + 1e-6f) : 0.f;      // 0: an all-zero operand outside the image
             const f32x2_t rstd2 = {rstd, rstd};
-            char* xs = lds_x + slot * XSLOT + xoff;
+            char* xs = lds_x + slot * XSLOT + xpix + half * 16;
 #pragma unroll
             for (int i = 0; i < NP0; ++i) {
                 uint4 o;
                 f32x2_t e0 = d[i][0] * rstd2, e1 = d[i][1] * rstd2, e2 = d[i][2] * rstd2, e3 = d[i][3] * rstd2;
                 o.x = pack_bf2(e0[0], e0[1]); o.y = pack_bf2(e1[0], e1[1]); o.z = pack_bf2(e2[0], e2[1]); o.w = pack_bf2(e3[0], e3[1]);
-                if (sval[i]) *(uint4*)(xs + i * 16) = o;
+                if (i + 1 < NP0 || lastv) *(uint4*)(xs + i * 32) = o;
             }
             // the constant-one slots K, K + 1 (the bias columns of the weights); the rest of that piece stays zero
-            if (half) *(uint32_t*)(lds_x + slot * XSLOT + ((spx & 3) * 16 + (spx >> 2)) * PSX + K * 2) = inimg ? 0x3f803f80u : 0u;
+            if (half) *(uint32_t*)(lds_x + slot * XSLOT + xpix + K * 2) = inimg ? 0x3f803f80u : 0u;
         };
+        // g2 rows leave as whole pixels: item e = (own pixel, 16-byte piece), fixed per lane for the whole walk
+        constexpr int NPO = C / 8, NIT = (SH::VWMAX * NPO + 127) / 128;
+        int so_l[NIT], so_g[NIT];                                             // LDS byte offset inside an out slot / element offset inside a g2 row; -1: no item
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int e = stid + 128 * k, px = e / NPO, pc = e - px * NPO, rc = SH::HALO + px, gx = x0 + px;
+            so_l[k] = ((rc & 3) * 16 + (rc >> 2)) * PSO + pc * 16;
+            so_g[k] = (px < A.vw && gx < w) ? gx * C + pc * 8 : -1;
+            if (so_g[k] < 0) so_l[k] = 0;
+        }
         auto store_row = [&](int j) {                                         // g2 row Y0 - 9 + j, written to out slot (j - 1) & 1 by the B waves in step j - 1
             const int yo = Y0 - 9 + j;
             const char* os = lds_o + ((j - 1) & 1) * OSLOT;
             bf16_t* const g2row = A.g2 + ((size_t)t * h + yo) * w * C;
-            constexpr int NPO = C / 8, NIT = (SH::VWMAX * NPO + 127) / 128;
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
-                const int e = stid + 128 * k, px = e / NPO, pc = e - px * NPO, rc = SH::HALO + px, gx = x0 + px;
-                const bool ok = px < A.vw && gx < w;
-                const uint4 v = *(const uint4*)(os + ((rc & 3) * 16 + (rc >> 2)) * PSO + pc * 16);
-                if (ok) *(uint4*)(g2row + (gx * C + pc * 8)) = v;
+                const uint4 v = *(const uint4*)(os + so_l[k]);
+                if (so_g[k] >= 0) *(uint4*)(g2row + so_g[k]) = v;
             }
         };
         issue_row(Y0 - 3, XA);
@@ -215,10 +270,12 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
         //  counts assume the path with the fewest younger operations, and a path without the refill degrades every wait to "everything landed".)
         const int ylast = Y1 + 2;
         auto step = [&](const int j, uint4* X) {
-            if (j <= seg + 4) stage_row((j + 1) & 1, X, Y0 - 2 + j);
-            issue_row(Y0 + j < ylast ? Y0 + j : ylast, X);
+            P1R_T0();
+            if (!(P1R_SKIP & 1) && j <= seg + 4) stage_row((j + 1) & 1, X, Y0 - 2 + j);
+            if (!(P1R_SKIP & 2)) issue_row(Y0 + j < ylast ? Y0 + j : ylast, X);
             __builtin_amdgcn_sched_barrier(0);                                // the loads stay in front of the stores (vmcnt retires in order)
-            if (j >= 9 && j <= seg + 8) store_row(j);                        // (NS may contain one padding step)
+            if (!(P1R_SKIP & 4) && j >= 9 && j <= seg + 8) store_row(j);                        // (NS may contain one padding step)
+            P1R_T1();
             __syncthreads();
         };
 #pragma unroll 1
@@ -228,6 +285,7 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
         }
     } else if (role == 0) {
         // =================================================== A: first 1x1, 3x3, gate ===================================================
+        __builtin_amdgcn_s_setprio(P1R_PRIO_A);
         bf16x8_t W1[2][KS1];
 #pragma unroll
         for (int s = 0; s < KS1; ++s) {
@@ -249,45 +307,27 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
         for (int n = 0; n < NX; ++n)
 #pragma unroll
             for (int k = 0; k < 4; ++k) { P0[n][k] = hz; P1[n][k] = hz; }
-        const int xrd = p * PSX + g * 16;                                     // + slot, + n * 16 PSX + 64 s (immediates)
+        const int xrd = p * PSX + g * 16;                                     // + slot, + n * XPL + 64 s (immediates)
         const int gwr = ((2 * q + (g >> 1)) * 4) * GPL + (p + 1) * 16 + (g & 1) * 8;      // + ring row, + n * GPL
         __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the weights have landed (no conservative waits inside the loop)
         __syncthreads();
         int gslot = 0;                                                        // j mod 6
 #pragma unroll 1
         for (int j = 0; j < NS; ++j) {
-            if (j <= seg + 5) {
+            P1R_T0();
+            if (!(P1R_SKIP & 8) && j <= seg + 5) {
                 const int yin = Y0 - 3 + j;
                 const char* xs = lds_x + (j & 1) * XSLOT + xrd;
+                // Two passes, one per M-tile of the wave's pair: pass m gives packed registers 2m, 2m + 1 of all four N-tiles, and their
+                // 3x3 (VALU) runs while the matrix core works on pass m + 1 (the stencil of register k needs register k of ALL tiles, so tile
+                // order would serialise MFMA phase and VALU phase: 544 + 823 cycles per step and wave in the first version).  Per pass the
+                // four N-tiles are four independent accumulator chains; fragments are read P1R_DA items ahead of their MFMA.
                 uint32_t ah[NX][4];
-                {
-                    // B fragments are read P1R_DA items AHEAD of the MFMAs that consume them (item = (tile n, k-step s), two MFMAs each): left to
-                    // itself the compiler issues every ds_read right in front of its MFMA and the wave waits out one LDS latency per fragment
-                    constexpr int NI = NX * KS1, DA = P1R_DA < NI ? P1R_DA : NI;
-                    uint4 bq[NI];
-#pragma unroll
-                    for (int i = 0; i < DA; ++i) bq[i] = *(const uint4*)(xs + (i / KS1) * 16 * PSX + 64 * (i % KS1));
-                    __builtin_amdgcn_sched_group_barrier(0x100, DA, 0);
-                    f32x4_t acc[NX][2];
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) {
-                        const int n = i / KS1, s_ = i % KS1;
-                        if (i + DA < NI) bq[i + DA] = *(const uint4*)(xs + ((i + DA) / KS1) * 16 * PSX + 64 * ((i + DA) % KS1));
-                        if (s_ == 0) { acc[n][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[n][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
-                        acc[n][0] = mfma16(W1[0][s_], as_frag(bq[i]), acc[n][0]); acc[n][1] = mfma16(W1[1][s_], as_frag(bq[i]), acc[n][1]);
-                        if (i + DA < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    }
-#pragma unroll
-                    for (int n = 0; n < NX; ++n) {
-                        ah[n][0] = cvt_pk_h2(acc[n][0][0], acc[n][0][1]); ah[n][1] = cvt_pk_h2(acc[n][0][2], acc[n][0][3]);
-                        ah[n][2] = cvt_pk_h2(acc[n][1][0], acc[n][1][1]); ah[n][3] = cvt_pk_h2(acc[n][1][2], acc[n][1][3]);
-                    }
-                }
-                // depthwise 3x3 (+identity), scatter form: input row yin completes output row yin - 1, feeds row yin, opens row yin + 1
                 h2_t F[NX][4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                constexpr int NI = NX * KS1, DA = P1R_DA < NI ? P1R_DA : NI;
+                auto rdx = [&](const int i) -> uint4 { return *(const uint4*)(xs + (i % NX) * XPL + 64 * (i / NX)); };      // item i = (k-step i / NX, tile i % NX)
+                auto stencil = [&](const int k) {
+                    // depthwise 3x3 (+identity), scatter form: input row yin completes output row yin - 1, feeds row yin, opens row yin + 1
                     const uint32_t Lw = lane_prev(ah[NX - 1][k]), Rw = lane_next(ah[0][k]);      // the two operands that cross the lane boundary
 #pragma unroll
                     for (int ti = 0; ti < 3; ++ti) {                          // ty = 2 first: it reads P1 before ty = 1 overwrites it (from P0), then ty = 0 reopens P0
@@ -303,6 +343,28 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
                                 else P0[n][k] = tx == 0 ? v * wk : __builtin_elementwise_fma(v, wk, P0[n][k]);
                             }
                     }
+                };
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    uint4 bq[NI];
+#pragma unroll
+                    for (int i = 0; i < DA; ++i) bq[i] = rdx(i);
+                    __builtin_amdgcn_sched_group_barrier(0x100, DA, 0);
+                    f32x4_t acc[NX];
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        const int n = i % NX, s_ = i / NX;
+                        if (i + DA < NI) bq[i + DA] = rdx(i + DA);
+                        if (s_ == 0) acc[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                        acc[n] = mfma16(W1[m][s_], as_frag(bq[i]), acc[n]);
+                        if (i + DA < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (m == 1 && P1R_AV) __builtin_amdgcn_sched_group_barrier(0x002, P1R_AV, 0);       // pass 0's stencil between pass 1's MFMAs
+                    }
+#pragma unroll
+                    for (int n = 0; n < NX; ++n) { ah[n][2 * m] = cvt_pk_h2(acc[n][0], acc[n][1]); ah[n][2 * m + 1] = cvt_pk_h2(acc[n][2], acc[n][3]); }
+                    stencil(2 * m);
+                    stencil(2 * m + 1);
                 }
                 // SimpleGate -> g1 row yin - 1 (zero outside the image: the zero padding of the RepConv) -> ring row j mod 6
                 const bool rin = (yin - 1) >= 0 && (yin - 1) < h;
@@ -314,10 +376,12 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
                 }
             }
             gslot = gslot == SH::GRING - 1 ? 0 : gslot + 1;
+            P1R_T1();
             __syncthreads();
         }
     } else {
         // =================================================== B: RepConv, second 1x1, gate2 ===================================================
+        __builtin_amdgcn_s_setprio(P1R_PRIO_B);
         uint4 Wg[2][8];
 #pragma unroll
         for (int G = 0; G < 2; ++G)
@@ -357,47 +421,50 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
         int jm = 1;                                                           // (j - 5) mod 6
 #pragma unroll 1
         for (int j = 0; j < NS; ++j) {
-            // ---- second 1x1 + SimpleGate2 on the r row of the previous step: g2 row Y0 - 8 + j -> out slot j & 1 ----
-            if (j >= 8 && j <= seg + 7) {
-                const char* rs = lds_r + ((j - 1) & 1) * RSLOT + rrd;
-                char* os = lds_o + (j & 1) * OSLOT + owr;
-                constexpr int NI = NX * KS2, DB = P1R_DB2 < NI ? P1R_DB2 : NI;      // item = (tile n, k-step s): one fragment, two MFMAs
+            P1R_T0();
+            // Per step: (1) second 1x1 + SimpleGate2 on the r row of the PREVIOUS step (g2 row Y0 - 8 + j -> out slot j & 1), (2) RepConv: r row
+            // Y0 - 7 + j from g1 ring rows (j - 5 + dy) mod 6 -> r slot j & 1.  In the steady state both run in ONE basic block, the 1x1 in tile
+            // pairs, so that the exp / rcp / pack work of a pair is scheduled between the MFMAs that follow it (next pair, RepConv).
+            const bool do1 = !(P1R_SKIP & 16) && j >= 8 && j <= seg + 7, do2 = !(P1R_SKIP & 32) && j >= 7 && j <= seg + 6;
+            const char* rs1 = lds_r + ((j - 1) & 1) * RSLOT + rrd;
+            char* os = lds_o + (j & 1) * OSLOT + owr;
+            int r6 = jm + g;
+            r6 = r6 >= SH::GRING ? r6 - SH::GRING : r6;
+            const char* gb = lds_g + r6 * GROW + gq0;                         // steps 0..5: this lane group's ring row
+            const int r4 = jm + 4 >= SH::GRING ? jm + 4 - SH::GRING : jm + 4;
+            const char* g4 = lds_g + r4 * GROW;                               // steps 6, 7: ring row of dy = 4
+            char* rs2 = lds_r + (j & 1) * RSLOT + rwr;
+            auto gemm2 = [&](const int n0) {                                  // tiles n0, n0 + 1: item i = (k-step i / 2, tile n0 + i % 2), two MFMAs each: four chains
+                constexpr int NI = 2 * KS2;
                 uint4 bq[NI];
 #pragma unroll
-                for (int i = 0; i < DB; ++i) bq[i] = *(const uint4*)(rs + (i / KS2) * 16 * PSR + 64 * (i % KS2));
-                __builtin_amdgcn_sched_group_barrier(0x100, DB, 0);
-                f32x4_t c[NX][2];
+                for (int i = 0; i < NI; ++i) bq[i] = *(const uint4*)(rs1 + (n0 + (i & 1)) * 16 * PSR + 64 * (i >> 1));
+                __builtin_amdgcn_sched_group_barrier(0x100, NI, 0);
+                f32x4_t c[2][2];
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
-                    const int n = i / KS2, s_ = i % KS2;
-                    if (i + DB < NI) bq[i + DB] = *(const uint4*)(rs + ((i + DB) / KS2) * 16 * PSR + 64 * ((i + DB) % KS2));
+                    const int n = i & 1, s_ = i >> 1;
                     if (s_ == 0) { c[n][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; c[n][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
                     c[n][0] = mfma16h(W2[0][s_], bq[i], c[n][0]); c[n][1] = mfma16h(W2[1][s_], bq[i], c[n][1]);
-                    if (i + DB < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 }
 #pragma unroll
-                for (int n = 0; n < NX; ++n) {
+                for (int n = 0; n < 2; ++n) {
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {                             // b1 * sigmoid(b2); the gate rows carry -log2(e) (prep.pack_phase1r)
                         v[r] = c[n][0][r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(c[n][1][r]));
-                        psum[r] = fmaf(v[r], own[n], psum[r]);
+                        psum[r] = fmaf(v[r], own[n0 + n], psum[r]);
                     }
-                    *(uint2*)(os + n * 16 * PSO) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    *(uint2*)(os + (n0 + n) * 16 * PSO) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                 }
-            }
-            // ---- RepConv: r row Y0 - 7 + j from g1 ring rows (j - 5 + dy) mod 6 -> r slot j & 1 ----
-            if (j >= 7 && j <= seg + 6) {
-                int r6 = jm + g;
-                r6 = r6 >= SH::GRING ? r6 - SH::GRING : r6;
-                const char* gb = lds_g + r6 * GROW + gq0;                     // steps 0..5: this lane group's ring row
-                const int r4 = jm + 4 >= SH::GRING ? jm + 4 - SH::GRING : jm + 4;
-                const char* g4 = lds_g + r4 * GROW;                           // steps 6, 7: ring row of dy = 4
-                char* rs = lds_r + (j & 1) * RSLOT + rwr;
-                // item i = (G, s, u): one fragment, one MFMA; fragments are read P1R_DB items ahead (see the A waves)
+            };
+            auto repconv = [&](auto nv) {
+                constexpr int nvalu = decltype(nv)::value;
+                // item i = (k-step i / 4, group (i / 2) % 2, pair-tile i % 2): one fragment, one MFMA, four accumulator chains in turn;
+                // fragments are read P1R_DB items ahead (see the A waves)
                 auto rd = [&](const int i) -> uint4 {
-                    const int G = i >> 4, s_ = (i >> 1) & 7, u = i & 1;
+                    const int s_ = i >> 2, G = (i >> 1) & 1, u = i & 1;
                     if (s_ < 6) {
                         const int e = 2 * u + s_ - 2 + 4;
                         return *(const uint4*)(gb + (G * 4 + (e & 3)) * GPL + (e >> 2) * 16);
@@ -412,21 +479,26 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
                 f32x4_t acc[2][2];
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
-                    const int G = i >> 4, s_ = (i >> 1) & 7, u = i & 1;
+                    const int s_ = i >> 2, G = (i >> 1) & 1, u = i & 1;
                     if (i + DB < NI) bq[i + DB] = rd(i + DB);
                     if (s_ == 0) acc[G][u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
                     acc[G][u] = mfma16h(Wg[G][s_], bq[i], acc[G][u]);
                     if (i + DB < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if constexpr (nvalu > 0) __builtin_amdgcn_sched_group_barrier(0x002, nvalu, 0);
                 }
 #pragma unroll
                 for (int G = 0; G < 2; ++G)
 #pragma unroll
                     for (int u = 0; u < 2; ++u)                               // D row 4g + r = (oc = 4 (g & 1) + r, xp = g >> 1): pixel 4p + 2u + xp = N-tile 2u + xp
-                        *(uint2*)(rs + (2 * u + (g >> 1)) * 16 * PSR + 16 * G) =
+                        *(uint2*)(rs2 + (2 * u + (g >> 1)) * 16 * PSR + 16 * G) =
                             make_uint2(cvt_pk_h2(acc[G][u][0], acc[G][u][1]), cvt_pk_h2(acc[G][u][2], acc[G][u][3]));
-            }
+            };
+            if (do1 && do2) { gemm2(0); gemm2(2); repconv(std::integral_constant<int, P1R_BV>{}); }
+            else if (do1) { gemm2(0); gemm2(2); }
+            else if (do2) repconv(std::integral_constant<int, 0>{});
             jm = jm == SH::GRING - 1 ? 0 : jm + 1;
+            P1R_T1();
             __syncthreads();
         }
         // channel sums of this (frame, strip, segment) for CALayer2: lane group g owns channels 16 q + 4 g + r
@@ -439,6 +511,16 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
             }
         }
     }
+#if P1R_TIMING
+    if (A.pool && lane == 0) {
+        const int nblk = A.nsx * A.nsy, blk = sy * A.nsx + sx;
+        float* o = A.pool + ((size_t)t * nblk + blk) * C;
+        __syncthreads();
+        o[2 * wv] = (float)twork_; o[2 * wv + 1] = (float)(__builtin_amdgcn_s_memtime() - tbegin_);
+        o[40] = (float)NS;
+    }
+    return;
+#endif
     // the last workgroup of the frame finishes CALayer2 (the out ring is free: its last reader is behind the final barrier of the walk)
     if (A.pool && A.se.ca) {
         const int nblk = A.nsx * A.nsy;

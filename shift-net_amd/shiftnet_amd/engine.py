@@ -312,7 +312,7 @@ class Engine:
     # sn_grp5_gemm_gate (g1 through HBM; what the denoisers always run).  SN_PHASE1 overrides it, e.g. for a checkpoint whose activations leave
     # the fp16 range the fused kernels carry `a`, g1 and r in (the chain keeps g1 in bf16).
     phase1 = os.environ.get("SN_PHASE1", "auto")
-    PHASE1_AUTO = {64: "v", 80: "r"}
+    PHASE1_AUTO = {64: "r", 80: "r"}     # C = 64, 20 x 360 x 640, CAB1 / CAB2: "r" 565 / 696 us, "v" 826 / 725 us, chain 837 / 950 us (one box)
     fused_cab_tail = True      # Engine32 (one kernel per reference module) runs conv, conv, pool, MLP, scale + residual instead
 
     def cab(self, pre: str, x: Act, extra: Optional[Act] = None) -> Act:

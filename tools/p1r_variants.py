@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""A/B builds of the role-split fused phase-1 kernel (csrc/sn_phase1r.hip): each variant is a mini library (sn_phase1.hip + sn_phase1r.hip with
+-D flags) timed on the level-1 sizes of configs 3 / 2.  Variants with P1R_SKIP switch off parts of the roles (wrong results) to show which role paces a step.
+  build (CPU, no GPU needed):  python tools/p1r_variants.py build
+  time (GPU box):              python tools/p1r_variants.py time [name ...]"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "shift-net_amd")):
+    sys.path.insert(0, p)
+DEV = os.path.join(ROOT, "shift-net_amd", "lib", "dev")
+VARIANTS = {
+    "base": [],
+    "S_only": ["-DP1R_SKIP=56"], "A_only": ["-DP1R_SKIP=55"], "B_only": ["-DP1R_SKIP=15"], "B_rep_only": ["-DP1R_SKIP=31"], "B_1x1_only": ["-DP1R_SKIP=47"],
+    "no_Smath": ["-DP1R_SKIP=1"], "no_loads": ["-DP1R_SKIP=2"], "no_stores": ["-DP1R_SKIP=4"], "no_A": ["-DP1R_SKIP=8"], "no_B": ["-DP1R_SKIP=48"],
+    "barriers_only": ["-DP1R_SKIP=63"],
+    "noAV": ["-DP1R_AV=0"], "noBV": ["-DP1R_BV=0"], "noAVBV": ["-DP1R_AV=0", "-DP1R_BV=0"], "d86": ["-DP1R_DB=8", "-DP1R_DA=6"], "d22": ["-DP1R_DB=2", "-DP1R_DA=2"],
+    "AV6": ["-DP1R_AV=6"], "BV2": ["-DP1R_BV=2"],
+    "timing": ["-DP1R_TIMING=1"],
+    "prio000": ["-DP1R_PRIO_S=0", "-DP1R_PRIO_B=0", "-DP1R_PRIO_A=0"], "prio300": ["-DP1R_PRIO_S=3", "-DP1R_PRIO_B=0", "-DP1R_PRIO_A=0"],
+    "prio311": ["-DP1R_PRIO_S=3", "-DP1R_PRIO_B=1", "-DP1R_PRIO_A=1"], "prio312": ["-DP1R_PRIO_S=3", "-DP1R_PRIO_B=1", "-DP1R_PRIO_A=2"],
+    "prio210": ["-DP1R_PRIO_S=2", "-DP1R_PRIO_B=1", "-DP1R_PRIO_A=0"], "prio231": ["-DP1R_PRIO_S=2", "-DP1R_PRIO_B=3", "-DP1R_PRIO_A=1"],
+}
+if os.environ.get("P1R_EXTRA"):       # "name:-Dflag,-Dflag;name2:..."
+    for item in os.environ["P1R_EXTRA"].split(";"):
+        n, f = item.split(":")
+        VARIANTS[n] = f.split(",")
+
+
+def build(only=None):
+    os.makedirs(DEV, exist_ok=True)
+    csrc = os.path.join(ROOT, "shift-net_amd", "csrc")
+    base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wno-unused-function"]
+    p1o = os.path.join(DEV, "sn_phase1.o")                      # the entry points (csrc/sn_phase1.hip) are the same for every variant
+    subprocess.run(base + ["-c", "-o", p1o, os.path.join(csrc, "sn_phase1.hip")], check=True)
+    for name, flags in VARIANTS.items():
+        if only and name not in only:
+            continue
+        out = os.path.join(DEV, f"libp1r_{name}.so")
+        subprocess.run(base + ["-shared", "-o", out, *flags, p1o, os.path.join(csrc, "sn_phase1r.hip")], check=True)
+        print("built", out, flush=True)
+
+
+def time_all(names):
+    import torch
+    from shiftnet_amd import lib as L
+    from shiftnet_amd.engine import Plan
+    from shiftnet_amd.spec import VARIANTS as SV
+    from shiftnet_amd.weights import synth_state_dict
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    for model, sizes in (("gshift_deblur1", ((52, 360, 640),)), ("gshift_deblur2", ((20, 360, 640),))):
+        V = SV[model]
+        P = Plan(V, synth_state_dict(model), dev)
+        Cc = V.c1
+        for (T, h, w) in sizes:
+            xd = torch.randn(T, h, w, Cc, device=dev).to(torch.bfloat16)
+            hwb = torch.randn(T, h, w, Cc // 2, device=dev).to(torch.bfloat16)
+            g2 = torch.empty((T, h, w, Cc), dtype=torch.bfloat16, device=dev)
+            for name in names:
+                path = os.path.join(DEV, f"libp1r_{name}.so")
+                if not os.path.exists(path):
+                    continue
+                lib = C.CDLL(path)
+                vp, ci = C.c_void_p, C.c_int
+                lib.sn_phase1_pool_blocks.argtypes = [ci, ci, ci, ci]
+                lib.sn_gsts_cab2_phase1.argtypes = [C.POINTER(L.UnitSrc), vp, C.POINTER(L.Phase1Weights), vp, vp, C.POINTER(L.SeFold), vp]
+                lib.sn_cab1_phase1.argtypes = [C.POINTER(L.UnitSrc), C.POINTER(L.Phase1Weights), vp, vp, C.POINTER(L.SeFold), vp]
+                nb = lib.sn_phase1_pool_blocks(T, h, w, 1)
+                pool = torch.zeros((T, nb, Cc), dtype=torch.float32, device=dev)
+                res = []
+                for mode, unit in ((0, "encoder_level1.1."), (1, "encoder_level1.0.")):
+                    u = P.units["stage1.decoder_level1." + unit]["p1r"]
+                    src = L.UnitSrc(xd.data_ptr(), T, h, w, Cc, mode, 0)
+                    f = (lambda: lib.sn_gsts_cab2_phase1(C.byref(src), hwb.data_ptr(), C.byref(u["desc"]), g2.data_ptr(), pool.data_ptr(), None, st)) if mode else \
+                        (lambda: lib.sn_cab1_phase1(C.byref(src), C.byref(u["desc"]), g2.data_ptr(), pool.data_ptr(), None, st))
+                    for _ in range(2):
+                        assert f() == 0
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(5):
+                        f()
+                    e1.record(); torch.cuda.synchronize()
+                    res.append(e0.elapsed_time(e1) / 5 * 1e3)
+                print(f"VAR {model} {T}x{h}x{w} {name:16s} CAB1 {res[0]:8.1f} us   CAB2 {res[1]:8.1f} us", flush=True)
+                if name.startswith("timing"):        # per-wave (work, total) cycles of three workgroups of the last launch (CAB2)
+                    pc = pool.cpu()
+                    for (tt, bb) in ((0, 0), (T // 2, nb // 2), (T - 1, nb - 1)):
+                        r = pc[tt, bb]
+                        ns = r[40].item()
+                        nw = 2 * (Cc // 16) + 2
+                        print(f"   WG t={tt} blk={bb} steps {ns:.0f}: total {r[1].item() / ns:.0f} cyc/step; work cyc/step per wave:",
+                              " ".join(f"{r[2 * k].item() / ns:.0f}" for k in range(nw)), flush=True)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build(sys.argv[2:] or None)
+    else:
+        time_all(sys.argv[2:] or list(VARIANTS))
