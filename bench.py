@@ -25,7 +25,10 @@ for p in (ROOT, os.path.join(ROOT, "shift-net_amd")):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PMC_FILE = "r03_pmc_hbm_traffic_bench_window.json"    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command with --no-parity --no-cpu-baseline (tools/make_profiles_r03.sh)
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS command line with --no-parity --no-cpu-baseline (tools/make_profiles_r04.sh), one file
+# per preset; every file records the hash of the kernel sources it was measured on and is ignored when they have changed since.
+PMC_FILES = {(2, "bf16"): "r04_pmc_hbm_traffic_cfg2.json", (3, "bf16"): "r04_pmc_hbm_traffic_cfg3.json",
+             (4, "bf16"): "r04_pmc_hbm_traffic_cfg4_bf16.json", (4, "fp32"): "r04_pmc_hbm_traffic_cfg4_fp32.json"}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 VARIANT = "gshift_deblur2"
 H, W, ONE_LEN = 720, 1280, 16
@@ -55,8 +58,53 @@ def algorithmic_bytes_window(variant, h, w, t_in, t_out, s=2):
     return h * w * s * (t_in * e_in + t_out * e_out)
 
 
+def csrc_hash():
+    """Identity of the kernels a PMC file was measured on: sha256 over the HIP sources and the C header, in name order."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "shift-net_amd", "csrc")
+    for f in sorted(os.listdir(d)) + [os.path.join("..", "..", "include", "shiftnet_hip.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def symbol_key(sym):
+    """rocprofv3 kernel name -> the key bench.py aggregates the same kernel under (None: not one of ours)."""
+    import re
+    s = sym.replace("(anonymous namespace)::", "")
+    m = re.search(r"cab_phase1r_kernel<\d+, (true|false)>", s)
+    if m:
+        return "sn_gsts_cab2_phase1" if m.group(1) == "true" else "sn_cab1_phase1"
+    m = re.search(r"cab_phase1_kernel<(\d)", s)
+    if m:
+        return "sn_gsts_cab2_phase1" if m.group(1) == "3" else "sn_cab1_phase1"
+    m = re.search(r"ln_gemm_gate_kernel<\d+, (true|false)>", s)
+    if m:
+        return "sn_ln_gemm_gate<cab2>" if m.group(1) == "true" else "sn_ln_gemm_gate<cab1>"
+    for pat, key in (("scale_gemm_res_kernel", "sn_cab_phase2"), ("shiftconv_kernel", "sn_gsts_shiftconv"), ("grp5p_gemm_gate_kernel", "sn_grp5_gemm_gate"),
+                     ("dw5m_gemm_gate_kernel", "sn_dw5m_gemm_gate"), ("ca_mlp_kernel", "sn_ca_mlp"), ("cab_ca", "sn_cab_ca"), ("temporal_roll", "sn_temporal_roll"),
+                     ("ingest_kernel", "sn_ingest")):
+        if pat in s:
+            return key
+    m = re.search(r"conv3_fast_kernel<(\d+), ", s)
+    if m:
+        return f"sn_conv2d<mt{m.group(1)},8x32>"
+    m = re.search(r"conv_mfma_kernel<(\d+), (\d+), (\d+)>", s)
+    if m:
+        return f"sn_conv2d<mt{m.group(1)},{m.group(2)}x{m.group(3)}>"
+    m = re.search(r"(sn32_\w+|conv32\w*_kernel|\w+32\w*_kernel)", s)
+    if m:
+        return "fp32:" + m.group(1)
+    return None
+
+
 def kernel_alg_bytes(fn, meta):
     """Minimal HBM bytes of ONE launch given its interface (each distinct input read once, output written once)."""
+    if meta and meta[0] == "conv32":           # fp32 engine: NHWC float32, channel counts as given
+        _, T, ho, wo, cin, co, k, stride, in_mode, out_mode = meta[:10]
+        pin = T * ho * wo * stride * stride / (4 if in_mode == 1 else 1)
+        return 4 * (pin * cin + T * ho * wo * (co // 4 if out_mode == 1 else co))
     if meta and meta[0] == "naf":
         _, T, h, w, c, mode = meta
         px = T * h * w * 2
@@ -151,6 +199,8 @@ def main():
     ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS), help="BASELINE.json config preset (default: 2)")
     ap.add_argument("--dtype", default=None, choices=list(DTYPES), help="module dtype (fp32 runs the fp32 engine)")
     ap.add_argument("--quadrants", action="store_true", help="denoise CLI tiling: 4 overlapping quadrants per step")
+    ap.add_argument("--fp32_exact", action="store_true", help="--dtype fp32: exact fp32 products (v_mfma_f32_16x16x4_f32) instead of the default bf16 hi + lo "
+                                                               "split products on the bf16 matrix cores (both within 1e-4 of the reference)")
     ap.add_argument("--lib", default=None, help="A/B measurements only: another build of libshiftnet_hip.so (the line then carries its path)")
     args = ap.parse_args()
     if args.lib:
@@ -221,6 +271,9 @@ def main():
 
     h, w, L = args.height, args.width, args.one_len
     dt = DTYPES[args.dtype]
+    if args.fp32_exact:
+        from shiftnet_amd.engine32 import Engine32
+        Engine32.split_bf16 = False
     net = GShiftNet(future_frames=2, past_frames=2)
     net.load_state_dict(synth_state_dict(args.variant), strict=True)
     net = net.to(dt).to(dev).eval()
@@ -311,42 +364,57 @@ def main():
                 key = f"{fn}<{'cab2' if meta[5] else 'cab1'}>"
             elif fn in ("sn_gsts_cab2_phase2", "sn_cab1_phase2"):
                 key = "sn_cab_phase2"                    # one GPU kernel behind both entry points
-            a = agg.setdefault(key, {"ms": 0.0, "n": 0, "bytes": 0.0, "gsts": bool(meta and meta[0] == "naf")})
+            in_unit = bool(meta) and (meta[0] == "naf" or "unit" in meta)      # a kernel of a CAB2 / CAB1 of a GSTS unit
+            if fn.startswith("sn32_"):
+                key = f"{fn}<k{meta[6]}{'g' if 'unit' in meta and meta[6] > 1 and meta[4] == meta[5] else ''}>" if meta and meta[0] == "conv32" else fn
+                if in_unit:
+                    key += "@unit"
+            a = agg.setdefault(key, {"ms": 0.0, "n": 0, "bytes": 0.0, "gsts": in_unit})
             d = e0.elapsed_time(e1)
             a["ms"] += d; a["n"] += 1; a["bytes"] += kernel_alg_bytes(fn, meta)
-            if meta and meta[0] == "naf":
+            if in_unit:
                 unit_ms += d
-                if fn in ("sn_gsts_cab2_phase2", "sn_cab1_phase2"):            # one CAB finished: its fused-unit bytes = read x + write y
+                if meta[0] == "naf" and fn in ("sn_gsts_cab2_phase2", "sn_cab1_phase2"):      # one CAB finished: its fused-unit bytes = read x + write y
                     unit_bytes += 2 * meta[1] * meta[2] * meta[3] * meta[4] * 2
+                    n_cabs += 1
+                elif "unit" in meta and label.endswith("weight]") and ".body." in label and meta[0] == "conv32" and meta[6] == 1 and meta[4] == meta[5]:
+                    ui = meta.index("unit")                                                     # the fp32 CAB's last 1x1 (C -> C): same accounting, 4-byte elements
+                    unit_bytes += 2 * meta[ui + 1] * meta[ui + 2] * meta[ui + 3] * meta[ui + 4] * 4
                     n_cabs += 1
         eng.prof = None
         dom = max(agg, key=lambda k: agg[k]["ms"])
-        # HBM traffic from the committed PMC passes of THIS command run with --no-parity --no-cpu-baseline (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE, separate passes, tools/make_profiles_r03.sh -> tools/pmc_summary.py): bytes per WINDOW per kernel symbol =
-        # sum over that symbol's launches / windows in the trace, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
-        # coalesced reads on gfx950.  A figure below 0.9 x the algorithmic bytes cannot be right (every input is read at least once):
-        # it is then reported as null with the reason (round 2's file averaged in the launches of a small parity clip).
-        SYM = {"sn_dw5m_gemm_gate": "dw5m_gemm_gate_kernel", "sn_ln_gemm_gate<cab2>": "ln_gemm_gate_kernel<64, true>",
-               "sn_ln_gemm_gate<cab1>": "ln_gemm_gate_kernel<64, false>", "sn_cab_phase2": "scale_gemm_res_kernel<64",
-               "sn_gsts_shiftconv": "shiftconv_kernel<32", "sn_conv2d<mt1,8x32>": "conv3_fast_kernel<1, 16, 8>",
-               "sn_conv2d<mt2,8x32>": "conv3_fast_kernel<2, 24, 8>", "sn_ca_mlp": "ca_mlp_kernel",
-               "sn_cab1_phase1": "cab_phase1_kernel<2", "sn_gsts_cab2_phase1": "cab_phase1_kernel<3"}
-        pmc, pmc_note = None, "no PMC file under profiles/"
-        headline = (args.variant, h, w, L, args.dtype, len(quads)) == (VARIANT, H, W, ONE_LEN, "bf16", 1)
-        try:
-            doc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
-            pmc = doc["kernels_per_window"] if headline else None
-            pmc_note = (f"profiles/{PMC_FILE}: 2 x FETCH_SIZE + WRITE_SIZE summed over the kernel's launches of one window "
-                        f"({doc.get('windows_in_trace')} full windows in the trace, no parity sample)") if headline else "PMC passes exist for the headline config only"
-        except Exception as e:                                      # noqa: BLE001
-            pmc_note = f"PMC file unreadable: {e}"
+        # HBM traffic from the committed PMC passes of THIS command line run with --no-parity --no-cpu-baseline (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE, separate passes, tools/make_profiles_r04.sh -> tools/pmc_summary.py): bytes per WINDOW per kernel = sum over the kernel's
+        # launches / windows in the trace, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950.  The file
+        # names the sources it was measured on (csrc_hash); after any kernel change the figure is reported as null until the passes are re-run.
+        # A figure below 0.9 x the algorithmic bytes cannot be right either (every input is read at least once).
+        pmc, pmc_note = None, "no PMC passes for this configuration under profiles/"
+        preset = args.config if args.config is not None else (2 if (args.variant, h, w, L, len(quads)) == (VARIANT, H, W, ONE_LEN, 1) else None)
+        pmc_file = PMC_FILES.get((preset, args.dtype)) if not args.fp32_exact else None
+        if pmc_file:
+            try:
+                doc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+                if doc.get("csrc_hash") != csrc_hash():
+                    pmc_note = f"profiles/{pmc_file} was measured on other kernel sources (csrc_hash {doc.get('csrc_hash')} != {csrc_hash()}): re-run tools/make_profiles_r04.sh"
+                else:
+                    pmc = {}
+                    for sym, v in doc["kernels_per_window"].items():
+                        k = symbol_key(sym)
+                        if k is not None:
+                            e = pmc.setdefault(k, {"FETCH_SIZE_KB": 0.0, "WRITE_SIZE_KB": 0.0})
+                            e["FETCH_SIZE_KB"] += v.get("FETCH_SIZE_KB", 0.0); e["WRITE_SIZE_KB"] += v.get("WRITE_SIZE_KB", 0.0)
+                    pmc_note = (f"profiles/{pmc_file}: 2 x FETCH_SIZE + WRITE_SIZE summed over the kernel's launches of one window "
+                                f"({doc.get('windows_in_trace')} full windows in the trace, no parity sample, csrc_hash {doc.get('csrc_hash')})")
+            except Exception as e:                                      # noqa: BLE001
+                pmc_note = f"PMC file unreadable: {e}"
 
         def window_gb(key):
-            sym = SYM.get(key)
-            if pmc is None or sym is None:
+            if pmc is None:
                 return None
-            hits = [v for k, v in pmc.items() if sym in k]
-            return sum(2 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"] for v in hits) * 1024 / 1e9 if hits else None
+            if key.startswith("sn32_"):                                 # the fp32 engine's kernels: all of them together, under the unit / non-unit split
+                return None
+            v = pmc.get(key)
+            return (2 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024 / 1e9 if v else None
 
         def checked(traffic_gb, alg_gb, what):
             if traffic_gb is None:
@@ -359,6 +427,8 @@ def main():
         dom_traffic, dom_note = checked(None if dw is None else dw / agg[dom]["n"], dom_alg, dom)
         n_units = max(n_cabs // 2, 1)
         gw = [window_gb(k) for k, v in agg.items() if v["gsts"]]
+        if pmc is not None and args.dtype == "fp32":      # fp32 engine: the unit's kernels are generic operators, told apart by launch order, not by symbol:
+            gw = []                                         # the unit share of the window's traffic is not separable -> whole-net traffic only (below)
         unit_alg = unit_bytes / n_units / 1e9
         unit_traffic, unit_note = checked(None if (not gw or any(g is None for g in gw)) else sum(gw) / n_units, unit_alg, "GSTS kernels per unit")
         ach_dom = agg[dom]["bytes"] / (agg[dom]["ms"] * 1e-3) / 1e9
@@ -373,7 +443,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
             # module dtype; fp16 / bf16 modules both compute with bf16 storage + fp32 accumulation
-            "dtype": {"bf16": "bf16", "fp16": "fp16 module on bf16 storage", "fp32": "f32"}[args.dtype],
+            "dtype": {"bf16": "bf16", "fp16": "fp16 module on bf16 storage",
+                      "fp32": "f32 exact (fp32 products)" if args.fp32_exact else "f32 (bf16 hi+lo split products, fp32 accumulation)"}[args.dtype],
             "config": {"workload": f"{'Shift-Net-s' if args.variant.endswith('2') else 'Shift-Net+'} ({args.variant}), {w}x{h}, one_len={L} (T_in={L + 4}), "
                                    + ("as the denoise CLI's 4 quadrants of %dx%d, " % (ww, hh) if args.quadrants else "")
                                    + (f"module dtype {args.dtype}, " if args.dtype != "bf16" else "")
@@ -385,14 +456,20 @@ def main():
             "roofline": {"bound": "hbm", "scope": "fused GSTS unit (SURVEY.md 8d), all pyramid levels of one window", "achieved": round(ach_unit, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_unit / HBM_PEAK_GBS, 4), "traffic": unit_traffic,
                          "traffic_note": "GB per unit (average over the window's units): " + unit_note,
-                         "algorithmic_gb_per_unit": round(unit_alg, 4), "avg_unit_ms": round(unit_ms / n_units, 4), "units": n_units},
+                         "algorithmic_gb_per_unit": round(unit_alg, 4), "avg_unit_ms": round(unit_ms / n_units, 4), "units": n_units,
+                         # what the two-phase structure could reach at the measured copy rate: CALayer2's global pool splits every CAB in two
+                         # passes, K0 writes hw: 11.5 C bytes per pixel and unit against the model's 4 C, x 6.3 / 8 TB/s
+                         "ceiling_frac": round(4.0 / 11.5 * 6300.0 / HBM_PEAK_GBS, 4),
+                         "ceiling_note": "bf16 two-phase CAB structure: 11.5 C bytes per pixel-unit floor vs 4 C algorithmic, at the 6.3 TB/s copy rate"},
             "dominant_kernel": {"kernel": dom, "bound": "hbm", "achieved": round(ach_dom, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(ach_dom / HBM_PEAK_GBS, 4), "traffic": dom_traffic, "traffic_note": "GB per launch: " + dom_note,
                                 "algorithmic_gb_per_launch": round(dom_alg, 4),
                                 "avg_launch_ms": round(agg[dom]["ms"] / agg[dom]["n"], 4), "launches": agg[dom]["n"],
                                 "note": "kernel-local figure: its inputs / outputs include intermediates that the fused-unit model counts as zero bytes"},
             "whole_net_roofline": {"achieved": round(win_bytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": round(win_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                                   "frac": round(win_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_gb_per_window": round(win_bytes / 1e9, 1),
+                                   "traffic": (round(sum((2 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) for v in pmc.values()) * 1024 / 1e9, 1) if pmc else None),
+                                   "traffic_note": "GB per window, all of this library's kernels: " + pmc_note},
             "kernels": kernels,
         }
         if per_rank is not None:

@@ -51,9 +51,6 @@ __global__ void gather_kernel(const UnitK U, const int8_t* offs, bf16_t* u, cons
 // config 3 (C = 80: one workgroup per CU) -- the fourth register-prefetch pipeline on this path that lost to plain occupancy.  So was a
 // ROW-WALKING build (strip of 32 columns, ring of 20 input rows in LDS: 1.56 instead of 4.5 window bytes per output byte): 11.3 vs
 // 10.05 ms -- the kernel is not bound by the bytes it loads either.
-// A persistent, software-pipelined build (64 workgroups per XCD walking tile lists, the next tile's window in flight in 76 registers
-// while the current one is computed; bit-identical) was slower as well: 11.88 vs 10.33 ms per window of config 2, 74.5 vs 49.4 ms of
-// config 3 (C = 80: one workgroup per CU) -- the fourth register-prefetch pipeline on this path that lost to plain occupancy.
 template <int CH, int PP>
 __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const XcdTiles G, const int8_t* __restrict__ offs,
                                                       const uint32_t* __restrict__ w1d, bf16_t* hw) {

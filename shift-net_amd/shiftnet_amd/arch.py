@@ -83,12 +83,15 @@ class GShiftNetBase(nn.Module):
         return super()._load_from_state_dict(*args, **kwargs)
 
     def _param_signature(self) -> Tuple:
-        ver, ptr = 0, 0
+        """Identity of the parameter storage the prepared plan was built from: an ORDERED hash of (data_ptr, version) per parameter (a XOR / sum
+        would cancel when two parameters swap storage).  Inference tensors (module built or loaded under torch.inference_mode()) have no
+        version counter: their in-place edits cannot be seen, `_apply` / `load_state_dict` still invalidate the plan."""
+        sig = []
         for p in self.parameters():
-            ver += p._version
-            ptr ^= p.data_ptr()
+            sig.append(p.data_ptr())
+            sig.append(-1 if p.is_inference() else p._version)
         p0 = next(self.parameters())
-        return (p0.device, p0.dtype, ver, ptr)
+        return (p0.device, p0.dtype, hash(tuple(sig)))
 
     def set_temporal_split(self, rank: int, world: int, group=None) -> None:
         """Make this module process frames [a, b) of ONE long window sharded over `world` ranks (temporal_split.py):

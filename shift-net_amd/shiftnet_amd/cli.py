@@ -6,6 +6,10 @@ Same flags, directory layout, window arithmetic, metric definitions and log line
   --checkpoint PATH   override the checkpoint; 'synthetic' uses the deterministic synthetic weights
   --dtype {fp16,bf16,fp32}  dtype of the module (upstream: fp16 except the "+" denoiser, which stays float32): fp16 / bf16
                       modules run the bf16-storage MFMA kernels, fp32 modules the fp32 kernels (engine32.py)
+  --gpus N            clip-parallel (deblur CLIs): N processes, one per GPU, take the windows of every clip N at a time (window k of a round on
+                      rank k); a rank decodes only the one_len frames it restores and receives the 2 + 2 halo frames of its window from its
+                      neighbours in ONE all-gather of raw uint8 frames (RCCL over xGMI; shiftnet_amd/clip_parallel.py); rank 0 writes the log,
+                      whose lines equal the single-process run's.  Also honoured when launched by torchrun (WORLD_SIZE set).
   --host_io           convert uint8 <-> float on the host exactly like upstream (default: on the device, csrc/sn_io.hip:
                       same values bit for bit, 3 instead of 12 bytes per pixel over PCIe, PSNR and SSIM reduced on the GPU; the
                       denoise CLIs then also draw their AWGN on the device -- upstream draws it unseeded on the host,
@@ -29,7 +33,7 @@ import torch
 
 from . import synth
 from .arch import CLASSES
-from .clip_parallel import window_ranges
+from .clip_parallel import assemble_window, rounds, window_ranges
 from .io_edges import egress_u8, ingest_u8, ssim_u8
 from .weights import synth_state_dict
 
@@ -37,11 +41,13 @@ DTYPES = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}
 
 
 class TraverseLogger:
-    def __init__(self, result_dir: str, filename: str) -> None:
+    def __init__(self, result_dir: str, filename: str, quiet: bool = False) -> None:
         self.path = os.path.join(result_dir, filename)
-        self.f = open(self.path, "a" if os.path.exists(self.path) else "w")
+        self.f = None if quiet else open(self.path, "a" if os.path.exists(self.path) else "w")     # quiet: ranks > 0 of a --gpus run
 
     def write_log(self, log: str) -> None:
+        if self.f is None:
+            return
         print(log)
         self.f.write(log + "\n")
         self.f.flush()
@@ -125,7 +131,9 @@ class Inference:
         self.result_path = args.result_path
         os.makedirs(self.result_path, exist_ok=True)
         now = time.strftime("%Y-%m-%d %H:%M:%S", time.localtime())
-        self.logger = TraverseLogger(self.result_path, "inference_log_{}.txt".format(now))
+        self.rank, self.world = getattr(args, "rank", 0), getattr(args, "world", 1)
+        self.device = torch.device("cuda", getattr(args, "local_device", torch.cuda.current_device() if torch.cuda.is_available() else 0))
+        self.logger = TraverseLogger(self.result_path, "inference_log_{}.txt".format(now), quiet=self.rank != 0)
         for k, v in (("Inference -", now), ("save_image:", args.save_image), ("border:", args.border), ("model_path:", args.model_path),
                      ("data_path:", args.data_path), ("result_path:", args.result_path), ("n_seq:", 4 if self.denoise else 5),
                      ("size_must_mode:", 4), ("device:", "cuda")):
@@ -136,7 +144,7 @@ class Inference:
         else:
             self.net.load_state_dict(torch.load(args.model_path, map_location="cpu")["params"])
         self.dtype = DTYPES[args.dtype]
-        self.net = self.net.to(self.dtype).to("cuda").eval()
+        self.net = self.net.to(self.dtype).to(self.device).eval()
         self.logger.write_log("Loading model from {}".format(args.model_path))
 
     # --- clip sources ---------------------------------------------------------------------------------------
@@ -158,9 +166,88 @@ class Inference:
         return [read_image(p) if isinstance(p, str) else p for p in items]
 
     # --- main loop (test_deblur.py:91-177 / test_denoise.py:91-232) ---------------------------------------------
+    def _summary(self, total_psnr, total_ssim) -> Tuple[float, float]:
+        sp = ss = sp2 = ss2 = 0.0
+        n = n2 = 0
+        for k in total_psnr:
+            self.logger.write_log("# Video:{} AVG-PSNR={:.5}, AVG-SSIM={:.4}".format(
+                k, sum(total_psnr[k]) / len(total_psnr[k]), sum(total_ssim[k]) / len(total_ssim[k])))
+            sp += sum(total_psnr[k]); ss += sum(total_ssim[k]); n += len(total_psnr[k])
+            sp2 += sum(total_psnr[k]) / len(total_psnr[k]); ss2 += sum(total_ssim[k]) / len(total_ssim[k]); n2 += 1
+        if n:
+            self.logger.write_log("# Total AVG-PSNR={:.5}, AVG-SSIM={:.4}".format(sp / n, ss / n))
+            if self.denoise:       # the denoise CLIs also log the mean of the per-video means (test_denoise.py:222-223)
+                self.logger.write_log("# Total AVG-PSNR={:.5}, AVG-SSIM={:.4}".format(sp2 / n2, ss2 / n2))
+        return (sp / n, ss / n) if n else (float("nan"), float("nan"))
+
+    @torch.no_grad()
+    def infer_clip_parallel(self) -> Tuple[float, float]:
+        """The deblur main loop (test_deblur.py:91-177) with the windows of a clip taken `world` at a time, one per rank: a rank
+        decodes the one_len frames it restores (+ the clip-side edge frames on the first / last active rank of a round), the 2 + 2 halo frames
+        arrive in one all-gather of raw uint8 frames, every rank restores and scores its window on its device, and rank 0 logs the gathered
+        lines in window order -- the same lines (times aside) as the single-process run with the same one_len."""
+        import torch.distributed as dist
+        a, rank, world = self.args, self.rank, self.world
+        on_host = dist.get_backend() == "gloo"                 # several ranks on one device (tests): the collective moves host tensors
+        total_psnr, total_ssim = {}, {}
+        for v, ins, gts in self.videos():
+            vp, vs = [], []
+            wins = window_ranges(len(ins), a.one_len)
+            for rnd in rounds(len(wins), world):
+                t0 = time.time()
+                act = len(rnd)
+                mine = rnd[rank] if rank < act else rnd[0]         # idle ranks of a partial last round decode window 0's frames as filler
+                r_in, r_out = wins[mine]
+                own_np = self._load(ins[r_out.start:r_out.stop])
+                h, w, _ = own_np[0].shape
+                nh, nw = h - h % 4, w - w % 4
+                crop = lambda ims: torch.from_numpy(np.stack([im[:nh, :nw] for im in ims])).permute(0, 3, 1, 2).contiguous()      # noqa: E731
+                to = (lambda t: t) if on_host else (lambda t: t.to(self.device))
+                own = to(crop(own_np))
+                first = to(crop(self._load(ins[r_in.start:r_in.start + 2]))) if rank == 0 else None
+                last = to(crop(self._load(ins[r_in.stop - 2:r_in.stop]))) if rank == act - 1 else None
+                win = assemble_window(own, first, last, rank, world, active=act)      # uint8 [L+4,3,H,W]
+                rec = None
+                if win is not None:
+                    u8 = win.to(self.device).permute(0, 2, 3, 1).contiguous()        # HWC frames, what ingest_u8 takes
+                    gtf = [im[:nh, :nw] for im in self._load(gts[r_out.start:r_out.stop])]
+                    x = ingest_u8(u8, self.dtype)
+                    x32 = ingest_u8(u8, torch.float32) if self.dtype != torch.float32 else None
+                    t1 = time.time()
+                    output = self.net.forward_fp32_out(x, shortcut=x32)
+                    torch.cuda.synchronize(self.device)
+                    t2 = time.time()
+                    gt_dev = torch.from_numpy(np.stack(gtf)).to(self.device)
+                    img_u8, psnrs = egress_u8(output, gt_dev, want_image=a.save_image)
+                    ssims = ssim_u8(output, gt_dev)
+                    if a.save_image:
+                        from PIL import Image
+                        os.makedirs(os.path.join(self.result_path, v), exist_ok=True)
+                        imgs = img_u8.cpu().numpy()
+                        for e in range(len(r_out)):
+                            Image.fromarray(imgs[e]).save(os.path.join(self.result_path, v, "%03d.png" % (r_out.start - 2 + e)))
+                    name = os.path.basename(ins[r_in.start + 2]).split(".")[0] if isinstance(ins[r_in.start + 2], str) else "%05d" % (r_in.start + 2)
+                    t3 = time.time()
+                    rec = (mine, name, [float(p) for p in psnrs], [float(q) for q in ssims], t1 - t0, t2 - t1, t3 - t2, t3 - t0)
+                    del output, x, x32
+                    torch.cuda.empty_cache()
+                recs = [None] * world
+                dist.all_gather_object(recs, rec)
+                for r in sorted((r for r in recs if r is not None), key=lambda r: r[0]):
+                    _, name, ps, ss, pre, fwd, post, tot = r
+                    vp += ps; vs += ss
+                    self.logger.write_log(
+                        "> {}-{} PSNR={:.5}, SSIM={:.4} pre_time:{:.3}s, forward_time:{:.3}s, post_time:{:.3}s, total_time:{:.3}s"
+                        .format(v, name, ps[-1], ss[-1], pre, fwd, post, tot))
+            if vp:
+                total_psnr[v], total_ssim[v] = vp, vs
+        return self._summary(total_psnr, total_ssim)
+
     @torch.no_grad()
     def infer(self) -> Tuple[float, float]:
         a = self.args
+        if self.world > 1:
+            return self.infer_clip_parallel()
         total_psnr, total_ssim = {}, {}
         for v, ins, gts in self.videos():
             vp, vs = [], []
@@ -237,18 +324,7 @@ class Inference:
                     .format(v, name, psnr, ssim, t1 - t0, t2 - t1, t3 - t2, t3 - t0))
             if vp:
                 total_psnr[v], total_ssim[v] = vp, vs
-        sp = ss = sp2 = ss2 = 0.0
-        n = n2 = 0
-        for k in total_psnr:
-            self.logger.write_log("# Video:{} AVG-PSNR={:.5}, AVG-SSIM={:.4}".format(
-                k, sum(total_psnr[k]) / len(total_psnr[k]), sum(total_ssim[k]) / len(total_ssim[k])))
-            sp += sum(total_psnr[k]); ss += sum(total_ssim[k]); n += len(total_psnr[k])
-            sp2 += sum(total_psnr[k]) / len(total_psnr[k]); ss2 += sum(total_ssim[k]) / len(total_ssim[k]); n2 += 1
-        if n:
-            self.logger.write_log("# Total AVG-PSNR={:.5}, AVG-SSIM={:.4}".format(sp / n, ss / n))
-            if self.denoise:       # the denoise CLIs also log the mean of the per-video means (test_denoise.py:222-223)
-                self.logger.write_log("# Total AVG-PSNR={:.5}, AVG-SSIM={:.4}".format(sp2 / n2, ss2 / n2))
-        return (sp / n, ss / n) if n else (float("nan"), float("nan"))
+        return self._summary(total_psnr, total_ssim)
 
 
 def main(variant: str, argv: Optional[Sequence[str]] = None) -> Tuple[float, float]:
@@ -268,7 +344,28 @@ def main(variant: str, argv: Optional[Sequence[str]] = None) -> Tuple[float, flo
     ap.add_argument("--dtype", choices=list(DTYPES), default="fp32" if variant == "gshift_denoise1" else "fp16")
     ap.add_argument("--result_path", type=str, default=None)
     ap.add_argument("--host_io", action="store_true", help="uint8<->float conversion and PSNR on the host, as upstream")
+    ap.add_argument("--fp32_exact", action="store_true",
+                    help="float32 modules: exact fp32 products on the fp32 matrix-core instructions instead of the default bf16 hi + lo split "
+                         "products (~2^-16 per product; both within 1e-4 of the reference, the exact mode is about half as fast)")
+    if not denoise:
+        ap.add_argument("--gpus", type=int, default=1, help="clip-parallel: one process per GPU, the windows of a clip N at a time")
     a = ap.parse_args(argv)
+    if a.fp32_exact:
+        os.environ["SN_FP32_EXACT"] = "1"
+    a.rank, a.world, a.local_device = 0, 1, 0
+    ngpus = getattr(a, "gpus", 1)
+    if ngpus > 1 and "RANK" not in os.environ:
+        return _spawn_ranks(ngpus, argv)                 # this process only launches and waits; rank 0 prints the log
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not denoise:
+        import torch.distributed as dist
+        a.rank, a.world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        ndev = torch.cuda.device_count()
+        a.local_device = int(os.environ.get("LOCAL_RANK", a.rank)) % max(ndev, 1)
+        torch.cuda.set_device(a.local_device)
+        # one GPU per rank -> RCCL; fewer devices than ranks (tests: two ranks on one device, which RCCL refuses) -> gloo with host staging
+        backend = os.environ.get("SN_CLI_BACKEND", "nccl" if ndev >= a.world else "gloo")
+        if not dist.is_initialized():
+            dist.init_process_group(backend, rank=a.rank, world_size=a.world)
     sfx = "_small" if small else ""
     a.data_path, a.model_path, rp = ".", "synthetic" if a.synthetic else "", "infer_results/synthetic"
     if denoise:
@@ -286,4 +383,31 @@ def main(variant: str, argv: Optional[Sequence[str]] = None) -> Tuple[float, flo
     a.result_path = a.result_path or rp
     if not a.model_path:
         ap.error("choose --default_data, or --synthetic H W N, or give --checkpoint")
-    return Inference(a, variant).infer()
+    try:
+        return Inference(a, variant).infer()
+    finally:
+        if a.world > 1:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.barrier()
+                dist.destroy_process_group()
+
+
+def _spawn_ranks(n: int, argv: Optional[Sequence[str]]) -> Tuple[float, float]:
+    """--gpus N outside a launcher: start N copies of this very command line, one rank each (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    the environment, rendezvous on 127.0.0.1), and wait for them.  The metrics are in rank 0's log."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, sys.argv[0]] + list(sys.argv[1:] if argv is None else argv)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(cmd, env=env))
+    rc = [p.wait() for p in procs]
+    if any(rc):
+        raise SystemExit("clip-parallel ranks exited with codes %s" % rc)
+    return float("nan"), float("nan")

@@ -22,18 +22,28 @@ def window_ranges(n_frames: int, one_len: int) -> List[Tuple[range, range]]:
 
 
 def assemble_window(own: torch.Tensor, first_edge: Optional[torch.Tensor], last_edge: Optional[torch.Tensor],
-                    rank: int = 0, world: int = 1, group=None) -> torch.Tensor:
+                    rank: int = 0, world: int = 1, group=None, active: Optional[int] = None) -> Optional[torch.Tensor]:
     """own:[L,3,H,W] -> this rank's input window [L+4,3,H,W].
 
-    ``first_edge`` ([2,3,H,W]) is required on rank 0, ``last_edge`` on rank world-1.  Without a process group (plain
-    single-GPU run) there is no communication at all.
+    ``first_edge`` ([2,3,H,W]) is required on rank 0, ``last_edge`` on the last ACTIVE rank (``active`` ranks hold a window in this round,
+    default all; the others still take part in the collective -- ``own`` is then any tensor of the right shape -- and get None).  Without a
+    process group (plain single-GPU run) there is no communication at all.  The collective runs where ``own`` lives (RCCL for device
+    tensors; a gloo group -- several ranks sharing one device in the tests -- needs host tensors: pass them as such).
     """
     if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return torch.cat((first_edge, own, last_edge), 0)
+    active = world if active is None else active
     # (a one-rank process group still goes through the collective: the RCCL path is exercised on a single-GPU box too)
     send = torch.cat((own[:2], own[-2:]), 0).contiguous()
     bufs = [torch.empty_like(send) for _ in range(world)]
     dist.all_gather(bufs, send, group=group)
+    if rank >= active:
+        return None
     head = first_edge if rank == 0 else bufs[rank - 1][2:4]
-    tail = last_edge if rank == world - 1 else bufs[rank + 1][0:2]
+    tail = last_edge if rank == active - 1 else bufs[rank + 1][0:2]
     return torch.cat((head, own, tail), 0)
+
+
+def rounds(n_windows: int, world: int) -> List[List[int]]:
+    """Window indices per lock-step round of a clip-parallel CLI run: round i = windows [i * world, (i + 1) * world), rank r takes the r-th."""
+    return [list(range(i, min(i + world, n_windows))) for i in range(0, n_windows, world)]

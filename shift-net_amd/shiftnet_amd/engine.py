@@ -212,6 +212,7 @@ class Engine:
         self.dev = plan.device
         self.prof: Optional[list] = None      # bench.py attaches a list to collect (fn, label, meta, ev0, ev1)
         self._meta: Tuple = ()
+        self._unit: Optional[Tuple] = None    # (T, h, w, c, mode) while the launches of a CAB2 / CAB1 of a GSTS unit are being issued
         self.split = None                     # temporal_split.TemporalSplit: this engine holds a frame range of a longer window
         self._side = None                     # side stream of the halo exchanges (created on first use)
         self._tickets = None                  # sn_se_fold frame counters: zero between launches (the kernels re-arm them)
@@ -236,7 +237,10 @@ class Engine:
         e0.record()
         L.check(f(*args), label)
         e1.record()
-        self.prof.append((fn, label, self._meta, e0, e1))
+        meta = self._meta
+        if self._unit is not None and not (meta and meta[0] == "naf"):       # a kernel of the unit with its own meta (the fp32 engine's operators)
+            meta = tuple(meta) + ("unit",) + self._unit
+        self.prof.append((fn, label, meta, e0, e1))
 
     act_dtype = torch.bfloat16
 
@@ -302,9 +306,6 @@ class Engine:
                                    p["wb"].data_ptr(), ca.data_ptr(), T, self._stream())
         return ca
 
-    def scale_residual(self, r: Act, x: Act, ca: torch.Tensor, extra: Optional[Act] = None) -> Act:
-        raise NotImplementedError("bf16 CABs apply the CALayer scale and the residual in conv2's epilogue (fused_cab_tail)")
-
     # ---- blocks (oracle/shiftnet_oracle.py has the same names) ----------------------------------------------
     fold_se = True             # fused phase 1: CALayer2's MLP is finished by the frame's last workgroup (sn_se_fold) instead of an sn_ca_mlp launch
     # Phase 1 of CAB2 / CAB1 of the deblur models.  "r": role-split fused kernel (csrc/sn_phase1r.hip, C = 64 / 80, RepConv on the matrix cores);
@@ -313,7 +314,7 @@ class Engine:
     # the fp16 range the fused kernels carry `a`, g1 and r in (the chain keeps g1 in bf16).
     phase1 = os.environ.get("SN_PHASE1", "auto")
     PHASE1_AUTO = {64: "r", 80: "r"}     # C = 64, 20 x 360 x 640, CAB1 / CAB2: "r" 565 / 696 us, "v" 826 / 725 us, chain 837 / 950 us (one box)
-    fused_cab_tail = True      # Engine32 (one kernel per reference module) runs conv, conv, pool, MLP, scale + residual instead
+    fused_cab_tail = True      # bf16 engine: always.  Engine32 (one kernel per reference module) runs conv, conv, pool, MLP, scale + residual instead
 
     def cab(self, pre: str, x: Act, extra: Optional[Act] = None) -> Act:
         """CAB: 3x3 -> PReLU -> 3x3 -> CALayer -> +x (gshift_deblur1.py:141-156).
@@ -332,6 +333,7 @@ class Engine:
             self._call("sn_cab_ca", f"sn_cab_ca[{pre}]", pool.data_ptr(), nblk, cpad, mid.t.data_ptr(), cs, p["c"], p["cr"], h, w,
                        p["w2"].data_ptr(), p["wa"].data_ptr(), p["wb"].data_ptr(), scratch.data_ptr(), ca.data_ptr(), T, self._stream())
             return self.conv(pre + "body.2", [mid], res=x, oscale=ca, res2=extra)
+        # one kernel per reference module (Engine32 provides scale_residual; the bf16 engine never takes this branch)
         r = self.conv(pre + "body.0", [x], prelu=self.P.scalar(pre + "body.1.weight"))
         r, pool, npix = self.conv(pre + "body.2", [r], pool=True)
         return self.scale_residual(r, x, self.ca_mlp(pre + "CA", pool, npix), extra)

@@ -13,6 +13,8 @@ activation is NHWC fp32 ``[T, H, W, C]`` with C the logical channel count.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Dict, Optional, Sequence
 
@@ -79,8 +81,9 @@ class Engine32(Engine):
     act_dtype = torch.float32
     fused_cab_tail = False
     # Dense k = 1 / 3 and grouped-by-8 k = 5 convs with their operands split into bf16 hi + lo parts (three bf16 MFMAs per k-step instead of
-    # eight fp32 ones; ~2^-16 per product, fp32 accumulation).  False: exact fp32 products everywhere -- the validation build of the tests.
-    split_bf16 = True
+    # eight fp32 ones; ~2^-16 per product, fp32 accumulation).  False: exact fp32 products everywhere (v_mfma_f32_16x16x4_f32), about half as
+    # fast -- SN_FP32_EXACT=1, `--fp32_exact` on the CLIs and bench.py.  Both are within 1e-4 of the reference (tests/test_gpu_fp32.py runs both).
+    split_bf16 = os.environ.get("SN_FP32_EXACT", "0") != "1"
 
     # ---- leaf operators ------------------------------------------------------------------------------------
     def _conv32(self, wkey: str, bkey: Optional[str], ins: Sequence[torch.Tensor], cins: Sequence[int], *, k: int, stride: int = 1,
@@ -120,6 +123,10 @@ class Engine32(Engine):
         if res is not None:
             d.res, d.cs_res = res.data_ptr(), res.stride(2)
         if out_mode == 2:
+            # the fp32 epilogues read the shortcut in the OUTPUT's element type (sn32_conv_desc has no sc_dtype): anything else would be reinterpreted
+            if nchw_sc.dtype != nchw_out.dtype:
+                nchw_sc = nchw_sc.to(nchw_out.dtype)
+            assert nchw_sc.is_contiguous() and nchw_sc.shape == nchw_out.shape, (tuple(nchw_sc.shape), tuple(nchw_out.shape))
             d.out, d.sc, d.nchw_dtype, d.cs_out = nchw_out.data_ptr(), nchw_sc.data_ptr(), _dtype_code(nchw_out.dtype), 0
             o = nchw_out
         else:
@@ -194,6 +201,13 @@ class Engine32(Engine):
         return self.ca_mlp(name, self._chan_sum(g), h * w)
 
     def naf(self, pre: str, x: Act, mode: int) -> Act:
+        self._unit = tuple(x.dims) + (mode,)
+        try:
+            return self._naf(pre, x, mode)
+        finally:
+            self._unit = None
+
+    def _naf(self, pre: str, x: Act, mode: int) -> Act:
         """CAB2 (mode 1/2) / CAB1 (mode 0), operator by operator as the reference module lists them (gshift_deblur1.py:183-255)."""
         P, V, st = self.P, self.V, self._stream()
         T, h, w, c = x.dims

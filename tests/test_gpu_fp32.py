@@ -132,3 +132,23 @@ def test_config1_fp32(golden_dir):
     with torch.no_grad():
         out = net(O.frames_to_tensor(list(blur)).cuda())
     close("config1_fp32", out, torch.from_numpy(g["out"]))
+
+
+def test_cli_quadrant_forward_matches_reference_fixture(golden_dir):
+    """cli.quadrant_forward (the denoise CLI's 4 overlapping quadrants, inference/test_denoise.py:153-173) on a float32 gshift_denoise1 module --
+    upstream's dtype for this model (:83-85) -- with the fixture's FIXED noise tensor, against the reference network run on the same four
+    crops and stitched by the CLI's own slice arithmetic (tests/golden/quadrants_gshift_denoise1.npz, made by make_golden.py from the
+    reference): <= 1e-4.  Host-side and device-side stitching, both conv arithmetics.  A swapped quadrant or crop offset is off by >= 1.5e-3."""
+    from basicsr.models.archs.gshift_denoise1 import GShiftNet
+    from shiftnet_amd import cli
+    from test_oracle_golden import quadrant_inputs
+    g = np.load(os.path.join(golden_dir, "quadrants_gshift_denoise1.npz"))
+    x, sigma = quadrant_inputs(g)
+    net = GShiftNet(future_frames=2, past_frames=2)
+    net.load_state_dict(synth_state_dict("gshift_denoise1"), strict=True)
+    net = net.to(DEV).eval()
+    with torch.no_grad():
+        for on_device in (False, True):
+            out = cli.quadrant_forward(net, x.to(DEV), sigma, on_device=on_device)
+            assert out.is_cuda == on_device
+            close(f"quadrants_on_device_{on_device}", out, torch.from_numpy(g["out"]))

@@ -392,6 +392,14 @@ def test_whole_net_vs_golden(name, dt, golden_dir):
                    "max_abs": (out32 - ref).abs().max().item()})
     assert p_oo >= 48.0 and p_32 >= 48.0 and dpsnr <= 0.01, (name, dt, p_oo, p_32, dpsnr, dpsnr_tensor)
     assert corr_err <= CORR_TOL, (name, dt, corr_err)
+    # The module contract itself: forward() takes and returns tensors of the module dtype, which quantises the frames for ANY implementation.
+    # Against the reference under the same I/O quantisation -- the fp32 oracle on the clip rounded to the module dtype, its output rounded to
+    # it: what upstream's half-precision CLI computes (test_deblur.py:128-143) -- the 0.01 dB bound holds for the module tensor too.
+    with torch.no_grad():
+        ref_q = O.forward(V, synth_state_dict(name), x.to(dt).float(), nm.to(dt).float() if V.denoise else None, 2, 2).to(dt).float()
+    dpsnr_q = abs(_psnr(out.clamp(0, 1), gt) - _psnr(ref_q.clamp(0, 1), gt))
+    REPORT[-1]["delta_psnr_gt_vs_reference_in_module_dtype"] = dpsnr_q
+    assert dpsnr_q <= 0.01, (name, dt, dpsnr_q)
     # default past/future of the ctor
     net2 = mod.GShiftNet()
     net2.load_state_dict(synth_state_dict(name), strict=True)
@@ -656,3 +664,114 @@ def test_nhwc_to_planar_bit_exact():
     torch.cuda.synchronize()
     assert torch.equal(xp[..., :w], x.permute(0, 1, 3, 2))
     assert torch.count_nonzero(xp[..., w:]) == 0
+
+
+@pytest.mark.parametrize("name,p1key", [("gshift_deblur2", "p1r"), ("gshift_deblur1", "p1r")])
+@pytest.mark.parametrize("ratio", [20.0, 100.0])
+def test_cab_phase1_layernorm_with_large_mean(name, p1key, ratio, engines):
+    """The role-split fused phase 1 computes the LayerNorm statistics in TWO passes (mean, then sum (x - mean)^2) and feeds the normalised
+    operand to the matrix core; the reference's LayerNorm2d (gshift_deblur1.py:17-28) on pixels whose channel mean is `ratio` times their
+    standard deviation, large absolute values included, must still come out within the kernel's usual bound (a one-pass E[x^2] - mean^2 loses
+    log2(ratio^2) bits there).  The input is generated as bf16-exact values so both sides see the same numbers."""
+    from shiftnet_amd import lib as L
+    eng, sd = engines(name)
+    V = O.VARIANTS[name]
+    C = V.c1
+    T, h, w = 2, 24, 70
+    base = torch.from_numpy(synth.unit_noise((T, C, h, w), seed=97))
+    pix_mean = torch.from_numpy(synth.unit_noise((1, 1, h, w), seed=98)).sign() * ratio          # the same for every frame: the rolled halves of CAB2's input keep the ratio
+    x = bf(((base + pix_mean) * 8.0))                               # |x| up to ~ 8 * (ratio + 4): 800+ at ratio 100
+    hw_in = bf(torch.from_numpy(synth.unit_noise((T, C // 2, h, w), seed=99)) * 8.0 + pix_mean * 8.0)
+    xd, hwd = to_dev(x), to_dev(hw_in)
+    st = torch.cuda.current_stream().cuda_stream
+    groups = C // 8 if V.grouped_rep else C
+    layout = 1 if p1key == "p1r" else 0
+
+    def ref_g2(q, v):
+        a = O._conv(sd, f"{q}body.0.", v)
+        a = O._conv(sd, f"{q}body.1.conv_2.", a, groups=a.shape[1]) + a
+        a1, a2 = a.chunk(2, dim=1)
+        b1, b2 = O._conv(sd, f"{q}body.4.", O._rep_conv(sd, f"{q}body.3.", a1 * a2, groups=groups)).chunk(2, dim=1)
+        return b1 * torch.sigmoid(b2)
+    blk = "stage1.decoder_level1."
+    for mode, unit in ((0, "encoder_level1.1."), (1, "encoder_level1.0.")):
+        pre = blk + unit
+        with torch.no_grad():
+            if mode:
+                u = O.gsts_gather(x, False, V.wrap)
+                ref = ref_g2(pre, O.layer_norm_2d(torch.cat((u[:, :C], hw_in), 1).double(), sd[pre + "norm.weight"].double(), sd[pre + "norm.bias"].double()).float())
+            else:
+                ref = ref_g2(pre, O.layer_norm_2d(x.double(), sd[pre + "norm.weight"].double(), sd[pre + "norm.bias"].double()).float())
+        p1 = eng.P.units[pre][p1key]
+        src = L.UnitSrc(xd.data_ptr(), T, h, w, C, mode, 1 if (V.wrap and mode) else 0)
+        nblk = eng.lib.sn_phase1_pool_blocks(T, h, w, layout)
+        g2 = torch.full((T, h, w, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+        pool = torch.zeros((T, nblk, C), dtype=torch.float32, device=DEV)
+        L.check(L.cab_phase1(eng.lib, src, hwd.data_ptr() if mode else None, p1["desc"], g2.data_ptr(), pool.data_ptr(), st), "phase 1")
+        check(f"phase1_ln_ratio{ratio}_{name}_{mode}", to_cpu(g2, C), ref, 1.5e-2)
+
+
+def _cli_lines(path):
+    """The metric part of the CLI's log lines (times differ from run to run)."""
+    import glob
+    import re
+    out = []
+    for f in sorted(glob.glob(os.path.join(path, "inference_log_*.txt"))):
+        for ln in open(f):
+            if ln.startswith(">"):
+                out.append(re.sub(r" pre_time:.*", "", ln.strip()))
+            elif ln.startswith("#"):
+                out.append(ln.strip())
+    return out
+
+
+def test_cli_real_inputs_directory_of_pngs_and_a_saved_checkpoint(tmp_path):
+    """The path no --synthetic run touches (inference/test_deblur.py:85,98-137): torch.load(path)['params'] with a strict load_state_dict,
+    directory walking ./dataset/GOPRO/test/{blur,gt}/<video>/*.png, PNG decoding -- on a checkpoint file and PNG frames written here from
+    the synthetic generators.  Run as the drop-in script itself (inference/test_deblur_small.py) from a scratch working directory, and
+    compared line for line with the in-memory --synthetic run of the same clip and weights."""
+    import subprocess
+    import sys
+    from PIL import Image
+    from shiftnet_amd import cli
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    H, W, N = 64, 96, 16
+    blur, sharp = synth.blurred_clip(N, H, W, seed=0)
+    for sub, clip in (("blur", blur), ("gt", sharp)):
+        d = tmp_path / "dataset" / "GOPRO" / "test" / sub / "synthetic"
+        d.mkdir(parents=True)
+        for i in range(N):
+            Image.fromarray(clip[i]).save(d / ("%05d.png" % i))
+    ck = tmp_path / "net.pth"
+    torch.save({"params": synth_state_dict("gshift_deblur2")}, ck)
+    script = os.path.join(root, "inference", "test_deblur_small.py")
+    r = subprocess.run([sys.executable, script, "--default_data", "GOPRO", "--checkpoint", str(ck), "--one_len", "4", "--dtype", "bf16",
+                        "--result_path", str(tmp_path / "real"), "--save_image"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    cli.main("gshift_deblur2", ["--synthetic", str(H), str(W), str(N), "--one_len", "4", "--dtype", "bf16", "--result_path", str(tmp_path / "syn")])
+    real, syn = _cli_lines(str(tmp_path / "real")), _cli_lines(str(tmp_path / "syn"))
+    assert len(real) == 3 + 2 and real == syn, (real, syn)          # 3 windows of 4, the video line, the total line
+    assert len(list((tmp_path / "real" / "synthetic").glob("*.png"))) == 12
+
+
+def test_cli_clip_parallel_two_ranks_log_the_single_process_lines(tmp_path):
+    """--gpus 2 on the drop-in deblur CLI (windows of a clip two at a time, one per rank, halo frames by all-gather): two
+    ranks share this box's one device (gloo transport with host staging, RCCL refuses two ranks per device), 5 windows = two full rounds
+    and a partial one, PNGs written by both ranks.  Log lines and images must equal the single-process run's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "inference", "test_deblur_small.py")
+    common = ["--synthetic", "64", "96", "24", "--one_len", "4", "--dtype", "bf16", "--save_image"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    for tag, extra in (("one", []), ("two", ["--gpus", "2"])):
+        r = subprocess.run([sys.executable, script] + common + extra + ["--result_path", str(tmp_path / tag)], cwd=tmp_path, env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    one, two = _cli_lines(str(tmp_path / "one")), _cli_lines(str(tmp_path / "two"))
+    assert len(one) == 5 + 2 and one == two, (one, two)
+    a = sorted((tmp_path / "one" / "synthetic").glob("*.png"))
+    b = sorted((tmp_path / "two" / "synthetic").glob("*.png"))
+    assert len(a) == 20 and [p.name for p in a] == [p.name for p in b]
+    for pa, pb in zip(a, b):
+        assert pa.read_bytes() == pb.read_bytes(), pa.name

@@ -130,3 +130,39 @@ def test_config1_and_windows(golden_dir):
     # T <= past+future yields an empty tensor, not an error (SURVEY.md §8b [probe])
     with torch.no_grad():
         assert O.forward(V, P, O.frames_to_tensor(list(blur[:4])), None, 2, 2).shape[0] == 0
+
+
+def quadrant_inputs(g):
+    """The fixture's input: clean synthetic clip + the fixed noise tensor (tests/golden/make_golden.py: quadrant_case)."""
+    T, H, W = (int(v) for v in g["dims"])
+    sigma = float(g["sigma"])
+    _, sharp = synth.blurred_clip(T, H, W, seed=11)
+    assert synth.crc(sharp) == int(g["in_crc"])
+    noise = torch.from_numpy(synth.unit_noise((1, T, 3, H, W), seed=12)).float() * sigma
+    assert synth.crc(noise.numpy()) == int(g["noise_crc"])
+    return O.frames_to_tensor(list(sharp)) + noise, sigma
+
+
+def test_denoise_quadrant_stitching_matches_reference(golden_dir):
+    """The denoise CLI's four overlapping quadrants (inference/test_denoise.py:153-173), restated on the ORACLE, against the reference network
+    run on the same four crops and stitched by the CLI's own slice arithmetic (fixture quadrants_gshift_denoise1.npz): fixed noise tensor,
+    96 x 128 frames.  A swapped quadrant or a wrong crop offset changes the result by the whole-frame-vs-stitched distance the fixture records
+    (1.5e-3) or far more; the bound is 1e-5."""
+    name = "gshift_denoise1"
+    g = np.load(os.path.join(golden_dir, f"quadrants_{name}.npz"))
+    x, sigma = quadrant_inputs(g)
+    V, sd = O.VARIANTS[name], synth_state_dict(name)
+    B, N, _, H, W = x.shape
+    pad_h, pad = 32 - (H // 2 % 16), 32 - (W // 2 % 16)
+    hh, ww = H // 2 + pad_h, W // 2 + pad
+    std = torch.full((B, N, 1, hh, ww), sigma)
+    with torch.no_grad():
+        def run(ys, xs):
+            return O.forward(V, sd, x[:, :, :, ys, xs].contiguous(), std, 2, 2)
+        out = torch.zeros(N - 4, 3, H, W)
+        out[..., 0:H // 2, 0:W // 2] = run(slice(0, hh), slice(0, ww))[..., 0:-pad_h, 0:-pad]
+        out[..., 0:H // 2, W // 2:] = run(slice(0, hh), slice(W // 2 - pad, W))[..., 0:-pad_h, pad:]
+        out[..., H // 2:, 0:W // 2] = run(slice(H // 2 - pad_h, H), slice(0, ww))[..., pad_h:, 0:-pad]
+        out[..., H // 2:, W // 2:] = run(slice(H // 2 - pad_h, H), slice(W // 2 - pad, W))[..., pad_h:, pad:]
+    close(out.numpy(), g["out"])
+    assert float(g["whole_vs_stitched_maxabs"]) > 1e-4      # the case distinguishes stitching from a whole-frame forward
