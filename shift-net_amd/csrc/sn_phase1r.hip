@@ -25,8 +25,9 @@
 //                 every B wave reads all C channels of the row back as the B operand of the second 1x1 (fp16 MFMA), SimpleGate2, channel
 //                 sums for CALayer2, g2 row -> out ring.
 //
-// Step j of a segment [Y0, Y1):   S stages input row Y0-2+j and stores g2 row Y0-9+j;  A turns input row Y0-3+j into g1 row Y0-4+j;
-// B computes r row Y0-7+j from g1 rows Y0-9+j .. Y0-5+j and g2 row Y0-8+j from the r row of the step before.  seg + 9 steps per segment.
+// Step j of a segment [Y0, Y1):   S stages input row Y0-2+j and stores g2 row Y0-10+j;  A turns the `a` row of step j-1 into g1 row Y0-5+j, then
+// input row Y0-3+j into the next `a` row;  B computes r row Y0-8+j from g1 rows Y0-10+j .. Y0-6+j and g2 row Y0-9+j from the r row of the step
+// before.  seg + 10 steps per segment.
 //
 // LDS (C = 80, CAB2: 149 KB, one workgroup per CU): x ring 2 rows, g1 ring 6 rows (5 being read + 1 being written), r ring 2, out ring 2.
 // Every ring is laid out [N-tile n][lane p] so that the 16 lanes of a ds_read_b128 lane group hit 16 distinct 16-byte slots; the g1 ring is
@@ -75,7 +76,7 @@ __device__ __forceinline__ uint32_t lane_next(uint32_t v) { return (uint32_t)__b
 #define P1R_SKIP 0
 #endif
 #ifndef P1R_DA
-#define P1R_DA 4
+#define P1R_DA 3
 #endif
 // measurement builds only: P1R_TIMING = 1 -> every wave accumulates the cycles between the start of a step and its arrival at the step's barrier
 // (s_memtime) and writes (work, total) to pool[(t, blk)][2 wave, 2 wave + 1] instead of the channel sums
@@ -133,7 +134,7 @@ template <int C, bool HW> struct P1RShape {
     static constexpr int OSLOT = RWD * PSO;
     static constexpr int OFF_X = 0, OFF_G = OFF_X + 2 * XSLOT, OFF_R = OFF_G + GRING * GROW, OFF_O = OFF_R + 2 * RSLOT;
     static constexpr int LDS = OFF_O + 2 * OSLOT + P1R_LDS_PAD;
-    static constexpr int WARM = 9;                            // steps per segment beyond its rows
+    static constexpr int WARM = 10;                           // steps per segment beyond its rows
     static_assert(GROW % 256 == 0, "the four lane groups of a RepConv B fragment read four ring rows: the pitch must keep their bank phase");
     static_assert(LDS <= 160 * 1024, "LDS");
     static_assert((16 + NTHR + 256) * 4 <= 2 * OSLOT, "sn_se_tail scratch lives in the out ring");
@@ -250,8 +251,8 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
             so_g[k] = (px < A.vw && gx < w) ? gx * C + pc * 8 : -1;
             if (so_g[k] < 0) so_l[k] = 0;
         }
-        auto store_row = [&](int j) {                                         // g2 row Y0 - 9 + j, written to out slot (j - 1) & 1 by the B waves in step j - 1
-            const int yo = Y0 - 9 + j;
+        auto store_row = [&](int j) {                                         // g2 row Y0 - 10 + j, written to out slot (j - 1) & 1 by the B waves in step j - 1
+            const int yo = Y0 - 10 + j;
             const char* os = lds_o + ((j - 1) & 1) * OSLOT;
             bf16_t* const g2row = A.g2 + ((size_t)t * h + yo) * w * C;
 #pragma unroll
@@ -274,7 +275,7 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
             if (!(P1R_SKIP & 1) && j <= seg + 4) stage_row((j + 1) & 1, X, Y0 - 2 + j);
             if (!(P1R_SKIP & 2)) issue_row(Y0 + j < ylast ? Y0 + j : ylast, X);
             __builtin_amdgcn_sched_barrier(0);                                // the loads stay in front of the stores (vmcnt retires in order)
-            if (!(P1R_SKIP & 4) && j >= 9 && j <= seg + 8) store_row(j);                        // (NS may contain one padding step)
+            if (!(P1R_SKIP & 4) && j >= 10 && j <= seg + 9) store_row(j);                        // (NS may contain one padding step)
             P1R_T1();
             __syncthreads();
         };
@@ -312,22 +313,25 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
         __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the weights have landed (no conservative waits inside the loop)
         __syncthreads();
         int gslot = 0;                                                        // j mod 6
+        // The wave is software-pipelined ACROSS steps: step j first runs the 3x3 + gate (VALU) on the packed `a` row of step j - 1, THEN the
+        // 1x1 MFMAs of input row Y0 - 3 + j.  A step of a B wave starts with MFMAs (second 1x1) and ends its first half with VALU (exp / rcp),
+        // so the roles sharing a SIMD are in complementary phases after every barrier -- with the MFMAs first, A and B waves queued for the
+        // matrix core together and for the VALU together, and a SIMD's step took the SUM of its VALU and MFMA time (4500 cycles: 2000 - 2700
+        // VALU + 1700 - 2700 MFMA) although the two pipes do overlap across waves (tools/ubench/mfma_valu_overlap.hip).  The stencil and the
+        // MFMAs of one step are independent: the compiler may mix them.
+        uint32_t ah[NX][4];                                                   // packed fp16 `a` row of the previous step's input row
+#pragma unroll
+        for (int n = 0; n < NX; ++n)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ah[n][k] = 0u;
 #pragma unroll 1
         for (int j = 0; j < NS; ++j) {
             P1R_T0();
-            if (!(P1R_SKIP & 8) && j <= seg + 5) {
-                const int yin = Y0 - 3 + j;
-                const char* xs = lds_x + (j & 1) * XSLOT + xrd;
-                // Two passes, one per M-tile of the wave's pair: pass m gives packed registers 2m, 2m + 1 of all four N-tiles, and their
-                // 3x3 (VALU) runs while the matrix core works on pass m + 1 (the stencil of register k needs register k of ALL tiles, so tile
-                // order would serialise MFMA phase and VALU phase: 544 + 823 cycles per step and wave in the first version).  Per pass the
-                // four N-tiles are four independent accumulator chains; fragments are read P1R_DA items ahead of their MFMA.
-                uint32_t ah[NX][4];
+            if (!(P1R_SKIP & 8) && j <= seg + 6) {
+                // ---- (1) depthwise 3x3 (+identity) on a row ya = Y0 - 4 + j, scatter form: it completes output row ya - 1, feeds row ya, opens row ya + 1 ----
                 h2_t F[NX][4];
-                constexpr int NI = NX * KS1, DA = P1R_DA < NI ? P1R_DA : NI;
-                auto rdx = [&](const int i) -> uint4 { return *(const uint4*)(xs + (i % NX) * XPL + 64 * (i / NX)); };      // item i = (k-step i / NX, tile i % NX)
-                auto stencil = [&](const int k) {
-                    // depthwise 3x3 (+identity), scatter form: input row yin completes output row yin - 1, feeds row yin, opens row yin + 1
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
                     const uint32_t Lw = lane_prev(ah[NX - 1][k]), Rw = lane_next(ah[0][k]);      // the two operands that cross the lane boundary
 #pragma unroll
                     for (int ti = 0; ti < 3; ++ti) {                          // ty = 2 first: it reads P1 before ty = 1 overwrites it (from P0), then ty = 0 reopens P0
@@ -343,36 +347,44 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
                                 else P0[n][k] = tx == 0 ? v * wk : __builtin_elementwise_fma(v, wk, P0[n][k]);
                             }
                     }
-                };
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    uint4 bq[NI];
-#pragma unroll
-                    for (int i = 0; i < DA; ++i) bq[i] = rdx(i);
-                    __builtin_amdgcn_sched_group_barrier(0x100, DA, 0);
-                    f32x4_t acc[NX];
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) {
-                        const int n = i % NX, s_ = i / NX;
-                        if (i + DA < NI) bq[i + DA] = rdx(i + DA);
-                        if (s_ == 0) acc[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                        acc[n] = mfma16(W1[m][s_], as_frag(bq[i]), acc[n]);
-                        if (i + DA < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        if (m == 1 && P1R_AV) __builtin_amdgcn_sched_group_barrier(0x002, P1R_AV, 0);       // pass 0's stencil between pass 1's MFMAs
-                    }
-#pragma unroll
-                    for (int n = 0; n < NX; ++n) { ah[n][2 * m] = cvt_pk_h2(acc[n][0], acc[n][1]); ah[n][2 * m + 1] = cvt_pk_h2(acc[n][2], acc[n][3]); }
-                    stencil(2 * m);
-                    stencil(2 * m + 1);
                 }
-                // SimpleGate -> g1 row yin - 1 (zero outside the image: the zero padding of the RepConv) -> ring row j mod 6
-                const bool rin = (yin - 1) >= 0 && (yin - 1) < h;
+                // SimpleGate -> g1 row Y0 - 5 + j (zero outside the image: the zero padding of the RepConv) -> ring row j mod 6
+                const int yg = Y0 - 5 + j;
+                const bool rin = yg >= 0 && yg < h;
                 char* gs = lds_g + gslot * GROW + gwr;
 #pragma unroll
                 for (int n = 0; n < NX; ++n) {
                     const uint32_t m = (rin && colin[n]) ? 0xffffffffu : 0u;
                     *(uint2*)(gs + n * GPL) = make_uint2(as_u(F[n][0] * F[n][2]) & m, as_u(F[n][1] * F[n][3]) & m);
+                }
+                // ---- (2) first 1x1 on input row Y0 - 3 + j (x slot j & 1) -> packed fp16 `a` row for the next step.  Item i = (k-step i / NX,
+                //      tile i % NX): one fragment, two MFMAs (the wave's two M-tiles); fragments are read P1R_DA items ahead ----
+                const char* xs = lds_x + (j & 1) * XSLOT + xrd;
+                // (two N-tiles at a time: 16 accumulator registers live; the MFMA issue rate does not depend on the number of chains,
+                //  tools/ubench/mfma_chains.hip)
+#pragma unroll
+                for (int n0 = 0; n0 < NX; n0 += 2) {
+                    constexpr int NI = 2 * KS1, DA = P1R_DA < NI ? P1R_DA : NI;
+                    auto rdx = [&](const int i) -> uint4 { return *(const uint4*)(xs + (n0 + (i & 1)) * XPL + 64 * (i >> 1)); };
+                    uint4 bq[NI];
+#pragma unroll
+                    for (int i = 0; i < DA; ++i) bq[i] = rdx(i);
+                    __builtin_amdgcn_sched_group_barrier(0x100, DA, 0);
+                    f32x4_t acc[2][2];
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        const int n = i & 1, s_ = i >> 1;
+                        if (i + DA < NI) bq[i + DA] = rdx(i + DA);
+                        if (s_ == 0) { acc[n][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[n][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+                        acc[n][0] = mfma16(W1[0][s_], as_frag(bq[i]), acc[n][0]); acc[n][1] = mfma16(W1[1][s_], as_frag(bq[i]), acc[n][1]);
+                        if (i + DA < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    }
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        ah[n0 + n][0] = cvt_pk_h2(acc[n][0][0], acc[n][0][1]); ah[n0 + n][1] = cvt_pk_h2(acc[n][0][2], acc[n][0][3]);
+                        ah[n0 + n][2] = cvt_pk_h2(acc[n][1][0], acc[n][1][1]); ah[n0 + n][3] = cvt_pk_h2(acc[n][1][2], acc[n][1][3]);
+                    }
                 }
             }
             gslot = gslot == SH::GRING - 1 ? 0 : gslot + 1;
@@ -422,10 +434,10 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
 #pragma unroll 1
         for (int j = 0; j < NS; ++j) {
             P1R_T0();
-            // Per step: (1) second 1x1 + SimpleGate2 on the r row of the PREVIOUS step (g2 row Y0 - 8 + j -> out slot j & 1), (2) RepConv: r row
-            // Y0 - 7 + j from g1 ring rows (j - 5 + dy) mod 6 -> r slot j & 1.  In the steady state both run in ONE basic block, the 1x1 in tile
+            // Per step: (1) second 1x1 + SimpleGate2 on the r row of the PREVIOUS step (g2 row Y0 - 9 + j -> out slot j & 1), (2) RepConv: r row
+            // Y0 - 8 + j from g1 ring rows (j - 5 + dy) mod 6 -> r slot j & 1.  In the steady state both run in ONE basic block, the 1x1 in tile
             // pairs, so that the exp / rcp / pack work of a pair is scheduled between the MFMAs that follow it (next pair, RepConv).
-            const bool do1 = !(P1R_SKIP & 16) && j >= 8 && j <= seg + 7, do2 = !(P1R_SKIP & 32) && j >= 7 && j <= seg + 6;
+            const bool do1 = !(P1R_SKIP & 16) && j >= 9 && j <= seg + 8, do2 = !(P1R_SKIP & 32) && j >= 8 && j <= seg + 7;
             const char* rs1 = lds_r + ((j - 1) & 1) * RSLOT + rrd;
             char* os = lds_o + (j & 1) * OSLOT + owr;
             int r6 = jm + g;
