@@ -27,8 +27,8 @@ import torch.distributed as dist  # noqa: E402
 
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS command line with --no-parity --no-cpu-baseline (tools/make_profiles_r04.sh), one file
 # per preset; every file records the hash of the kernel sources it was measured on and is ignored when they have changed since.
-PMC_FILES = {(2, "bf16"): "r04_pmc_hbm_traffic_cfg2.json", (3, "bf16"): "r04_pmc_hbm_traffic_cfg3.json",
-             (4, "bf16"): "r04_pmc_hbm_traffic_cfg4_bf16.json", (4, "fp32"): "r04_pmc_hbm_traffic_cfg4_fp32.json"}
+# (Config 4 = 4 quadrants x ~2900 launches per window: a --pmc pass of it did not finish within 10 minutes on the GPU box; no file.)
+PMC_FILES = {(2, "bf16"): "r04_pmc_hbm_traffic_cfg2.json", (3, "bf16"): "r04_pmc_hbm_traffic_cfg3.json"}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 VARIANT = "gshift_deblur2"
 H, W, ONE_LEN = 720, 1280, 16

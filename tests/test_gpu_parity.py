@@ -312,13 +312,14 @@ def C_byref(s):
     return ctypes.byref(s)
 
 
-@pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_deblur1"])
-@pytest.mark.parametrize("T,h,w", [(3, 184, 328), (3, 40, 200)])
+@pytest.mark.parametrize("name,T,h,w", [("gshift_deblur2", 3, 184, 328), ("gshift_deblur2", 3, 40, 200), ("gshift_deblur1", 3, 184, 328),
+                                        ("gshift_deblur1", 3, 40, 200), ("gshift_denoise1", 3, 136, 224)])
 def test_unit_parity_at_production_tile_counts(name, T, h, w, engines):
     """A whole GSTS unit against the oracle at sizes where the persistent, XCD-partitioned schedule of the matrix-core
     stencil kernel really loops: 184x328x3 = 414 tiles of 64x8 (> 256 workgroups, ragged right and bottom tiles, a
     segment boundary in the middle of a frame); 40x200x3 = 60 tiles (a workgroup count that is not a multiple of 8, so
-    the XCD partition falls back to one segment)."""
+    the XCD partition falls back to one segment); gshift_denoise1 at 3 x 136 x 224 = level 1 of the denoise CLI's quadrants (config 4): the
+    two-kernel phase 1 with the inner CALayer2 and the grouped RepConv kernel's persistent walk over 238 tiles."""
     eng, sd = engines(name)
     V = O.VARIANTS[name]
     x = bf(torch.from_numpy(synth.unit_noise((T, V.c1, h, w), seed=83)))
