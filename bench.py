@@ -73,7 +73,7 @@ def symbol_key(sym):
     """rocprofv3 kernel name -> the key bench.py aggregates the same kernel under (None: not one of ours)."""
     import re
     s = sym.replace("(anonymous namespace)::", "")
-    m = re.search(r"cab_phase1r_kernel<\d+, (true|false)>", s)
+    m = re.search(r"cab_phase1r_kernel<\d+, (true|false)", s)
     if m:
         return "sn_gsts_cab2_phase1" if m.group(1) == "true" else "sn_cab1_phase1"
     m = re.search(r"cab_phase1_kernel<(\d)", s)

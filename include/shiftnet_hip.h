@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 10     /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
+#define SN_ABI_VERSION 11     /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
 
 /* element types of NCHW tensors exchanged with the PyTorch side */
 #define SN_F32 0
@@ -207,9 +207,20 @@ typedef struct sn_se_fold {
     unsigned* ticket;
     float* ca;
 } sn_se_fold;
+/* The denoisers' inner CALayer2 on g1 = SimpleGate(...) (gshift_denoise1.py:224,257; gshift_denoise2.py:194,227), layout 1 only.  Its global average
+ * pool sits INSIDE phase 1, so phase 1 runs twice over the input and g1 still never reaches HBM:
+ *   pass 1, g1_sums = 1: LayerNorm -> 1x1 -> dw3x3 -> gate only; pool receives the partial channel sums of g1 (finish them with sn_ca_mlp, or pass
+ *           the inner CALayer2's weights as `se`: se->ca is then that layer's scale); g2 is not touched (may be NULL);
+ *   pass 2, g1_scale = that scale [T][C] f32: the whole phase 1 with g1 multiplied by it before the RepConv.
+ * NULL / zeros: the deblur models (no inner CALayer2). */
+typedef struct sn_phase1_opts {
+    const float* g1_scale;
+    int g1_sums;
+} sn_phase1_opts;
 int sn_phase1_pool_blocks(int T, int h, int w, int layout);
-int sn_gsts_cab2_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se, void* stream);
-int sn_cab1_phase1(const sn_unit_src* s, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se, void* stream);
+int sn_gsts_cab2_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se,
+                        const sn_phase1_opts* opt, void* stream);
+int sn_cab1_phase1(const sn_unit_src* s, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se, const sn_phase1_opts* opt, void* stream);
 
 /* PHASE 2, all variants (C = 64 / 80): y = shortcut + beta * body[7](ca * g2) (gshift_deblur1.py:201,210,254): beta and the optional bias
  * are folded into wfrag / bias; the shortcut is the ROLLED tensor for CAB2 (s->mode 1 / 2: sn_gsts_cab2_phase2) and x itself for CAB1

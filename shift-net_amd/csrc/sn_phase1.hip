@@ -445,7 +445,8 @@ constexpr int P1_NX = 3, P1_VWMAX = 16 * P1_NX - 6;      // NX = 4 needs ~300 re
 
 // layout 1 of sn_phase1_weights: the role-split kernel (csrc/sn_phase1r.hip)
 int sn_p1r_pool_blocks(int T, int h, int w);
-int sn_p1r_launch(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se, void* stream);
+int sn_p1r_launch(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se,
+                  const sn_phase1_opts* opt, void* stream);
 
 extern "C" {
 
@@ -459,9 +460,11 @@ int sn_phase1_pool_blocks(int T, int h, int w, int layout) {
     return nsx * nsy;
 }
 
-static int cab_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se, void* stream) {
+static int cab_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se,
+                      const sn_phase1_opts* opt, void* stream) {
     sn_clear_error();
-    if (wt && wt->layout == 1) return sn_p1r_launch(s, hw, wt, g2, pool, se, stream);
+    if (wt && wt->layout == 1) return sn_p1r_launch(s, hw, wt, g2, pool, se, opt, stream);
+    if (opt && (opt->g1_scale || opt->g1_sums)) return SN_EINVAL;          // the VALU kernel has no inner CALayer2
     if (!s || !s->x || s->C != 64 || (wt && wt->layout != 0) || s->mode < 0 || s->mode > 2 || s->T < 1 || s->h < 1 || s->w < 1 || !wt || !wt->wfrag1 || !wt->wfragx || !wt->w3 ||
         !wt->w5 || !wt->wfrag2 || !g2 || (s->mode != 0 && !hw) || s->wrap < 0 || s->wrap > 2 || (s->wrap == 2 && s->mode != 0 && !s->halo)) return SN_EINVAL;
     const int ncu = p1_ncu();
@@ -486,14 +489,15 @@ static int cab_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weig
     return sn_check_launch();
 }
 
-int sn_gsts_cab2_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se, void* stream) {
+int sn_gsts_cab2_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se,
+                        const sn_phase1_opts* opt, void* stream) {
     if (!s || (s->mode != 1 && s->mode != 2)) return SN_EINVAL;
-    return cab_phase1(s, hw, wt, g2, pool, se, stream);
+    return cab_phase1(s, hw, wt, g2, pool, se, opt, stream);
 }
 
-int sn_cab1_phase1(const sn_unit_src* s, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se, void* stream) {
+int sn_cab1_phase1(const sn_unit_src* s, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se, const sn_phase1_opts* opt, void* stream) {
     if (!s || s->mode != 0) return SN_EINVAL;
-    return cab_phase1(s, nullptr, wt, g2, pool, se, stream);
+    return cab_phase1(s, nullptr, wt, g2, pool, se, opt, stream);
 }
 
 }  // extern "C"

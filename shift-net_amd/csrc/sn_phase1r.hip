@@ -51,6 +51,8 @@ struct P1RArgs {
     bf16_t* g2; float* pool;
     int nsx, nsy, seg, vw;
     SeFold se;
+    const float* g1_scale;               // denoisers: [T][C] scale of the inner CALayer2 (gshift_denoise1.py:224,257), applied to g1 by the A waves; or NULL
+    int g1_sums;                         // 1: only the channel sums of g1 (the A waves' SimpleGate output) are produced: pool / se describe g1, no g2
 };
 
 __device__ __forceinline__ f32x4_t mfma16h(const uint4 a, const uint4 b, const f32x4_t c) {
@@ -140,7 +142,9 @@ template <int C, bool HW> struct P1RShape {
     static_assert((16 + NTHR + 256) * 4 <= 2 * OSLOT, "sn_se_tail scratch lives in the out ring");
 };
 
-template <int C, bool HW>
+// ICA: the denoisers' inner CALayer2 on g1 (sn_phase1_opts).  0: none (deblur models); 1: sums pass (stagers + A waves only, channel sums of g1);
+// 2: g1 times A.g1_scale before the RepConv.  A template parameter: the deblur kernels sit at the 168-register limit of three waves per SIMD.
+template <int C, bool HW, int ICA>
 __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(const P1RArgs A) {
     using SH = P1RShape<C, HW>;
     constexpr int NGP = SH::NGP, NTHR = SH::NTHR, CH = SH::CH, K = SH::K, KS1 = SH::KS1, KS2 = SH::KS2, NX = SH::NX;
@@ -155,7 +159,7 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
     const int x0 = sx * A.vw, Y0 = sy * A.seg, Y1 = Y0 + A.seg < A.h ? Y0 + A.seg : A.h;
     if (Y0 >= A.h) return;                                                    // workgroup-uniform
     const int h = A.h, w = A.w, hw = h * w;
-    const int seg = Y1 - Y0, NS = (seg + SH::WARM + 1) & ~1;      // even: the stagers rotate two register sets (a padding step only has the barrier)
+    const int seg = Y1 - Y0, NS = (seg + (ICA == 1 ? 7 : SH::WARM) + 1) & ~1;      // even: the stagers rotate two register sets (a padding step only has the barrier)
 
     // role of this wave.  A workgroup's waves go to the four SIMDs round-robin, so waves wv, wv + 4, wv + 8 share a SIMD: the roles are laid
     // out so that every SIMD gets one A wave (VALU-heavy), one B wave (MFMA-heavy) and one of {A4, B4, S0, S1}
@@ -275,7 +279,7 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
             if (!(P1R_SKIP & 1) && j <= seg + 4) stage_row((j + 1) & 1, X, Y0 - 2 + j);
             if (!(P1R_SKIP & 2)) issue_row(Y0 + j < ylast ? Y0 + j : ylast, X);
             __builtin_amdgcn_sched_barrier(0);                                // the loads stay in front of the stores (vmcnt retires in order)
-            if (!(P1R_SKIP & 4) && j >= 10 && j <= seg + 9) store_row(j);                        // (NS may contain one padding step)
+            if (!(P1R_SKIP & 4) && ICA != 1 && j >= 10 && j <= seg + 9) store_row(j);                        // (NS may contain one padding step)
             P1R_T1();
             __syncthreads();
         };
@@ -324,6 +328,22 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
         for (int n = 0; n < NX; ++n)
 #pragma unroll
             for (int k = 0; k < 4; ++k) ah[n][k] = 0u;
+        // denoisers: the inner CALayer2 between SimpleGate and RepConv.  Pass 1 (g1_sums) reduces the channel sums of g1 over the strip's own
+        // pixels (pool -> the squeeze-excite tail gives the scale), pass 2 multiplies g1 by that scale here; g1 itself never leaves the CU.
+        h2_t cmul[2] = {{(_Float16)1.f, (_Float16)1.f}, {(_Float16)1.f, (_Float16)1.f}};
+        if constexpr (ICA == 2) {
+            const float4 cs = *(const float4*)(A.g1_scale + (size_t)t * C + 16 * q + 4 * g);
+            cmul[0] = (h2_t){(_Float16)cs.x, (_Float16)cs.y}; cmul[1] = (h2_t){(_Float16)cs.z, (_Float16)cs.w};
+        }
+        float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+        float ownc[NX];
+        if constexpr (ICA == 1) {
+#pragma unroll
+            for (int n = 0; n < NX; ++n) {
+                const int rc = NX * p + n;
+                ownc[n] = (rc >= SH::HALO && rc < SH::HALO + A.vw && colin[n]) ? 1.f : 0.f;
+            }
+        }
 #pragma unroll 1
         for (int j = 0; j < NS; ++j) {
             P1R_T0();
@@ -355,7 +375,16 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
 #pragma unroll
                 for (int n = 0; n < NX; ++n) {
                     const uint32_t m = (rin && colin[n]) ? 0xffffffffu : 0u;
-                    *(uint2*)(gs + n * GPL) = make_uint2(as_u(F[n][0] * F[n][2]) & m, as_u(F[n][1] * F[n][3]) & m);
+                    const h2_t g1a = F[n][0] * F[n][2], g1b = F[n][1] * F[n][3];
+                    if constexpr (ICA == 1) {
+                        const float rown = (yg >= Y0 && yg < Y1) ? ownc[n] : 0.f;      // every pixel of the frame is counted by exactly one workgroup
+                        gsum[0] = fmaf((float)g1a[0], rown, gsum[0]); gsum[1] = fmaf((float)g1a[1], rown, gsum[1]);
+                        gsum[2] = fmaf((float)g1b[0], rown, gsum[2]); gsum[3] = fmaf((float)g1b[1], rown, gsum[3]);
+                    } else if constexpr (ICA == 2) {
+                        *(uint2*)(gs + n * GPL) = make_uint2(as_u(g1a * cmul[0]) & m, as_u(g1b * cmul[1]) & m);
+                    } else {
+                        *(uint2*)(gs + n * GPL) = make_uint2(as_u(g1a) & m, as_u(g1b) & m);
+                    }
                 }
                 // ---- (2) first 1x1 on input row Y0 - 3 + j (x slot j & 1) -> packed fp16 `a` row for the next step.  Item i = (k-step i / NX,
                 //      tile i % NX): one fragment, two MFMAs (the wave's two M-tiles); fragments are read P1R_DA items ahead ----
@@ -391,6 +420,19 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
             P1R_T1();
             __syncthreads();
         }
+        if (ICA == 1 && A.pool) {                                             // channel sums of g1 (g1 is carried times 2^-4: undone here, exactly)
+            const int nblk = A.nsx * A.nsy, blk = sy * A.nsx + sx;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sm = row_sum16(gsum[r]) * 16.0f;
+                if (p == 0) sn_pool_store(&A.pool[((size_t)t * nblk + blk) * C + 16 * q + 4 * g + r], sm);
+            }
+        }
+    } else if constexpr (ICA == 1) {
+        // B waves have no work in the sums pass: they only keep the barrier count
+        __syncthreads();
+#pragma unroll 1
+        for (int j = 0; j < NS; ++j) __syncthreads();
     } else {
         // =================================================== B: RepConv, second 1x1, gate2 ===================================================
         __builtin_amdgcn_s_setprio(P1R_PRIO_B);
@@ -562,13 +604,18 @@ int p1r_ncu() {
     return ncu;
 }
 
+template <int C, bool HW, int ICA>
+int p1r_launch1(P1RArgs& A, int nt, hipStream_t st) {
+    using SH = P1RShape<C, HW>;
+    if (hipFuncSetAttribute((const void*)cab_phase1r_kernel<C, HW, ICA>, hipFuncAttributeMaxDynamicSharedMemorySize, SH::LDS) != hipSuccess) return SN_ELAUNCH;
+    sn_clear_error();
+    hipLaunchKernelGGL((cab_phase1r_kernel<C, HW, ICA>), dim3((unsigned)(nt * A.nsx * A.nsy)), dim3(SH::NTHR), SH::LDS, st, A);
+    return sn_check_launch();
+}
 template <int C, bool HW>
 int p1r_launch(P1RArgs& A, int nt, hipStream_t st) {
-    using SH = P1RShape<C, HW>;
-    if (hipFuncSetAttribute((const void*)cab_phase1r_kernel<C, HW>, hipFuncAttributeMaxDynamicSharedMemorySize, SH::LDS) != hipSuccess) return SN_ELAUNCH;
-    sn_clear_error();
-    hipLaunchKernelGGL((cab_phase1r_kernel<C, HW>), dim3((unsigned)(nt * A.nsx * A.nsy)), dim3(SH::NTHR), SH::LDS, st, A);
-    return sn_check_launch();
+    if (A.g1_sums) return p1r_launch1<C, HW, 1>(A, nt, st);
+    return A.g1_scale ? p1r_launch1<C, HW, 2>(A, nt, st) : p1r_launch1<C, HW, 0>(A, nt, st);
 }
 
 }  // namespace
@@ -582,16 +629,19 @@ int sn_p1r_pool_blocks(int T, int h, int w) {
     return nsx * nsy;
 }
 
-int sn_p1r_launch(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se, void* stream) {
+int sn_p1r_launch(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se,
+                  const sn_phase1_opts* opt, void* stream) {
     sn_clear_error();
+    const bool sums = opt && opt->g1_sums;
     if (!s || !s->x || (s->C != 64 && s->C != 80) || s->mode < 0 || s->mode > 2 || s->T < 1 || s->h < 1 || s->w < 1 || !wt || !wt->wfrag1 || !wt->w3 ||
-        !wt->wgrp || !wt->wfrag2 || !g2 || (s->mode != 0 && !hw) || s->wrap < 0 || s->wrap > 2 || (s->wrap == 2 && s->mode != 0 && !s->halo)) return SN_EINVAL;
+        !wt->wgrp || !wt->wfrag2 || (!g2 && !sums) || (sums && !pool) || (s->mode != 0 && !hw) || s->wrap < 0 || s->wrap > 2 || (s->wrap == 2 && s->mode != 0 && !s->halo)) return SN_EINVAL;
     const int ncu = p1r_ncu();
     if (ncu < 1) return SN_ELAUNCH;
     P1RArgs A;
     A.x = (const bf16_t*)s->x; A.halo = (const bf16_t*)s->halo; A.hwb = (const bf16_t*)hw; A.T = s->T; A.h = s->h; A.w = s->w; A.mode = s->mode; A.wrap = s->wrap;
     A.wfrag1 = (const uint4*)wt->wfrag1; A.w3 = (const uint4*)wt->w3; A.wgrp = (const uint4*)wt->wgrp; A.wfrag2 = (const uint4*)wt->wfrag2;
     A.g2 = (bf16_t*)g2; A.pool = pool;
+    A.g1_scale = opt ? opt->g1_scale : nullptr; A.g1_sums = sums ? 1 : 0;
     A.se.ca = nullptr;
     if (se) {
         if (!pool || !se->wa || !se->wb || !se->ticket || !se->ca || se->c != s->C || se->cr < 1 || se->cr > 128) return SN_EINVAL;

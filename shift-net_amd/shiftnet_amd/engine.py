@@ -121,10 +121,10 @@ class Plan:
             u["w_toep5"] = self._dev(prep.pack_toeplitz(w5, 5))           # K3m: 5x5 on the matrix cores
         i += 1
         u["w_gate"] = self._dev(prep.pack_gate_gemm(sd[f"{pre}body.{i}.weight"], c))
-        if not V.denoise:      # fused phase 1 (sn_gsts_cab2_phase1 / sn_cab1_phase1): the deblur models (the denoisers' inner CALayer2 needs the global pool of g1)
+        if True:               # fused phase 1 (sn_gsts_cab2_phase1 / sn_cab1_phase1); the denoisers run it twice (inner CALayer2: sn_phase1_opts)
             args = (sd[f"{pre}body.0.weight"], sd[pre + "norm.weight"], sd[pre + "norm.bias"], sd[f"{pre}body.1.conv_2.weight"],
                     sd[f"{pre}body.{i - 1}.conv_1.weight"], sd[f"{pre}body.{i - 1}.conv_2.weight"], sd[f"{pre}body.{i}.weight"], c)
-            if c == 64 and not V.grouped_rep:      # layout 0: csrc/sn_phase1.hip, depthwise stencils on the VALU
+            if c == 64 and not V.grouped_rep and not V.denoise:      # layout 0: csrc/sn_phase1.hip, depthwise stencils on the VALU
                 d = {k: self._dev(v) for k, v in prep.pack_phase1(*args).items()}
                 d["desc"] = L.Phase1Weights(*(d[k].data_ptr() for k in ("wfrag1", "wfragx", "w3", "w5", "wfrag2")), None, 0)   # the tensors stay referenced in d
                 u["p1"] = d
@@ -313,7 +313,8 @@ class Engine:
     # sn_grp5_gemm_gate (g1 through HBM; what the denoisers always run).  SN_PHASE1 overrides it, e.g. for a checkpoint whose activations leave
     # the fp16 range the fused kernels carry `a`, g1 and r in (the chain keeps g1 in bf16).
     phase1 = os.environ.get("SN_PHASE1", "auto")
-    PHASE1_AUTO = {64: "r", 80: "r"}     # C = 64, 20 x 360 x 640, CAB1 / CAB2: "r" 565 / 696 us, "v" 826 / 725 us, chain 837 / 950 us (one box)
+    PHASE1_AUTO = {64: "r", 80: "r"}     # (the denoisers run the kernel twice: sums of g1 for the inner CALayer2, then the whole phase 1)
+    # C = 64, 20 x 360 x 640, CAB1 / CAB2: "r" 565 / 696 us, "v" 826 / 725 us, chain 837 / 950 us (one box)
     fused_cab_tail = True      # bf16 engine: always.  Engine32 (one kernel per reference module) runs conv, conv, pool, MLP, scale + residual instead
 
     def cab(self, pre: str, x: Act, extra: Optional[Act] = None) -> Act:
@@ -409,7 +410,9 @@ class Engine:
         mode1 = self.PHASE1_AUTO.get(c, "0") if self.phase1 == "auto" else self.phase1
         p1key = {"r": "p1r", "v": "p1"}.get(mode1)
         if p1key == "p1" and "p1" not in u:
-            p1key = "p1r"                                # the VALU kernel exists for C = 64 depthwise only
+            p1key = "p1r"                                # the VALU kernel exists for C = 64 depthwise without the inner CALayer2 only
+        if V.denoise and (not self.fold_se or T > self.MAX_TICKETS):
+            p1key = None                                 # the denoisers' two-pass phase 1 relies on the squeeze-excite tail for the inner scale
         fused = p1key is not None and p1key in u         # phase 1 in ONE kernel: neither a, g1 nor r leave the CU
         layout = 1 if p1key == "p1r" else 0
         mstencil = not V.grouped_rep                     # depthwise RepConv (C = 64): Toeplitz-MFMA 5x5 on a channel-planar g1
@@ -421,6 +424,10 @@ class Engine:
             nb2 = lib.sn_phase1_pool_blocks(T, h, w, layout)
             if nb2 < 1:
                 raise L.ShiftNetLibError(f"sn_phase1_pool_blocks failed with code {nb2}")
+            if V.denoise:
+                ca1 = torch.empty((T, c), dtype=torch.float32, device=self.dev)
+                if self._tickets is None:
+                    self._tickets = torch.zeros((self.MAX_TICKETS,), dtype=torch.int32, device=self.dev)
         else:
             g1 = (torch.empty((T, h, c, lib.sn_planar_pitch(w)), dtype=torch.bfloat16, device=self.dev) if mstencil else self._new(T, h, w, c))
             nb2 = lib.sn_dw5m_blocks(h, w) if mstencil else lib.sn_grp5_blocks(h, w)
@@ -457,10 +464,20 @@ class Engine:
                     q = P.cas[pre + "ca2"]
                     se = L.SeFold(q["wa"].data_ptr(), q["wb"].data_ptr(), q["c"], q["cr"], self._tickets.data_ptr(), ca2.data_ptr())
                     sep = C.byref(se)
+                opt = None
+                if V.denoise:      # inner CALayer2 on g1 (gshift_denoise1.py:224,257): pass 1 = the channel sums of g1 and, by the tail, its scale ca1
+                    q1 = P.cas[pre + "ca1"]
+                    se1 = L.SeFold(q1["wa"].data_ptr(), q1["wb"].data_ptr(), q1["c"], q1["cr"], self._tickets.data_ptr(), ca1.data_ptr())
+                    o1 = L.Phase1Opts(None, 1)
+                    fn1 = "sn_gsts_cab2_phase1" if mode else "sn_cab1_phase1"
+                    a1 = (C.byref(src), hw_ptr, wt, None, pool2.data_ptr(), C.byref(se1), C.byref(o1), st) if mode else \
+                         (C.byref(src), wt, None, pool2.data_ptr(), C.byref(se1), C.byref(o1), st)
+                    self._call(fn1, fn1 + "[g1 sums]", *a1)
+                    opt = C.byref(L.Phase1Opts(ca1.data_ptr(), 0))
                 if mode:
-                    self._call("sn_gsts_cab2_phase1", "sn_gsts_cab2_phase1", C.byref(src), hw_ptr, wt, g2.data_ptr(), pool2.data_ptr(), sep, st)
+                    self._call("sn_gsts_cab2_phase1", "sn_gsts_cab2_phase1", C.byref(src), hw_ptr, wt, g2.data_ptr(), pool2.data_ptr(), sep, opt, st)
                 else:
-                    self._call("sn_cab1_phase1", "sn_cab1_phase1", C.byref(src), wt, g2.data_ptr(), pool2.data_ptr(), sep, st)
+                    self._call("sn_cab1_phase1", "sn_cab1_phase1", C.byref(src), wt, g2.data_ptr(), pool2.data_ptr(), sep, opt, st)
                 folded = sep is not None
             else:
                 self._call("sn_ln_gemm_gate", "sn_ln_gemm_gate", C.byref(src), hw_ptr, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(),

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libshiftnet_hip.so")
 
 SN_F32, SN_F16, SN_BF16 = 0, 1, 2
 
-ABI_VERSION = 10     # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so from before a struct / signature change fails the check in load()
+ABI_VERSION = 11     # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so from before a struct / signature change fails the check in load()
 
 SYMBOLS = [          # include/shiftnet_hip.h, production ABI
     "sn_abi_version", "sn_selftest_mfma", "sn_ingest", "sn_conv2d", "sn_conv_pool_blocks", "sn_ca_mlp",
@@ -38,12 +38,18 @@ class SeFold(C.Structure):
     _fields_ = [("wa", C.c_void_p), ("wb", C.c_void_p), ("c", C.c_int), ("cr", C.c_int), ("ticket", C.c_void_p), ("ca", C.c_void_p)]
 
 
-def cab_phase1(lib, src: "UnitSrc", hw_ptr, wt: "Phase1Weights", g2_ptr, pool_ptr, stream, se: "SeFold" = None) -> int:
+class Phase1Opts(C.Structure):
+    """sn_phase1_opts: the denoisers' inner CALayer2 (pass 1: g1_sums = 1; pass 2: g1_scale = its scale [T][C] f32)."""
+    _fields_ = [("g1_scale", C.c_void_p), ("g1_sums", C.c_int)]
+
+
+def cab_phase1(lib, src: "UnitSrc", hw_ptr, wt: "Phase1Weights", g2_ptr, pool_ptr, stream, se: "SeFold" = None, opt: "Phase1Opts" = None) -> int:
     """sn_gsts_cab2_phase1 (src.mode 1 / 2) or sn_cab1_phase1 (mode 0)."""
     sep = C.byref(se) if se is not None else None
+    op = C.byref(opt) if opt is not None else None
     if src.mode:
-        return lib.sn_gsts_cab2_phase1(C.byref(src), hw_ptr, C.byref(wt), g2_ptr, pool_ptr, sep, stream)
-    return lib.sn_cab1_phase1(C.byref(src), C.byref(wt), g2_ptr, pool_ptr, sep, stream)
+        return lib.sn_gsts_cab2_phase1(C.byref(src), hw_ptr, C.byref(wt), g2_ptr, pool_ptr, sep, op, stream)
+    return lib.sn_cab1_phase1(C.byref(src), C.byref(wt), g2_ptr, pool_ptr, sep, op, stream)
 
 
 class ConvDesc(C.Structure):
@@ -120,8 +126,8 @@ def load() -> C.CDLL:
     lib.sn_grp5_gemm_gate.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.sn_grp5_blocks.argtypes = [ci, ci]
     lib.sn_phase1_pool_blocks.argtypes = [ci, ci, ci, ci]
-    lib.sn_gsts_cab2_phase1.argtypes = [C.POINTER(UnitSrc), vp, C.POINTER(Phase1Weights), vp, vp, C.POINTER(SeFold), vp]
-    lib.sn_cab1_phase1.argtypes = [C.POINTER(UnitSrc), C.POINTER(Phase1Weights), vp, vp, C.POINTER(SeFold), vp]
+    lib.sn_gsts_cab2_phase1.argtypes = [C.POINTER(UnitSrc), vp, C.POINTER(Phase1Weights), vp, vp, C.POINTER(SeFold), C.POINTER(Phase1Opts), vp]
+    lib.sn_cab1_phase1.argtypes = [C.POINTER(UnitSrc), C.POINTER(Phase1Weights), vp, vp, C.POINTER(SeFold), C.POINTER(Phase1Opts), vp]
     lib.sn_gsts_cab2_phase2.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp, vp]
     lib.sn_cab1_phase2.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp, vp]
     lib.sn_ingest_u8.argtypes = [vp, vp, ci, ci, ci, ci, vp]

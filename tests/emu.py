@@ -401,12 +401,13 @@ def cab_phase1(x, hwb, pk, mode, wrap):
     return g2.reshape(T, h, w, C), g2.sum(1)
 
 
-def cab_phase1r(x, hwb, pk, mode, wrap):
+def cab_phase1r(x, hwb, pk, mode, wrap, ca_in=None, want_g1_sums=False):
     """Role-split fused phase 1 (csrc/sn_phase1r.hip) on whole frames, C = 64 / 80: the stager's two-pass LayerNorm + constant-one bias slots,
     first 1x1 with wave-paired rows (wave q, lane group g, register r <-> channel 16 q + 4 g + r), packed-fp16 3x3 table addressed by
     (wave, lane group, tap, word), RepConv as the x-pair Toeplitz GEMM (row = oc + 8 xp, k-slot -> tap through prep.p1r_tap), fp16 second
     1x1.  Strips, rings and lane <-> pixel maps are index arithmetic of the kernel and not emulated; everything the HOST prepares
-    (prep.pack_phase1r) is decoded exactly as the kernel addresses it.  x [T,h,w,C], hwb [T,h,w,C/2] or None -> (g2 [T,h,w,C], sums [T,C])."""
+    (prep.pack_phase1r) is decoded exactly as the kernel addresses it.  x [T,h,w,C], hwb [T,h,w,C/2] or None -> (g2 [T,h,w,C], sums [T,C]).
+    Denoisers (sn_phase1_opts): want_g1_sums -> the channel sums [T,C] of g1 (pass 1); ca_in [T,C] -> g1 scaled by it before the RepConv (pass 2)."""
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "shift-net_amd"))
     from shiftnet_amd import prep
@@ -459,6 +460,10 @@ def cab_phase1r(x, hwb, pk, mode, wrap):
             o += k3[:, ty * 3 + tx][None, None, None, :] * ap[:, ty:ty + h, tx:tx + w]
     o = o.astype(np.float16).astype(np.float32)
     g1 = (o[..., :C] * o[..., C:]).astype(np.float16).astype(np.float32)          # carries P1_G1_SCALE
+    if want_g1_sums:
+        return g1.reshape(T, h * w, C).sum(1) * 16.0
+    if ca_in is not None:
+        g1 = (g1 * np.asarray(ca_in, np.float32).astype(np.float16).astype(np.float32)[:, None, None, :]).astype(np.float16).astype(np.float32)
     # RepConv: pairs of pixels (cx, cx + 1), cx = -3, -1, 1, ... (region column 0 is image column x0 - 3)
     npair = (w + 3 + 1) // 2 + 1
     gp = np.zeros((T, h + 4, 2 * npair + 8, C), np.float32)

@@ -776,3 +776,58 @@ def test_cli_clip_parallel_two_ranks_log_the_single_process_lines(tmp_path):
     assert len(a) == 20 and [p.name for p in a] == [p.name for p in b]
     for pa, pb in zip(a, b):
         assert pa.read_bytes() == pb.read_bytes(), pa.name
+
+
+@pytest.mark.parametrize("name", ["gshift_denoise1", "gshift_denoise2"])
+@pytest.mark.parametrize("T,h,w", [(2, 13, 70), (3, 40, 200), (2, 97, 130)])
+def test_cab_phase1_fused_kernel_denoisers_two_passes(T, h, w, name, engines):
+    """The denoisers' phase 1 on the role-split kernel (csrc/sn_phase1r.hip, sn_phase1_opts): pass 1 leaves the channel sums of g1 and -- through
+    the squeeze-excite tail -- the scale of the inner CALayer2 (gshift_denoise1.py:224,257; gshift_denoise2.py:194,227), pass 2 the block's g2 with
+    g1 scaled before the RepConv.  Against the reference's g1 sums, scale and g2, CAB1 and a forward CAB2; several strips and row segments."""
+    from shiftnet_amd import lib as L
+    eng, sd = engines(name)
+    V = O.VARIANTS[name]
+    C = V.c1
+    x = bf(torch.from_numpy(synth.unit_noise((T, C, h, w), seed=101 + h)))
+    xd = to_dev(x)
+    st = torch.cuda.current_stream().cuda_stream
+    groups = C // 8 if V.grouped_rep else C
+    blk = "stage1.decoder_level1."
+    tickets = torch.zeros((T,), dtype=torch.int32, device=DEV)
+    for mode, unit in ((0, "encoder_level1.1."), (1, "encoder_level1.0.")):
+        pre = blk + unit
+        with torch.no_grad():
+            if mode:
+                u = O.gsts_gather(x, False, V.wrap)
+                hw = bf(O._conv(sd, pre + "conv1.", u[:, C:], groups=C // 2))
+                v = O.layer_norm_2d(torch.cat((u[:, :C], hw), 1), sd[pre + "norm.weight"], sd[pre + "norm.bias"])
+                hwd = to_dev(hw)
+            else:
+                v = O.layer_norm_2d(x, sd[pre + "norm.weight"], sd[pre + "norm.bias"])
+                hwd = None
+            a = O._conv(sd, f"{pre}body.0.", v)
+            a = O._conv(sd, f"{pre}body.1.conv_2.", a, groups=a.shape[1]) + a
+            a1, a2 = a.chunk(2, dim=1)
+            g1 = a1 * a2
+            ca_ref = torch.sigmoid(O._conv(sd, f"{pre}body.3.conv_du.2.", torch.relu(O._conv(sd, f"{pre}body.3.conv_du.0.", g1.mean((2, 3), keepdim=True))))).reshape(T, C)
+            b1, b2 = O._conv(sd, f"{pre}body.5.", O._rep_conv(sd, f"{pre}body.4.", O.channel_attention(sd, f"{pre}body.3.", g1), groups=groups)).chunk(2, dim=1)
+            ref = b1 * torch.sigmoid(b2)
+        p1, q1 = eng.P.units[pre]["p1r"], eng.P.cas[pre + "ca1"]
+        src = L.UnitSrc(xd.data_ptr(), T, h, w, C, mode, 0)
+        nblk = eng.lib.sn_phase1_pool_blocks(T, h, w, 1)
+        pool = torch.full((T, nblk, C), float("nan"), dtype=torch.float32, device=DEV)
+        ca1 = torch.full((T, C), float("nan"), dtype=torch.float32, device=DEV)
+        se1 = L.SeFold(q1["wa"].data_ptr(), q1["wb"].data_ptr(), q1["c"], q1["cr"], tickets.data_ptr(), ca1.data_ptr())
+        hp = hwd.data_ptr() if hwd is not None else None
+        L.check(L.cab_phase1(eng.lib, src, hp, p1["desc"], None, pool.data_ptr(), st, se1, L.Phase1Opts(None, 1)), "phase 1, g1 sums")
+        torch.cuda.synchronize()
+        sums, rs = pool.sum(1).cpu(), g1.sum((2, 3))
+        assert torch.isfinite(sums).all() and (sums - rs).abs().max().item() <= 1e-2 * max(1.0, rs.abs().max().item()), (name, mode, (sums - rs).abs().max().item())
+        assert (ca1.cpu() - ca_ref).abs().max().item() <= 2e-3, (name, mode, (ca1.cpu() - ca_ref).abs().max().item())
+        assert int(tickets.abs().sum()) == 0
+        g2 = torch.full((T, h, w, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+        L.check(L.cab_phase1(eng.lib, src, hp, p1["desc"], g2.data_ptr(), pool.data_ptr(), st, None, L.Phase1Opts(ca1.data_ptr(), 0)), "phase 1, pass 2")
+        check(f"phase1_denoise_g2_{name}_{mode}_{T}x{h}x{w}", to_cpu(g2, C), ref, 1.2e-2)
+        s2 = pool.sum(1).cpu()
+        r2 = ref.sum((2, 3))
+        assert (s2 - r2).abs().max().item() <= 1e-2 * max(1.0, r2.abs().max().item())

@@ -366,3 +366,36 @@ def test_phase1r_emulation_matches_oracle(name, reverse):
         got, _ = emu.cab_phase1r(nhwc(x), None, pk(q), 0, V.wrap)
         err = (nchw(got, C) - ref).abs().max().item()
         assert err < 0.02 * max(1.0, ref.abs().max().item()), ("cab1", err)
+
+
+@pytest.mark.parametrize("name", ["gshift_denoise1", "gshift_denoise2"])
+def test_phase1r_emulation_of_the_denoisers_two_passes(name):
+    """The denoisers' inner CALayer2 on g1 (gshift_denoise1.py:224,257) through the role-split kernel's two passes (sn_phase1_opts): pass 1 =
+    channel sums of g1 -> the layer's scale (the reference's conv_du MLP on the mean); pass 2 = g1 times that scale -> RepConv -> 1x1 -> gate2.
+    emu.cab_phase1r x prep.pack_phase1r against the reference's g2 for CAB1."""
+    V = O.VARIANTS[name]
+    sd = synth_state_dict(name)
+    C, T, h, w = V.c1, 2, 6, 13
+    x = torch.from_numpy(synth.unit_noise((T, C, h, w), seed=31)).bfloat16().float()
+    q = "stage1.decoder_level1.encoder_level1.1."
+    groups = C // 8 if V.grouped_rep else C
+    pk = prep.pack_phase1r(sd[f"{q}body.0.weight"], sd[q + "norm.weight"], sd[q + "norm.bias"], sd[f"{q}body.1.conv_2.weight"],
+                           sd[f"{q}body.4.conv_1.weight"], sd[f"{q}body.4.conv_2.weight"], sd[f"{q}body.5.weight"], C)
+    with torch.no_grad():
+        v = O.layer_norm_2d(x, sd[q + "norm.weight"], sd[q + "norm.bias"])
+        a = O._conv(sd, f"{q}body.0.", v)
+        a = O._conv(sd, f"{q}body.1.conv_2.", a, groups=a.shape[1]) + a
+        a1, a2 = a.chunk(2, dim=1)
+        g1 = a1 * a2
+        g1s = O.channel_attention(sd, f"{q}body.3.", g1)
+        b1, b2 = O._conv(sd, f"{q}body.5.", O._rep_conv(sd, f"{q}body.4.", g1s, groups=groups)).chunk(2, dim=1)
+        ref = b1 * torch.sigmoid(b2)
+        sums = emu.cab_phase1r(nhwc(x), None, pk, 0, V.wrap, want_g1_sums=True)
+        rs = g1.sum((2, 3)).numpy()
+        assert np.abs(sums - rs).max() <= 2e-2 * max(1.0, np.abs(rs).max())
+        mean = torch.from_numpy(sums / (h * w)).float()
+        hid = torch.relu(mean @ sd[f"{q}body.3.conv_du.0.weight"].reshape(-1, C).T)
+        ca = torch.sigmoid(hid @ sd[f"{q}body.3.conv_du.2.weight"].reshape(C, -1).T)
+        got, _ = emu.cab_phase1r(nhwc(x), None, pk, 0, V.wrap, ca_in=ca.numpy())
+        err = (nchw(got, C) - ref).abs().max().item()
+        assert err < 0.02 * max(1.0, ref.abs().max().item()), (name, err)

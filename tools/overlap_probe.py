@@ -26,8 +26,8 @@ def main():
     libs = {"product": lib}
     if len(sys.argv) > 1 and os.path.exists(sys.argv[1]):
         l1 = C.CDLL(sys.argv[1]); vp, ci = C.c_void_p, C.c_int
-        l1.sn_gsts_cab2_phase1.argtypes = [C.POINTER(L.UnitSrc), vp, C.POINTER(L.Phase1Weights), vp, vp, C.POINTER(L.SeFold), vp]
-        l1.sn_cab1_phase1.argtypes = [C.POINTER(L.UnitSrc), C.POINTER(L.Phase1Weights), vp, vp, C.POINTER(L.SeFold), vp]
+        l1.sn_gsts_cab2_phase1.argtypes = [C.POINTER(L.UnitSrc), vp, C.POINTER(L.Phase1Weights), vp, vp, C.POINTER(L.SeFold), C.POINTER(L.Phase1Opts), vp]
+        l1.sn_cab1_phase1.argtypes = [C.POINTER(L.UnitSrc), C.POINTER(L.Phase1Weights), vp, vp, C.POINTER(L.SeFold), C.POINTER(L.Phase1Opts), vp]
         l1.sn_phase1_pool_blocks.argtypes = [ci, ci, ci]
         libs["one workgroup per CU"] = l1
     T, h, w, c = 10, 360, 640, 64

@@ -62,8 +62,8 @@ def run(variants):
                 continue
             lib = C.CDLL(lib_path(vname))
             vp, ci = C.c_void_p, C.c_int
-            lib.sn_gsts_cab2_phase1.argtypes = [C.POINTER(L.UnitSrc), vp, C.POINTER(L.Phase1Weights), vp, vp, C.POINTER(L.SeFold), vp]
-            lib.sn_cab1_phase1.argtypes = [C.POINTER(L.UnitSrc), C.POINTER(L.Phase1Weights), vp, vp, C.POINTER(L.SeFold), vp]
+            lib.sn_gsts_cab2_phase1.argtypes = [C.POINTER(L.UnitSrc), vp, C.POINTER(L.Phase1Weights), vp, vp, C.POINTER(L.SeFold), C.POINTER(L.Phase1Opts), vp]
+            lib.sn_cab1_phase1.argtypes = [C.POINTER(L.UnitSrc), C.POINTER(L.Phase1Weights), vp, vp, C.POINTER(L.SeFold), C.POINTER(L.Phase1Opts), vp]
             lib.sn_phase1_pool_blocks.argtypes = [ci, ci, ci]
             nblk = lib.sn_phase1_pool_blocks(T, h, w)
             pool = torch.zeros((T, nblk, Cc), dtype=torch.float32, device=dev)

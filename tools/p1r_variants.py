@@ -67,16 +67,16 @@ def time_all(names):
                 lib = C.CDLL(path)
                 vp, ci = C.c_void_p, C.c_int
                 lib.sn_phase1_pool_blocks.argtypes = [ci, ci, ci, ci]
-                lib.sn_gsts_cab2_phase1.argtypes = [C.POINTER(L.UnitSrc), vp, C.POINTER(L.Phase1Weights), vp, vp, C.POINTER(L.SeFold), vp]
-                lib.sn_cab1_phase1.argtypes = [C.POINTER(L.UnitSrc), C.POINTER(L.Phase1Weights), vp, vp, C.POINTER(L.SeFold), vp]
+                lib.sn_gsts_cab2_phase1.argtypes = [C.POINTER(L.UnitSrc), vp, C.POINTER(L.Phase1Weights), vp, vp, C.POINTER(L.SeFold), C.POINTER(L.Phase1Opts), vp]
+                lib.sn_cab1_phase1.argtypes = [C.POINTER(L.UnitSrc), C.POINTER(L.Phase1Weights), vp, vp, C.POINTER(L.SeFold), C.POINTER(L.Phase1Opts), vp]
                 nb = lib.sn_phase1_pool_blocks(T, h, w, 1)
                 pool = torch.zeros((T, nb, Cc), dtype=torch.float32, device=dev)
                 res = []
                 for mode, unit in ((0, "encoder_level1.1."), (1, "encoder_level1.0.")):
                     u = P.units["stage1.decoder_level1." + unit]["p1r"]
                     src = L.UnitSrc(xd.data_ptr(), T, h, w, Cc, mode, 0)
-                    f = (lambda: lib.sn_gsts_cab2_phase1(C.byref(src), hwb.data_ptr(), C.byref(u["desc"]), g2.data_ptr(), pool.data_ptr(), None, st)) if mode else \
-                        (lambda: lib.sn_cab1_phase1(C.byref(src), C.byref(u["desc"]), g2.data_ptr(), pool.data_ptr(), None, st))
+                    f = (lambda: lib.sn_gsts_cab2_phase1(C.byref(src), hwb.data_ptr(), C.byref(u["desc"]), g2.data_ptr(), pool.data_ptr(), None, None, st)) if mode else \
+                        (lambda: lib.sn_cab1_phase1(C.byref(src), C.byref(u["desc"]), g2.data_ptr(), pool.data_ptr(), None, None, st))
                     for _ in range(2):
                         assert f() == 0
                     torch.cuda.synchronize()
