@@ -161,12 +161,19 @@ __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const Xcd
 template <int C, int NT>
 __global__ __launch_bounds__(256, 3)
 void scale_gemm_res_kernel(const UnitK U, const bf16_t* __restrict__ g2, const float* __restrict__ ca,
-                           const uint4* __restrict__ wfrag, const float* __restrict__ bias, bf16_t* y) {
+                           const uint4* __restrict__ wfrag, const float* __restrict__ bias, bf16_t* y, const int nchunk, const int nfr) {
     constexpr int CH = C / 2, KS = (C + 31) / 32, MT = C / 16;
     const int lane = threadIdx.x & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
-    const int t = U.t0 + blockIdx.y, hw = U.h * U.w;
+    // Workgroup -> (pixel chunk, frame) with the FRAMES of one chunk back to back on ONE XCD (workgroup b runs on XCD b % 8): the rolled shortcut
+    // of a CAB2 is the upper half-channels of frame t-1 and the lower ones of frame t, i.e. 64 / 80-byte halves of 128-byte lines whose other half
+    // is read by the workgroup of the neighbouring frame -- with the natural (chunk fastest, frame slowest) order that workgroup ran a whole frame
+    // later on whatever XCD, and every line came from HBM twice (PMC round 4: 1.17x the kernel's bytes; the kernel is HBM-bound).
+    // (items = (chunk, frame), frame fastest; XCD k takes the k-th contiguous eighth of the item list: equal load)
+    const int nitem = nchunk * nfr, per = (nitem + 7) >> 3, item = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (item >= nitem) return;
+    const int chunk = item / nfr, t = U.t0 + (item - chunk * nfr), hw = U.h * U.w;
     const SnSlabs<bf16_t> sl = unit_slabs(U, t);
-    const int ibase = blockIdx.x * (64 * NT) + wv * (16 * NT);
+    const int ibase = chunk * (64 * NT) + wv * (16 * NT);
     const int c0 = g * 4 * MT;                   // lane (g,p) owns channels [c0, c0 + 4 MT): one contiguous 8*MT-byte run of the shortcut and of y
     const bf16_t* const sbase = c0 < CH ? sl.p0 + c0 : sl.p1 + c0 - CH;
     const int sstr = c0 < CH ? sl.s0 : sl.s1;                                  // pixel stride of this lane's half (C, or C/2 for a halo half-frame)
@@ -286,9 +293,10 @@ int cab_phase2(const sn_unit_src* s, const void* g2, const float* ca, const void
     const int npx = s->h * s->w;
     constexpr int PXWG = 64 * SN_K4_NT;
     SN_FRAME_RANGE(s, t0, nt);
-    dim3 grid((npx + PXWG - 1) / PXWG, nt);
-    if (s->C == 64) hipLaunchKernelGGL((scale_gemm_res_kernel<64, SN_K4_NT>), grid, dim3(256), 0, (hipStream_t)stream, to_k(s), (const bf16_t*)g2, ca, (const uint4*)wfrag, bias, (bf16_t*)y);
-    else hipLaunchKernelGGL((scale_gemm_res_kernel<80, SN_K4_NT>), grid, dim3(256), 0, (hipStream_t)stream, to_k(s), (const bf16_t*)g2, ca, (const uint4*)wfrag, bias, (bf16_t*)y);
+    const int nchunk = (npx + PXWG - 1) / PXWG;
+    dim3 grid((unsigned)(8 * ((nchunk * nt + 7) / 8)));
+    if (s->C == 64) hipLaunchKernelGGL((scale_gemm_res_kernel<64, SN_K4_NT>), grid, dim3(256), 0, (hipStream_t)stream, to_k(s), (const bf16_t*)g2, ca, (const uint4*)wfrag, bias, (bf16_t*)y, nchunk, nt);
+    else hipLaunchKernelGGL((scale_gemm_res_kernel<80, SN_K4_NT>), grid, dim3(256), 0, (hipStream_t)stream, to_k(s), (const bf16_t*)g2, ca, (const uint4*)wfrag, bias, (bf16_t*)y, nchunk, nt);
     return sn_check_launch();
 }
 }  // namespace

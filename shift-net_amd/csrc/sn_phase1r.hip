@@ -46,7 +46,7 @@ typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
 struct P1RArgs {
     const bf16_t* x; const bf16_t* halo; const bf16_t* hwb;
-    int T, h, w, mode, wrap, t0;
+    int T, h, w, mode, wrap, t0, nfr;
     const uint4* wfrag1; const uint4* w3; const uint4* wgrp; const uint4* wfrag2;
     bf16_t* g2; float* pool;
     int nsx, nsy, seg, vw;
@@ -155,7 +155,13 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
     char* const lds_r = smem + SH::OFF_R;
     char* const lds_o = smem + SH::OFF_O;
     const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
-    const int b = blockIdx.x, sx = b % A.nsx, sy = (b / A.nsx) % A.nsy, t = A.t0 + b / (A.nsx * A.nsy);
+    // workgroup -> (strip, segment, frame) with the FRAMES of one (strip, segment) back to back on ONE XCD (workgroup b runs on XCD b % 8): the
+    // half-channel roll of a CAB2 reads 64- / 80-byte halves of 128-byte lines whose other half belongs to the neighbouring frame's workgroup;
+    // frame-major order sent every such line over the fabric twice (PMC: CAB2 1.59x its bytes, CAB1 1.09x)
+    // (items = (strip-segment, frame) with the frame fastest; XCD k takes the k-th contiguous eighth of the item list: equal load, neighbours in t adjacent)
+    const int nst = A.nsx * A.nsy, nitem = nst * A.nfr, per = (nitem + 7) >> 3, item = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || item >= nitem) return;               // workgroup-uniform (padding of the last eighth)
+    const int si = item / A.nfr, sx = si % A.nsx, sy = si / A.nsx, t = A.t0 + (item - si * A.nfr);
     const int x0 = sx * A.vw, Y0 = sy * A.seg, Y1 = Y0 + A.seg < A.h ? Y0 + A.seg : A.h;
     if (Y0 >= A.h) return;                                                    // workgroup-uniform
     const int h = A.h, w = A.w, hw = h * w;
@@ -609,7 +615,8 @@ int p1r_launch1(P1RArgs& A, int nt, hipStream_t st) {
     using SH = P1RShape<C, HW>;
     if (hipFuncSetAttribute((const void*)cab_phase1r_kernel<C, HW, ICA>, hipFuncAttributeMaxDynamicSharedMemorySize, SH::LDS) != hipSuccess) return SN_ELAUNCH;
     sn_clear_error();
-    hipLaunchKernelGGL((cab_phase1r_kernel<C, HW, ICA>), dim3((unsigned)(nt * A.nsx * A.nsy)), dim3(SH::NTHR), SH::LDS, st, A);
+    A.nfr = nt;
+    hipLaunchKernelGGL((cab_phase1r_kernel<C, HW, ICA>), dim3((unsigned)(8 * ((A.nsx * A.nsy * nt + 7) / 8))), dim3(SH::NTHR), SH::LDS, st, A);
     return sn_check_launch();
 }
 template <int C, bool HW>
