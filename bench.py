@@ -105,8 +105,6 @@ def kernel_alg_bytes(fn, meta):
         _, T, ho, wo, cin, co, k, stride, in_mode, out_mode = meta[:10]
         pin = T * ho * wo * stride * stride / (4 if in_mode == 1 else 1)
         return 4 * (pin * cin + T * ho * wo * (co // 4 if out_mode == 1 else co))
-    if meta and meta[0] == "cabf":             # fused dense CAB: passes over the [T][h][w][cs] tensor (statistics 1, scale 0, fused 2 or 3)
-        return meta[1] * meta[2] * meta[3] * meta[4] * 2 * meta[5]
     if meta and meta[0] == "naf":
         _, T, h, w, c, mode = meta
         px = T * h * w * 2

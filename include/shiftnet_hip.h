@@ -229,33 +229,6 @@ int sn_gsts_cab2_phase2(const sn_unit_src* s, const void* g2, const float* ca, c
 int sn_cab1_phase2(const sn_unit_src* s, const void* g2, const float* ca, const void* wfrag, const float* bias, void* y, void* stream);
 
 
-/* ---- fused dense CAB for the narrow CABs (c <= 24), csrc/sn_cabf.hip -----------------------------------------------------------------------
- * out = x + ca * body[2](PReLU(body[0](x))) [+ res2]   (CAB, gshift_deblur1.py:141-156) with `mid` kept in LDS: three tensor passes per CAB
- * (statistics: read x; fused: read x, write out) instead of the five of two sn_conv2d launches.
- *   sn_cabf_stats : conv1 + PReLU only; part [T][sn_cabf_blocks(T,h,w)][9][16 mt] f32 receives per workgroup the sums of mid over its pixels
- *                   (k = 0 total, 1 / 2 first / last row, 3 / 4 first / last column) and the four corner pixels (k = 5..8, written by their owners);
- *   sn_cabf_ca    : the CALayer scale ca [T][cpad] from those sums (closed form through body[2]'s weights w2 [c][9][w2pad] f32, as sn_cab_ca);
- *   sn_cabf       : the fused block.  x, out, res2: NHWC bf16 [T][h][w][cs], cs in {16, 24}; wfrag1 / wfrag2 / bias: the operands of sn_conv2d
- *                   (prep.pack_conv) of body[0] / body[2]; out must not alias x.
- * sn_cabf_supported(c): 1 if a CAB of c channels can take this path. */
-typedef struct sn_cabf_desc {
-    const void* x;
-    const void* res2;      /* optional second residual (the "+ shortcut" folded into the last CAB of a TFR_UNet) or NULL */
-    void* out;
-    const void* wfrag1; const void* wfrag2;
-    const float* bias1; const float* bias2;   /* NULL: no bias */
-    float prelu;           /* slope of the shared PReLU */
-    const float* ca;       /* [T][16 mt] (sn_cabf only) */
-    float* part;           /* sn_cabf_stats only */
-    int T, h, w, cs, mt;
-} sn_cabf_desc;
-int sn_cabf_supported(int c);
-int sn_cabf_blocks(int T, int h, int w);
-int sn_cabf_stats(const sn_cabf_desc* d, void* stream);
-int sn_cabf_ca(const float* part, int T, int h, int w, int cpad, int c, int cr, const float* w2, int w2pad, const float* wa, const float* wb,
-               float* ca, void* stream);
-int sn_cabf(const sn_cabf_desc* d, void* stream);
-
 /* ---- fp32-storage path (csrc/sn_f32.hip) -----------------------------------------------------------------------
  * The arithmetic type upstream runs the "+" denoiser in (inference/test_denoise.py:83-85: the .half() is commented out)
  * and the validation build of the engine: activations fp32 NHWC [T][H][W][C] with an explicit pixel stride `cs`

@@ -33,11 +33,6 @@ class Act:
         return tuple(self.t.shape)  # type: ignore[return-value]
 
 
-def cs_ok(a: "Act") -> bool:
-    """The fused CAB takes tensors whose storage width is the padded logical width (no channel-slice views)."""
-    return a.t.is_contiguous() and a.t.shape[3] == prep.ceil8(a.c) and a.t.shape[3] in (16, 24)
-
-
 def _dtype_code(dt: torch.dtype) -> int:
     return {torch.float32: L.SN_F32, torch.float16: L.SN_F16, torch.bfloat16: L.SN_BF16}[dt]
 
@@ -328,8 +323,6 @@ class Engine:
         The CALayer scale is known BEFORE the second conv (its pooled input is linear in `mid`, sn_cab_ca), so scale and residual
         (and the optional second residual `extra`) are applied in conv2's epilogue: two sn_conv2d launches, 5 tensor passes.
         (A fused CAB with `mid` in LDS -- 3 passes -- was built and measured slower in round 2)"""
-        if self.fused_cab and self.fused_cab_tail and cs_ok(x) and self.lib.sn_cabf_supported(x.c):
-            return self._cab_fused(pre, x, extra)
         if self.fused_cab_tail:
             p = self.P.cas[pre + "CA"]
             T, h, w, cs = x.dims
@@ -345,35 +338,6 @@ class Engine:
         r = self.conv(pre + "body.0", [x], prelu=self.P.scalar(pre + "body.1.weight"))
         r, pool, npix = self.conv(pre + "body.2", [r], pool=True)
         return self.scale_residual(r, x, self.ca_mlp(pre + "CA", pool, npix), extra)
-
-    # Narrow CABs (c <= 24) in three tensor passes with `mid` in LDS (csrc/sn_cabf.hip): statistics pass -> CALayer scale -> fused conv / PReLU / conv /
-    # scale / residual.  SN_FUSED_CAB=0 keeps the two sn_conv2d launches for them as well (A/B).
-    fused_cab = os.environ.get("SN_FUSED_CAB", "1") != "0"
-
-    def _cab_fused(self, pre: str, x: Act, extra: Optional[Act]) -> Act:
-        P, lib = self.P, self.lib
-        p1, p2, q = P.convs[pre + "body.0"], P.convs[pre + "body.2"], P.cas[pre + "CA"]
-        T, h, w, cs = x.dims
-        mt = int(p1["mt"])
-        assert int(p2["mt"]) == mt and int(p1["cs_in"]) == cs and int(p2["cs_in"]) == cs and (extra is None or extra.dims == x.dims)
-        nblk = lib.sn_cabf_blocks(T, h, w)
-        if nblk < 1:
-            raise L.ShiftNetLibError(f"sn_cabf_blocks failed with code {nblk}")
-        part = torch.empty((T, nblk, 9, 16 * mt), dtype=torch.float32, device=self.dev)
-        ca = torch.empty((T, 16 * mt), dtype=torch.float32, device=self.dev)
-        out = self._new(T, h, w, cs)
-        d = L.CabfDesc(x.t.data_ptr(), extra.t.data_ptr() if extra is not None else None, out.data_ptr(), p1["wfrag"].data_ptr(), p2["wfrag"].data_ptr(),
-                       p1["bias"].data_ptr() if p1["bias"] is not None else None, p2["bias"].data_ptr() if p2["bias"] is not None else None,
-                       self.P.scalar(pre + "body.1.weight"), ca.data_ptr(), part.data_ptr(), T, h, w, cs, mt)
-        st = self._stream()
-        self._meta = ("cabf", T, h, w, cs, 1)
-        self._call("sn_cabf_stats", f"sn_cabf_stats[{pre}]", C.byref(d), st)
-        self._meta = ("cabf", T, h, w, cs, 0)
-        self._call("sn_cabf_ca", f"sn_cabf_ca[{pre}]", part.data_ptr(), T, h, w, 16 * mt, q["c"], q["cr"], q["w2"].data_ptr(), int(q["w2"].shape[2]),
-                   q["wa"].data_ptr(), q["wb"].data_ptr(), ca.data_ptr(), st)
-        self._meta = ("cabf", T, h, w, cs, 2 if extra is None else 3)
-        self._call("sn_cabf", f"sn_cabf[{pre}]", C.byref(d), st)
-        return Act(out, x.c)
 
     def _wrap_flag(self, mode: int, circular: bool) -> int:
         """sn_unit_src.wrap: 0 keep the window's boundary frame, 1 circular, 2 the neighbour frame's half arrives from the adjacent rank."""

@@ -24,7 +24,6 @@ SYMBOLS = [          # include/shiftnet_hip.h, production ABI
     "sn_ingest_u8", "sn_egress_blocks", "sn_egress_u8", "sn_ssim_blocks", "sn_ssim_u8",
     "sn32_conv2d", "sn32_gsts_gather", "sn32_layernorm", "sn32_gate", "sn32_gate_sum", "sn32_chan_sum", "sn32_scale_residual", "sn32_ingest",
     "sn_ln_gemm_gate", "sn_lngate_blocks", "sn_grp5_gemm_gate", "sn_grp5_blocks", "sn_gsts_cab2_phase1", "sn_cab1_phase1", "sn_phase1_pool_blocks",
-    "sn_cabf_supported", "sn_cabf_blocks", "sn_cabf_stats", "sn_cabf_ca", "sn_cabf",
 ]
 
 
@@ -51,13 +50,6 @@ def cab_phase1(lib, src: "UnitSrc", hw_ptr, wt: "Phase1Weights", g2_ptr, pool_pt
     if src.mode:
         return lib.sn_gsts_cab2_phase1(C.byref(src), hw_ptr, C.byref(wt), g2_ptr, pool_ptr, sep, op, stream)
     return lib.sn_cab1_phase1(C.byref(src), C.byref(wt), g2_ptr, pool_ptr, sep, op, stream)
-
-
-class CabfDesc(C.Structure):
-    """sn_cabf_desc: the fused dense CAB (csrc/sn_cabf.hip)."""
-    _fields_ = [("x", C.c_void_p), ("res2", C.c_void_p), ("out", C.c_void_p), ("wfrag1", C.c_void_p), ("wfrag2", C.c_void_p),
-                ("bias1", C.c_void_p), ("bias2", C.c_void_p), ("prelu", C.c_float), ("ca", C.c_void_p), ("part", C.c_void_p),
-                ("T", C.c_int), ("h", C.c_int), ("w", C.c_int), ("cs", C.c_int), ("mt", C.c_int)]
 
 
 class ConvDesc(C.Structure):
@@ -136,11 +128,6 @@ def load() -> C.CDLL:
     lib.sn_phase1_pool_blocks.argtypes = [ci, ci, ci, ci]
     lib.sn_gsts_cab2_phase1.argtypes = [C.POINTER(UnitSrc), vp, C.POINTER(Phase1Weights), vp, vp, C.POINTER(SeFold), C.POINTER(Phase1Opts), vp]
     lib.sn_cab1_phase1.argtypes = [C.POINTER(UnitSrc), C.POINTER(Phase1Weights), vp, vp, C.POINTER(SeFold), C.POINTER(Phase1Opts), vp]
-    lib.sn_cabf_supported.argtypes = [ci]
-    lib.sn_cabf_blocks.argtypes = [ci, ci, ci]
-    lib.sn_cabf_stats.argtypes = [C.POINTER(CabfDesc), vp]
-    lib.sn_cabf_ca.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp]
-    lib.sn_cabf.argtypes = [C.POINTER(CabfDesc), vp]
     lib.sn_gsts_cab2_phase2.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp, vp]
     lib.sn_cab1_phase2.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp, vp]
     lib.sn_ingest_u8.argtypes = [vp, vp, ci, ci, ci, ci, vp]

@@ -831,32 +831,3 @@ def test_cab_phase1_fused_kernel_denoisers_two_passes(T, h, w, name, engines):
         s2 = pool.sum(1).cpu()
         r2 = ref.sum((2, 3))
         assert (s2 - r2).abs().max().item() <= 1e-2 * max(1.0, r2.abs().max().item())
-
-
-@pytest.mark.parametrize("name,pre,c", [("gshift_deblur2", "orb1.encoder_level1.0.", 14), ("gshift_deblur2", "orb1.encoder_level2.1.", 18),
-                                        ("gshift_deblur2", "orb1.decoder_level3.2.", 22), ("gshift_deblur1", "orb1.decoder_level1.0.", 24)])
-@pytest.mark.parametrize("T,h,w", [(2, 97, 130), (1, 5, 200), (2, 184, 70), (3, 1, 1)])
-def test_cab_fused_row_walker(name, pre, c, T, h, w, engines):
-    """The fused dense CAB (csrc/sn_cabf.hip: statistics pass -> closed-form CALayer scale -> conv / PReLU / conv / scale / residuals with `mid` in LDS)
-    against the oracle's CAB (gshift_deblur1.py:141-156) and against the two-kernel path it replaces: several strips (ragged last one) and row segments,
-    a map narrower than a strip, a one-pixel map (all four corners coincide), with and without the second residual; pad channels stay zero."""
-    eng, sd = engines(name)
-    assert eng.lib.sn_cabf_supported(c) == 1
-    x = bf(torch.from_numpy(synth.unit_noise((T, c, h, w), seed=111 + h)))
-    e = bf(torch.from_numpy(synth.unit_noise((T, c, h, w), seed=112 + w)))
-    ref = O.cab(sd, pre, x)
-    old = eng.fused_cab
-    try:
-        eng.fused_cab = True
-        out = eng.cab(pre, act(to_dev(x), c))
-        out2 = eng.cab(pre, act(to_dev(x), c), act(to_dev(e), c))
-        eng.fused_cab = False
-        two = eng.cab(pre, act(to_dev(x), c)) if h * w > 1 else None     # (sn_cab_ca of the two-kernel path does not take a one-pixel map)
-    finally:
-        eng.fused_cab = old
-    check(f"cabf_{name}_{c}_{T}x{h}x{w}", to_cpu(out.t, c), ref, 8e-3)
-    check(f"cabf_extra_{name}_{c}_{T}x{h}x{w}", to_cpu(out2.t, c), ref + e, 8e-3)
-    if two is not None:
-        check(f"cabf_vs_two_kernel_{name}_{c}_{T}x{h}x{w}", to_cpu(out.t, c), to_cpu(two.t, c), 4e-3)  # same operands; bf16 rounding of `mid` and of the output
-    if out.t.shape[-1] > c:
-        assert out.t[..., c:].float().abs().max().item() == 0.0
