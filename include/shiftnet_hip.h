@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 12     /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
+#define SN_ABI_VERSION 11     /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
 
 /* element types of NCHW tensors exchanged with the PyTorch side */
 #define SN_F32 0
