@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 11     /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
+#define SN_ABI_VERSION 12     /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
 
 /* element types of NCHW tensors exchanged with the PyTorch side */
 #define SN_F32 0
@@ -96,6 +96,10 @@ int sn_ca_mlp(const float* partial, int nblk, int cpad, int c, int cr, float inv
 int sn_cab_ca_scratch_floats(int T);
 int sn_cab_ca(const float* partial, int nblk, int cpad, const void* mid, int cs, int c, int cr, int h, int w,
               const float* w2, const float* wa, const float* wb, float* scratch, float* ca, int T, void* stream);
+/* the same for the fp32 engine: mid [T][h][w][c] float32 (pixel stride c), partial = sn32_chan_sum(mid), w2 [c][9][cpad] f32: the CAB's scale and
+ * residual then ride on the second sn32_conv2d (oscale / res) instead of a pass of their own (sn32_scale_residual). */
+int sn32_cab_ca(const float* partial, int nblk, int cpad, const float* mid, int c, int cr, int h, int w,
+                const float* w2, const float* wa, const float* wb, float* scratch, float* ca, int T, void* stream);
 
 /* ---- grouped spatial-temporal shift unit: channel_shift -> CAB2 -> CAB1 (gshift_deblur1.py:504-547) ---- */
 typedef struct sn_unit_src {

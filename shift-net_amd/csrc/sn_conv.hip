@@ -613,11 +613,15 @@ __global__ __launch_bounds__(1024) void ca_mlp_kernel(const float* partial, int 
 // per-workgroup partials, first/last row, first/last column) are split over SN_CABCA_NS workgroups per frame -- one
 // workgroup per frame was a 40 us latency chain, 101 times per window -- then one workgroup per frame finishes.
 #define SN_CABCA_NS 16
-__global__ __launch_bounds__(256) void cab_ca_part_kernel(const float* partial, int nblk, int cpad, const bf16_t* mid, int cs,
+__device__ __forceinline__ float cab_ldf(const bf16_t* p) { return bf_to_f(*p); }
+__device__ __forceinline__ float cab_ldf(const float* p) { return *p; }
+// E = bf16_t (bf16 engine: cs = padded channel count = pixel stride) or float (fp32 engine: cs = channel count = pixel stride)
+template <typename E>
+__global__ __launch_bounds__(256) void cab_ca_part_kernel(const float* partial, int nblk, int cpad, const E* mid, int cs,
                                                         int h, int w, float* scratch) {
     __shared__ float acc[256];
     const int t = blockIdx.y, sidx = blockIdx.x, tid = threadIdx.x;
-    const bf16_t* mt = mid + (size_t)t * h * w * cs;
+    const E* mt = mid + (size_t)t * h * w * cs;
     float* out = scratch + ((size_t)t * SN_CABCA_NS + sidx) * 5 * 128;
     {
         const int nsplit = 256 / cpad, ch = tid % cpad, part = tid / cpad;
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(256) void cab_ca_part_kernel(const float* partial, 
         if (seg < nseg)
             for (int i = sidx * nseg + seg; i < len; i += SN_CABCA_NS * nseg) {
                 const int y = line == 0 ? 0 : (line == 1 ? h - 1 : i), x = line == 2 ? 0 : (line == 3 ? w - 1 : i);
-                sm += bf_to_f(mt[((size_t)y * w + x) * cs + ch]);
+                sm += cab_ldf(mt + ((size_t)y * w + x) * cs + ch);
             }
         acc[tid] = sm;
         __syncthreads();
@@ -655,14 +659,15 @@ __global__ __launch_bounds__(256) void cab_ca_part_kernel(const float* partial, 
     }
 }
 
-__global__ __launch_bounds__(1024) void cab_ca_kernel(const float* scratch, int cpad, const bf16_t* mid, int cs, int c, int cr,
+template <typename E>
+__global__ __launch_bounds__(1024) void cab_ca_kernel(const float* scratch, int cpad, const E* mid, int cs, int c, int cr,
                                                      int h, int w, const float* w2, const float* wa, const float* wb, float* ca) {
     __shared__ float acc[1024];
     __shared__ float S[9][128];      // 0 total, 1 row0, 2 row h-1, 3 col0, 4 col w-1, 5..8 corners (0,0) (0,w-1) (h-1,0) (h-1,w-1)
     __shared__ float mean[128];
     __shared__ float hid[128];
     const int t = blockIdx.x, tid = threadIdx.x;
-    const bf16_t* mt = mid + (size_t)t * h * w * cs;
+    const E* mt = mid + (size_t)t * h * w * cs;
     if (tid < 5 * 128) {
         const int k = tid >> 7, ch = tid & 127;
         float m = 0.f;
@@ -673,10 +678,10 @@ __global__ __launch_bounds__(1024) void cab_ca_kernel(const float* scratch, int 
         S[k][ch] = m;
     }
     if (tid < cs) {
-        S[5][tid] = bf_to_f(mt[tid]);
-        S[6][tid] = bf_to_f(mt[((size_t)(w - 1)) * cs + tid]);
-        S[7][tid] = bf_to_f(mt[((size_t)(h - 1) * w) * cs + tid]);
-        S[8][tid] = bf_to_f(mt[((size_t)(h - 1) * w + w - 1) * cs + tid]);
+        S[5][tid] = cab_ldf(mt + tid);
+        S[6][tid] = cab_ldf(mt + ((size_t)(w - 1)) * cs + tid);
+        S[7][tid] = cab_ldf(mt + ((size_t)(h - 1) * w) * cs + tid);
+        S[8][tid] = cab_ldf(mt + ((size_t)(h - 1) * w + w - 1) * cs + tid);
     }
     __syncthreads();
     {   // pooled res[co] = (1/hw) sum_ci sum_tap w2[ci][tap][co] * S_tap[ci]; thread = (slice of ci, co), then a tree over slices
@@ -826,10 +831,20 @@ int sn_cab_ca(const float* partial, int nblk, int cpad, const void* mid, int cs,
     sn_clear_error();
     if (!partial || !mid || !w2 || !wa || !wb || !ca || !scratch || cpad < 16 || cpad > 128 || cs > 128 || (cs & 7) || c > cs ||
         c > cpad || cr < 1 || cr > 128 || nblk < 1 || h < 2 || w < 2) return SN_EINVAL;
-    hipLaunchKernelGGL(cab_ca_part_kernel, dim3(SN_CABCA_NS, T), dim3(256), 0, (hipStream_t)stream, partial, nblk, cpad,
+    hipLaunchKernelGGL(cab_ca_part_kernel<bf16_t>, dim3(SN_CABCA_NS, T), dim3(256), 0, (hipStream_t)stream, partial, nblk, cpad,
                        (const bf16_t*)mid, cs, h, w, scratch);
-    hipLaunchKernelGGL(cab_ca_kernel, dim3(T), dim3(1024), 0, (hipStream_t)stream, (const float*)scratch, cpad, (const bf16_t*)mid, cs,
+    hipLaunchKernelGGL(cab_ca_kernel<bf16_t>, dim3(T), dim3(1024), 0, (hipStream_t)stream, (const float*)scratch, cpad, (const bf16_t*)mid, cs,
                        c, cr, h, w, w2, wa, wb, ca);
+    return sn_check_launch();
+}
+
+int sn32_cab_ca(const float* partial, int nblk, int cpad, const float* mid, int c, int cr, int h, int w,
+                const float* w2, const float* wa, const float* wb, float* scratch, float* ca, int T, void* stream) {
+    sn_clear_error();
+    if (!partial || !mid || !w2 || !wa || !wb || !ca || !scratch || cpad < 16 || cpad > 128 || c < 1 || c > cpad || cr < 1 || cr > 128 ||
+        nblk < 1 || h < 2 || w < 2) return SN_EINVAL;
+    hipLaunchKernelGGL(cab_ca_part_kernel<float>, dim3(SN_CABCA_NS, T), dim3(256), 0, (hipStream_t)stream, partial, nblk, cpad, mid, c, h, w, scratch);
+    hipLaunchKernelGGL(cab_ca_kernel<float>, dim3(T), dim3(1024), 0, (hipStream_t)stream, (const float*)scratch, cpad, mid, c, c, cr, h, w, w2, wa, wb, ca);
     return sn_check_launch();
 }
 

@@ -49,6 +49,11 @@ class Plan32(Plan):
         self.add_conv(pre + "body.0", pre + "body.0.", [c])
         self.add_conv(pre + "body.2", pre + "body.2.", [c])
         self.add_ca(pre + "CA", pre + "CA.")
+        # [cin][9][cpad] copy of the second conv for the closed-form pooled mean of res (sn32_cab_ca): exact fp32 weights
+        cpad = max(16, prep.ceil8(c))
+        w2 = torch.zeros((c, 9, cpad), dtype=torch.float32)
+        w2[:, :, :c] = self.sd[pre + "body.2.weight"].float().reshape(c, c, 9).permute(1, 2, 0)
+        self.cas[pre + "CA"]["w2"] = w2.to(self.device)
 
     def add_naf(self, pre: str, c: int, with_shift: bool) -> None:
         i = 2                                    # body.0 1x1, body.1 RepConv2, (SimpleGate has no entry in the checkpoint)
@@ -156,6 +161,33 @@ class Engine32(Engine):
             T, h, w, c = o.shape
             return a, self._chan_sum(o), h * w
         return a
+
+    # CAB with the CALayer scale known BEFORE the second conv (its pooled input is linear in `mid`: sn32_cab_ca), so that scale and residual ride on
+    # conv2's epilogue: chan_sum reads mid instead of res, and the pass of sn32_scale_residual over res and x (3 of a CAB's 9 tensor passes) is gone.
+    # SN_FP32_CAB_TAIL=0 restores one kernel per reference module.
+    cab_closed_form = os.environ.get("SN_FP32_CAB_TAIL", "1") != "0"
+
+    def cab(self, pre: str, x: Act, extra: Optional[Act] = None) -> Act:
+        T, h, w, c = x.dims
+        if not self.cab_closed_form or h < 2 or w < 2 or x.t.stride(2) != c:
+            return super().cab(pre, x, extra)
+        q = self.P.cas[pre + "CA"]
+        mid = self.conv(pre + "body.0", [x], prelu=self.P.scalar(pre + "body.1.weight"))
+        part = self._chan_sum(mid.t)
+        cpad = part.shape[2]
+        scratch = torch.empty((self.lib.sn_cab_ca_scratch_floats(T),), dtype=torch.float32, device=self.dev)
+        ca = torch.empty((T, cpad), dtype=torch.float32, device=self.dev)
+        self._call("sn32_cab_ca", f"sn32_cab_ca[{pre}]", part.data_ptr(), part.shape[1], cpad, mid.t.data_ptr(), c, q["cr"], h, w,
+                   q["w2"].data_ptr(), q["wa"].data_ptr(), q["wb"].data_ptr(), scratch.data_ptr(), ca.data_ptr(), T, self._stream())
+        key = self.P.convs[pre + "body.2"]["key"]
+        o = self._conv32(key + "weight", key + "bias", [mid.t], [c], k=3, res=x.t, oscale=ca, oscale_stride=cpad, label=pre + "body.2")
+        out = Act(o, c)
+        if extra is not None:                     # "+ shortcut" after the last TFR_UNet of a stage (gshift_deblur1.py:769,779)
+            ones = torch.ones((T, c), dtype=torch.float32, device=self.dev)
+            o2 = self._new(T, h, w, c)
+            self._call("sn32_scale_residual", "sn32_add", o.data_ptr(), extra.t.data_ptr(), ones.data_ptr(), c, o2.data_ptr(), T, h * w, c, self._stream())
+            out = Act(o2, c)
+        return out
 
     def _chan_sum(self, x: torch.Tensor) -> torch.Tensor:
         T, h, w, c = x.shape
