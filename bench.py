@@ -101,6 +101,8 @@ def symbol_key(sym):
 
 def kernel_alg_bytes(fn, meta):
     """Minimal HBM bytes of ONE launch given its interface (each distinct input read once, output written once)."""
+    if meta and meta[0] == "ew32":             # fp32 engine, non-conv operator: the engine states its own minimal bytes
+        return meta[1]
     if meta and meta[0] == "conv32":           # fp32 engine: NHWC float32, channel counts as given
         _, T, ho, wo, cin, co, k, stride, in_mode, out_mode = meta[:10]
         pin = T * ho * wo * stride * stride / (4 if in_mode == 1 else 1)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 12     /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
+#define SN_ABI_VERSION 13     /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
 
 /* element types of NCHW tensors exchanged with the PyTorch side */
 #define SN_F32 0
@@ -260,12 +260,26 @@ typedef struct sn32_conv_desc {
                           * (~2^-16 relative per product), taken for single-input stride-1 dense k = 1 / 3 and grouped-by-8 k = 3 / 5 convs */
     const float* iscale; int iscale_stride;   /* NULL or [T][iscale_stride] f32: the input is multiplied by iscale[t][ci] while it is loaded (the
                           * CALayer scale of the producer, gshift_deblur1.py:69-70, without a pass of its own); single-input dense / grouped-by-8 convs */
+    const float* rscale; int rscale_stride;   /* NULL or [T][rscale_stride] f32: res is multiplied by rscale[t][co] before it is added (RepConv of the
+                          * denoisers: conv(g1 ca1) + g1 ca1 with iscale = rscale = ca1, gshift_denoise1.py RepConv after CALayer2); grouped-by-8 convs */
+    const float* ln_w; const float* ln_b;     /* NULL or [cin]: LayerNorm2d (gshift_deblur1.py:19-28, eps 1e-6) over the cin channels of every input pixel while
+                          * it is loaded; the split-precision 1x1 path only (wsplit, k 1, cin <= 128, h_out w_out >= 64), SN_EINVAL otherwise */
+    float* csum; int csum_cpad;               /* NULL or [T][sn32_conv_csum_tiles(h_out, w_out)][csum_cpad] f32: channel sums of the stored output per workgroup
+                          * (AdaptiveAvgPool2d(1) of the CALayer behind a conv, finished by sn_ca_mlp / sn32_cab_ca); split-precision dense 3x3 only */
 } sn32_conv_desc;
+int sn32_conv_csum_tiles(int h_out, int w_out);
 int sn32_conv2d(const sn32_conv_desc* d, void* stream);
 /* channel_shift (gshift_deblur1.py:504-528) materialised in fp32: offs != NULL: u [T][h][w][3C/2] = cat(roll(x), shift(borrowed));
  * offs == NULL: the temporal roll alone, [T][h][w][C] (Shift_CAB, gshift_denoise1.py:167-179).  s->x is a float tensor.
  * u2: NULL, or (offs != NULL) a second [T][h][w][3C/2] tensor whose first C channels receive roll(x) too (CAB2's LayerNorm input is built in it). */
 int sn32_gsts_gather(const sn_unit_src* s, const int8_t* offs, float* u, float* u2, void* stream);
+/* channel_shift (gshift_deblur1.py:504-528) written where CAB2 consumes it: vin:[T][h][w][3C/2] receives roll(x) in its first C channels
+ * (LayerNorm input and shortcut -- one copy, not the two of sn32_gsts_gather), and
+ *   w == NULL, u != NULL: u:[T][h][w][C/2] = shift(borrowed half) for a separate conv1 (sn32_conv2d depthwise into vin[:, C:]);
+ *   w != NULL, u == NULL: conv1 (depthwise 3x3, no bias, :206-212; w:[9][C/2] tap-major) is applied here, vin[:, C:] = conv1(shift(borrowed))
+ *                         (bit-identical, slower: scattered 4-byte taps).
+ * C % 8 == 0.  Frame range as sn32_gsts_gather. */
+int sn32_gsts_shiftconv(const sn_unit_src* s, const int8_t* offs, const float* w, float* vin, float* u, void* stream);
 /* LayerNorm2d (gshift_deblur1.py:19-28,44-53) over K channels per pixel. */
 int sn32_layernorm(const float* x, int cs_x, int K, const float* w, const float* b, float* out, int cs_out, long long npix, void* stream);
 /* SimpleGate (mode 0, :175-178) / SimpleGate2 (mode 1, :179-182): a:[npix][2C] -> out:[npix][C]. */
@@ -273,6 +287,14 @@ int sn32_gate(const float* a, int C, int mode, float* out, long long npix, void*
 /* SimpleGate / SimpleGate2 plus the channel sums of the result in one pass (the CALayer2 after it): out:[T][hw][C], partial as
  * sn32_chan_sum would compute from out. */
 int sn32_gate_sum(const float* a, int C, int cpad, int mode, float* out, int T, int hw, int nblk, float* partial, void* stream);
+/* The second 1x1 of phase 1 (C -> 2C, no bias) + SimpleGate2 (gshift_deblur1.py:179-182, x1 * sigmoid(x2)) + the channel sums of the result for
+ * CALayer2, split-precision arithmetic (wsplit as in sn32_conv_desc): x:[T][hw][cs_x >= cin], out:[T][hw][C], partial:[T][hw / 64][cpad]
+ * (finished by sn_ca_mlp with nblk = hw / 64).  hw % 64 == 0, C % 16 == 0, cin % 4 == 0, cin <= 128. */
+int sn32_conv1x1_gate2(const float* x, int cs_x, int cin, const void* wsplit, int C, int cpad, float* out, int T, int hw, float* partial, void* stream);
+/* RepConv2 (depthwise 3x3 + identity, gshift_deblur1.py:143-157) and SimpleGate (:175-178) in one pass: a:[T][h][w][cs_a >= 2C] f32,
+ * w:[9][2C] (the depthwise weight, tap-major), out:[T][h][w][C] = a'[c] * a'[C + c]; partial NULL, or [T][nblk][cpad] channel sums of out
+ * (what sn32_gate_sum returns) for the CALayer2 of the denoisers.  Bit-identical to sn32_conv2d(depthwise, res = a) + sn32_gate. */
+int sn32_dw_gate(const float* a, int cs_a, const float* w, int C, int cpad, float* out, int T, int h, int wd, int nblk, float* partial, void* stream);
 /* AdaptiveAvgPool2d(1) first half: partial:[T][nblk][cpad] sums (cpad >= C, <= 256), finished by sn_ca_mlp. */
 int sn32_chan_sum(const float* x, int cs, int C, int cpad, int T, int hw, int nblk, float* partial, void* stream);
 /* out = r * ca[t][c] (+ x if x != NULL). */

@@ -27,6 +27,9 @@ struct Conv32K {
     void* out; int cs_out, out_mode, nchw_dtype; const void* sc;
     const uint4* wsplit;
     const float* iscale; int iscale_stride;      // NULL or [T][iscale_stride]: the input is multiplied by iscale[t][ci] while it is staged
+    const float* rscale; int rscale_stride;      // NULL or [T][rscale_stride]: res is multiplied by rscale[t][co] before it is added
+    const float* lnw; const float* lnb;          // NULL or [cin]: LayerNorm2d over the input channels of a pixel while it is staged (split 1x1 kernel)
+    float* csum; int csum_cpad;                  // NULL or [T][tiles][csum_cpad]: per-workgroup channel sums of the stored output (split dense 3x3 kernel)
 };
 
 __device__ __forceinline__ float ld_bilinear32(const float* src, int hs, int ws, int cs, int c, int gy, int gx) {
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void conv32_kernel(const Conv32K P) {
             if (P.bias) a += P.bias[c];
             if (P.act == 1) a = a >= 0.f ? a : a * P.prelu;
             if (P.oscale) a *= P.oscale[(size_t)t * P.oscale_stride + c];
-            if (P.res) a += P.res[pix * P.cs_res + c];
+            if (P.res) a += P.res[pix * P.cs_res + c] * (P.rscale ? P.rscale[(size_t)t * P.rscale_stride + c] : 1.0f);
             if (P.out_mode == 0) {
                 ((float*)P.out)[pix * P.cs_out + c] = a;
             } else if (P.out_mode == 1) {          // F.pixel_shuffle(., 2): out[cc][2y+i][2x+jj] = in[4cc+2i+jj][y][x]
@@ -132,7 +135,7 @@ constexpr int C32_CB = 32, C32_PSL = C32_CB + 8;      // input channels staged p
 // Epilogue shared by the two matrix-core conv kernels: lane (g4, p) holds output channels co0 + 16 m + 4 g4 + r of pixel p of each N-tile
 // (same arithmetic as conv32_kernel: bias, PReLU, per-frame scale, residual; NHWC / pixel-shuffle / NCHW + shortcut outputs).
 template <int MTC, int NTW, int XB>
-__device__ __forceinline__ void conv32_epilogue(const Conv32K& P, const f32x4_t (&acc)[MTC][NTW], int t, int oy0, int ox0, int co0, int mt_n, int wv, int g4, int p) {
+__device__ __forceinline__ void conv32_epilogue(const Conv32K& P, const f32x4_t (&acc)[MTC][NTW], int t, int oy0, int ox0, int co0, int mt_n, int wv, int g4, int p, float (&sum)[MTC][4]) {
     const bool vout = P.out_mode == 0 && (P.cout & 3) == 0 && (P.cs_out & 3) == 0 && ((size_t)P.out & 15) == 0 &&
                       (!P.res || ((P.cs_res & 3) == 0 && ((size_t)P.res & 15) == 0));
 #pragma unroll
@@ -157,8 +160,13 @@ __device__ __forceinline__ void conv32_epilogue(const Conv32K& P, const f32x4_t 
                     const float* os = P.oscale + (size_t)t * P.oscale_stride + c0;
                     a[0] *= os[0]; a[1] *= os[1]; a[2] *= os[2]; a[3] *= os[3];
                 }
-                if (P.res) { const float4 rr = *(const float4*)(P.res + pix * P.cs_res + c0); a[0] += rr.x; a[1] += rr.y; a[2] += rr.z; a[3] += rr.w; }
+                if (P.res) {
+                    float4 rr = *(const float4*)(P.res + pix * P.cs_res + c0);
+                    if (P.rscale) { const float4 q = *(const float4*)(P.rscale + (size_t)t * P.rscale_stride + c0); rr.x *= q.x; rr.y *= q.y; rr.z *= q.z; rr.w *= q.w; }
+                    a[0] += rr.x; a[1] += rr.y; a[2] += rr.z; a[3] += rr.w;
+                }
                 *(float4*)((float*)P.out + pix * P.cs_out + c0) = make_float4(a[0], a[1], a[2], a[3]);
+                sum[m][0] += a[0]; sum[m][1] += a[1]; sum[m][2] += a[2]; sum[m][3] += a[3];
                 continue;
             }
 #pragma unroll
@@ -169,7 +177,8 @@ __device__ __forceinline__ void conv32_epilogue(const Conv32K& P, const f32x4_t 
                 if (P.bias) a += P.bias[c];
                 if (P.act == 1) a = a >= 0.f ? a : a * P.prelu;
                 if (P.oscale) a *= P.oscale[(size_t)t * P.oscale_stride + c];
-                if (P.res) a += P.res[pix * P.cs_res + c];
+                if (P.res) a += P.res[pix * P.cs_res + c] * (P.rscale ? P.rscale[(size_t)t * P.rscale_stride + c] : 1.0f);
+                sum[m][r] += a;
                 if (P.out_mode == 0) {
                     ((float*)P.out)[pix * P.cs_out + c] = a;
                 } else if (P.out_mode == 1) {
@@ -327,7 +336,11 @@ __global__ __launch_bounds__(256) void conv32m_kernel(const Conv32K P) {
                     const float* os = P.oscale + (size_t)t * P.oscale_stride + c0;
                     a[0] *= os[0]; a[1] *= os[1]; a[2] *= os[2]; a[3] *= os[3];
                 }
-                if (P.res) { const float4 rr = *(const float4*)(P.res + pix * P.cs_res + c0); a[0] += rr.x; a[1] += rr.y; a[2] += rr.z; a[3] += rr.w; }
+                if (P.res) {
+                    float4 rr = *(const float4*)(P.res + pix * P.cs_res + c0);
+                    if (P.rscale) { const float4 q = *(const float4*)(P.rscale + (size_t)t * P.rscale_stride + c0); rr.x *= q.x; rr.y *= q.y; rr.z *= q.z; rr.w *= q.w; }
+                    a[0] += rr.x; a[1] += rr.y; a[2] += rr.z; a[3] += rr.w;
+                }
                 *(float4*)((float*)P.out + pix * P.cs_out + c0) = make_float4(a[0], a[1], a[2], a[3]);
                 continue;
             }
@@ -339,7 +352,7 @@ __global__ __launch_bounds__(256) void conv32m_kernel(const Conv32K P) {
                 if (P.bias) a += P.bias[c];
                 if (P.act == 1) a = a >= 0.f ? a : a * P.prelu;
                 if (P.oscale) a *= P.oscale[(size_t)t * P.oscale_stride + c];
-                if (P.res) a += P.res[pix * P.cs_res + c];
+                if (P.res) a += P.res[pix * P.cs_res + c] * (P.rscale ? P.rscale[(size_t)t * P.rscale_stride + c] : 1.0f);
                 if (P.out_mode == 0) {
                     ((float*)P.out)[pix * P.cs_out + c] = a;
                 } else if (P.out_mode == 1) {
@@ -494,7 +507,33 @@ __global__ __launch_bounds__(256, 2) void conv32s_kernel(const Conv32K P) {
             }
         }
     }
-    conv32_epilogue<MTC, NTW, XB>(P, acc, t, oy0, ox0, co0, mt_n, wv, g4, p);
+    float sum[MTC][4];
+#pragma unroll
+    for (int m = 0; m < MTC; ++m) sum[m][0] = sum[m][1] = sum[m][2] = sum[m][3] = 0.f;
+    conv32_epilogue<MTC, NTW, XB>(P, acc, t, oy0, ox0, co0, mt_n, wv, g4, p, sum);
+    if (P.csum) {                                                   // workgroup-uniform: channel sums of this tile (AdaptiveAvgPool2d of the CAB behind it)
+        __syncthreads();                                            // the staged tile is dead: its LDS becomes the [4 waves][MTC * 16] scratch
+        float* const red = (float*)lds;
+#pragma unroll
+        for (int m = 0; m < MTC; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = sum[m][r];
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
+                if (p == 0) red[wv * MTC * 16 + 16 * m + 4 * g4 + r] = v;
+            }
+        __syncthreads();
+        if (tid < MTC * 16) {
+            const int c = co0 + tid;
+            if (c < P.csum_cpad) {
+                float v = 0.f;
+                if (c < P.cout)
+                    for (int q = 0; q < 4; ++q) v += red[q * MTC * 16 + tid];
+                P.csum[(((size_t)t * tiles_y + ty) * gridDim.x + tx) * P.csum_cpad + c] = v;
+            }
+        }
+    }
 }
 
 template <int MTC, int KSZ, bool GROUPED>
@@ -516,8 +555,15 @@ int launch_conv32s(const Conv32K& K, hipStream_t st) {
 #ifndef SN_1X1_NPX
 #define SN_1X1_NPX 64         // pixels per workgroup: 64 (30 KB of LDS at 80 input channels: 5 workgroups per CU) or 128
 #endif
-template <int NCB>
-__global__ __launch_bounds__(256, 2) void conv32s_1x1_kernel(const Conv32K P, const long long npix) {
+// GATE: the output channels are consumed pairwise by SimpleGate2 (gshift_deblur1.py:179-182: x1 * sigmoid(x2), x1 = channels [0, C), x2 = [C, 2C)):
+// a wave takes the M-tile PAIRS (m, m + C/16), gates in registers and stores the C-channel result -- the 2C-channel tensor is neither written
+// nor read back -- and leaves the per-workgroup channel sums of the result for the CALayer2 behind the gate (partial [npix / NPX][cpad];
+// a workgroup must not span two frames: hw % NPX == 0, checked by the entry point).
+// LNF: LayerNorm2d (gshift_deblur1.py:19-28) of the input pixel while it is staged -- the eight lanes that load a pixel's 32-channel blocks hold all of
+// its channels in registers, so mean and variance (two-pass, as layernorm32_kernel) cost three lane exchanges each and the normalised tensor
+// is neither written nor read.
+template <int NCB, bool GATE, bool LNF>
+__global__ __launch_bounds__(256, 2) void conv32s_1x1_kernel(const Conv32K P, const long long npix, float* partial, const int cpad) {
     constexpr int ncb = NCB;                                         // compile-time: the k-loop unrolls and a group's weight fragments load up front
     extern __shared__ __attribute__((aligned(16))) float smem32[];
     char* const lds = (char*)smem32;
@@ -527,6 +573,56 @@ __global__ __launch_bounds__(256, 2) void conv32s_1x1_kernel(const Conv32K P, co
     const long long pix0 = (long long)blockIdx.x * NPX;
     const int hw = P.hout * P.wout;
     const int t0 = (int)(pix0 / hw), prem = (int)(pix0 - (long long)t0 * hw);     // frame of the first pixel (a workgroup spans at most two: hw >= 128)
+    if constexpr (LNF) {
+        constexpr int IT = NPX * 8 / 256;
+        const int q = tid & 7;
+        float4 v[NCB][IT];
+#pragma unroll
+        for (int cb = 0; cb < ncb; ++cb)
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int pl = (tid + it * 256) >> 3, ci = cb * 32 + 4 * q;
+                const long long pg = pix0 + pl;
+                const bool in = ci < P.cin_total && pg < npix;
+                v[cb][it] = *(const float4*)(P.in0 + (in ? (size_t)pg * P.cs0 + ci : 0));
+                if (!in) v[cb][it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        const float rk = 1.0f / (float)P.cin_total;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            float mu = 0.f;
+#pragma unroll
+            for (int cb = 0; cb < ncb; ++cb) mu += (v[cb][it].x + v[cb][it].y) + (v[cb][it].z + v[cb][it].w);
+            mu += __shfl_xor(mu, 1, 64); mu += __shfl_xor(mu, 2, 64); mu += __shfl_xor(mu, 4, 64);
+            mu *= rk;
+            float var = 0.f;
+#pragma unroll
+            for (int cb = 0; cb < ncb; ++cb) {
+                if (cb * 32 + 4 * q < P.cin_total) {
+                    const float dx = v[cb][it].x - mu, dy = v[cb][it].y - mu, dz = v[cb][it].z - mu, dw = v[cb][it].w - mu;
+                    var += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+                }
+            }
+            var += __shfl_xor(var, 1, 64); var += __shfl_xor(var, 2, 64); var += __shfl_xor(var, 4, 64);
+            const float rstd = 1.0f / sqrtf(var * rk + 1e-6f);
+            const int pl = (tid + it * 256) >> 3;
+#pragma unroll
+            for (int cb = 0; cb < ncb; ++cb) {
+                const int ci = cb * 32 + 4 * q;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ci < P.cin_total) {
+                    const float4 g = *(const float4*)(P.lnw + ci), b = *(const float4*)(P.lnb + ci);
+                    x = make_float4((v[cb][it].x - mu) * rstd * g.x + b.x, (v[cb][it].y - mu) * rstd * g.y + b.y,
+                                    (v[cb][it].z - mu) * rstd * g.z + b.z, (v[cb][it].w - mu) * rstd * g.w + b.w);
+                }
+                const uint32_t h01 = pack_bf2(x.x, x.y), h23 = pack_bf2(x.z, x.w);
+                const uint32_t l01 = pack_bf2(x.x - __uint_as_float(h01 << 16), x.y - __uint_as_float(h01 & 0xffff0000u));
+                const uint32_t l23 = pack_bf2(x.z - __uint_as_float(h23 << 16), x.w - __uint_as_float(h23 & 0xffff0000u));
+                *(uint2*)(lds + pl * PSK + cb * 160 + 8 * q) = make_uint2(h01, h23);
+                *(uint2*)(lds + pl * PSK + cb * 160 + 64 + 8 * q) = make_uint2(l01, l23);
+            }
+        }
+    } else {
 #pragma unroll
     for (int cb = 0; cb < ncb; ++cb) {
         float4 v[NPX * 8 / 256], sc[NPX * 8 / 256];
@@ -551,6 +647,7 @@ __global__ __launch_bounds__(256, 2) void conv32s_1x1_kernel(const Conv32K P, co
             *(uint2*)(lds + pl * PSK + cb * 160 + 64 + 8 * q) = make_uint2(l01, l23);
         }
     }
+    }
     __syncthreads();
     // The four waves share the workgroup's pixels (NTW N-tiles each of them reads from LDS) and SPLIT THE M-TILES: wave w takes M-tiles
     // w, w + 4, ...  With the pixels split instead, every wave fetched the fragments of ALL M-tiles -- 4 x 60 KB per 64 pixels for 80 -> 160
@@ -568,6 +665,49 @@ __global__ __launch_bounds__(256, 2) void conv32s_1x1_kernel(const Conv32K P, co
             h[cb] = as_frag(wh[wi]); l[cb] = as_frag(wl[wi]);
         }
     };
+    if constexpr (GATE) {
+        const int mh = mt_all >> 1, Cg = P.cout >> 1;                // C = 16 mh
+        bf16x8_t bhc[NCB], blc[NCB];
+        for (int m = wv; m < mh; m += 4) {
+            wload(m, ahc, alc);
+            wload(m + mh, bhc, blc);
+            f32x4_t acc1[NT], acc2[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) { acc1[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc2[n] = acc1[n]; }
+#pragma unroll
+            for (int cb = 0; cb < ncb; ++cb)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const char* bp = lds + (n * 16 + p) * PSK + cb * 160 + g4 * 16;
+                    const bf16x8_t bh = as_frag(*(const uint4*)bp), bl = as_frag(*(const uint4*)(bp + 64));
+                    acc1[n] = mfma16(alc[cb], bh, acc1[n]);
+                    acc1[n] = mfma16(ahc[cb], bl, acc1[n]);
+                    acc1[n] = mfma16(ahc[cb], bh, acc1[n]);
+                    acc2[n] = mfma16(blc[cb], bh, acc2[n]);
+                    acc2[n] = mfma16(bhc[cb], bl, acc2[n]);
+                    acc2[n] = mfma16(bhc[cb], bh, acc2[n]);
+                }
+            const int c0 = 16 * m + 4 * g4;
+            float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const long long pg = pix0 + n * 16 + p;
+                if (pg >= npix) continue;
+                float g[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { g[r] = acc1[n][r] / (1.0f + expf(-acc2[n][r])); sum[r] += g[r]; }
+                *(float4*)((float*)P.out + (size_t)pg * P.cs_out + c0) = make_float4(g[0], g[1], g[2], g[3]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) sum[r] += __shfl_xor(sum[r], off, 64);
+            }
+            if (p == 0) *(float4*)(partial + (size_t)blockIdx.x * cpad + c0) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+        }
+        if (tid < cpad - Cg) partial[(size_t)blockIdx.x * cpad + Cg + tid] = 0.f;
+        return;
+    }
     wload(wv, ahc, alc);
     for (int m = wv; m < mt_all; m += 4) {                          // wave-uniform; no barrier inside
         wload(m + 4, ahn, aln);
@@ -659,6 +799,58 @@ __global__ __launch_bounds__(256) void dw32_kernel(const Conv32K P) {
     }
 }
 
+// RepConv2 + SimpleGate in one pass (gshift_deblur1.py:143-157,175-178): g1[c] = a'[c] * a'[C + c] with a' = dw3x3(a) + a over the 2C channels of
+// the first 1x1's output.  One thread = the channel quads c..c+3 and C+c..C+c+3 of a pixel (their 18 weight rows live in registers), a workgroup
+// = 256 / (C/4) pixels abreast walking a contiguous chunk of one frame.  a' is never written (2C floats per pixel out and back in), and the
+// products are summed in the order dw32_kernel + gate32_kernel use, so g1 is bit-identical to the unfused pair.  partial != NULL: the
+// per-(frame, workgroup) channel sums of g1 for the CALayer2 behind the gate (denoisers), as sn32_gate_sum.
+__global__ __launch_bounds__(256) void dwgate32_kernel(const float* a, int cs, const float* w, int C, int cpad, int h, int wd, int chunk, float* out, float* partial) {
+    __shared__ float red[256 * 4];
+    const int t = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    const int c4n = C >> 2, npp = 256 / c4n, q = tid % c4n, part = tid / c4n, c = 4 * q, hw = h * wd;
+    float4 w1[9], w2[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { w1[i] = *(const float4*)(w + (size_t)i * 2 * C + c); w2[i] = *(const float4*)(w + (size_t)i * 2 * C + C + c); }
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* at = a + (size_t)t * hw * cs;
+    float* ot = out + (size_t)t * hw * C;
+    const int pend = min(hw, (blk + 1) * chunk);
+    if (part < npp) {
+        for (int pix = blk * chunk + part; pix < pend; pix += npp) {
+            const int oy = pix / wd, ox = pix - oy * wd;
+            float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1, r1 = a1, r2 = a1;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int gy = oy - 1 + ky;
+                if (gy < 0 || gy >= h) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int gx = ox - 1 + kx;
+                    if (gx < 0 || gx >= wd) continue;
+                    const float* px = at + ((size_t)gy * wd + gx) * cs + c;
+                    const float4 x1 = *(const float4*)px, x2 = *(const float4*)(px + C);
+                    const float4 u = w1[ky * 3 + kx], v = w2[ky * 3 + kx];
+                    a1.x = fmaf(x1.x, u.x, a1.x); a1.y = fmaf(x1.y, u.y, a1.y); a1.z = fmaf(x1.z, u.z, a1.z); a1.w = fmaf(x1.w, u.w, a1.w);
+                    a2.x = fmaf(x2.x, v.x, a2.x); a2.y = fmaf(x2.y, v.y, a2.y); a2.z = fmaf(x2.z, v.z, a2.z); a2.w = fmaf(x2.w, v.w, a2.w);
+                    if (ky == 1 && kx == 1) { r1 = x1; r2 = x2; }
+                }
+            }
+            const float4 g = make_float4((a1.x + r1.x) * (a2.x + r2.x), (a1.y + r1.y) * (a2.y + r2.y), (a1.z + r1.z) * (a2.z + r2.z), (a1.w + r1.w) * (a2.w + r2.w));
+            *(float4*)(ot + (size_t)pix * C + c) = g;
+            s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+        }
+    }
+    if (!partial) return;
+    *(float4*)(red + tid * 4) = s;                                  // [part][C] (tid * 4 = part * C + c for part < npp)
+    __syncthreads();
+    if (tid < cpad) {
+        float m = 0.f;
+        if (tid < C)
+            for (int pq = 0; pq < npp; ++pq) m += red[pq * C + tid];
+        partial[((size_t)t * gridDim.x + blk) * cpad + tid] = m;
+    }
+}
+
 struct Unit32 { const float* x; const float* halo; int T, h, w, C, mode, wrap, t0; };
 
 // u = cat(roll(x), spatial_shift2(borrowed half)) (gshift_deblur1.py:504-528); CU = 3C/2, or C for the roll alone (Shift_CAB)
@@ -680,6 +872,54 @@ __global__ void gather32_kernel(const Unit32 U, const int8_t* offs, float* u, co
         }
         u[(size_t)t * n + e] = v;
         if (u2 && c < U.C) u2[(size_t)t * n + e] = v;
+    }
+}
+
+// channel_shift for CAB2 without the second copy of roll(x) that sn32_gsts_gather's cat(roll(x), shift(borrowed)) holds: roll(x) goes
+// straight into the LayerNorm input vin[:, :C] (which also is the shortcut), and either (CONV = false, the default of the engine) the
+// shifted half alone goes to u [T][hw][C/2] for the depthwise conv1, or (CONV = true) conv1 is computed here as well and vin is complete.
+// The CONV form is bit-identical but SLOWER on MI355X (0.60 ms against 0.30 + 0.11 ms at 36 x 272 x 448 x 80): nine 4-byte loads per
+// output whose addresses scatter over 24 shift offsets per wave, where the separate conv reads 16 bytes per lane, coalesced.  Phase A copies roll(x) in 16-byte pieces; phase B computes one (pixel, borrowed channel)
+// per thread: nine taps of the SHIFTED image, each tap zero when it falls outside the frame (the conv's padding) or when its source does
+// (the shift's zero fill), summed in the tap order of dw32_kernel (bit-identical to gather + conv).
+template <bool CONV>
+__global__ __launch_bounds__(256) void shiftconv32_kernel(const Unit32 U, const int8_t* offs, const float* w, float* vin, float* u) {
+    const int t = U.t0 + blockIdx.y, Ch = U.C >> 1, hw = U.h * U.w, CU = U.C + Ch, c4n = U.C >> 2;
+    const SnSlabs<float> s = sn_unit_slabs<float>(U.x, U.halo, U.T, hw, U.C, U.mode, U.wrap, t);      // SURVEY.md 8a-1 table (sn_common.h)
+    float* const vt = vin + (size_t)t * hw * CU;
+    const size_t na = (size_t)hw * c4n;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < na; e += (size_t)gridDim.x * 256) {
+        const int i = (int)(e / c4n), c = (int)(e - (size_t)i * c4n) * 4;
+        const float4 v = c < Ch ? *(const float4*)(s.p0 + (size_t)i * s.s0 + c) : *(const float4*)(s.p1 + (size_t)i * s.s1 + c - Ch);
+        *(float4*)(vt + (size_t)i * CU + c) = v;
+    }
+    const size_t nb = (size_t)hw * Ch;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nb; e += (size_t)gridDim.x * 256) {
+        const int i = (int)(e / Ch), k = (int)(e - (size_t)i * Ch);
+        const int y = i / U.w, x = i - y * U.w, oy = offs[2 * k], ox = offs[2 * k + 1];
+        if constexpr (!CONV) {                                     // the shifted half alone, for a separate conv1: u [T][hw][C/2]
+            const int sy = y + oy, sx = x + ox;
+            float xv = 0.f;
+            if (sy >= 0 && sy < U.h && sx >= 0 && sx < U.w) xv = s.pb[((size_t)sy * U.w + sx) * s.sb + k];
+            u[(size_t)t * nb + e] = xv;
+            continue;
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int gy = y - 1 + ky;
+            if (gy < 0 || gy >= U.h) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int gx = x - 1 + kx;
+                if (gx < 0 || gx >= U.w) continue;
+                const int sy = gy + oy, sx = gx + ox;
+                float xv = 0.f;
+                if (sy >= 0 && sy < U.h && sx >= 0 && sx < U.w) xv = s.pb[((size_t)sy * U.w + sx) * s.sb + k];
+                acc = fmaf(xv, w[(ky * 3 + kx) * Ch + k], acc);
+            }
+        }
+        vt[(size_t)i * CU + U.C + k] = acc;
     }
 }
 
@@ -813,6 +1053,21 @@ int sn32_conv2d(const sn32_conv_desc* d, void* stream) {
     const int cin_g = K.cin_total / d->groups, cout_g = d->c_out / d->groups;
     K.wsplit = (const uint4*)d->wsplit;
     K.iscale = d->iscale; K.iscale_stride = d->iscale_stride;
+    K.rscale = d->rscale; K.rscale_stride = d->rscale_stride;
+    K.lnw = d->ln_w; K.lnb = d->ln_b; K.csum = d->csum; K.csum_cpad = d->csum_cpad;
+    {
+        const bool split1 = d->wsplit && d->n_in == 1 && d->in_mode == 0 && d->stride == 1 && (d->cs_in[0] & 3) == 0 && (K.cin_total & 3) == 0 &&
+                            ((size_t)d->in[0] & 15) == 0 && ((size_t)d->wsplit & 15) == 0 && d->groups == 1 && d->out_mode == 0;
+        const int mt0 = (d->c_out + 15) / 16;
+        // LayerNorm on load: the flat-pixel split 1x1 kernel only (same conditions as its dispatch below)
+        if (d->ln_w && !(split1 && d->ln_b && !d->iscale && d->k == 1 && d->pad == 0 && (K.cin_total + 31) / 32 <= 4 && d->h_out * d->w_out >= SN_1X1_NPX &&
+                         (d->c_out & 3) == 0 && (d->cs_out & 3) == 0 && ((size_t)d->out & 15) == 0 && (!d->res || ((d->cs_res & 3) == 0 && ((size_t)d->res & 15) == 0)) &&
+                         mt0 > 1 && (((size_t)d->ln_w | (size_t)d->ln_b) & 15) == 0)) return SN_EINVAL;
+        // channel sums of the output: the split dense 3x3 kernel only
+        if (d->csum && !(split1 && d->k == 3 && d->pad == 1 && d->csum_cpad >= d->c_out && d->csum_cpad <= 16 * mt0)) return SN_EINVAL;
+    }
+    // the residual scale exists in the grouped-by-8 matrix-core kernels only (the "+" RepConv of the denoisers: res = g1 * ca1, never materialised)
+    if (d->rscale && !(d->res && d->groups > 1 && cin_g == 8 && cout_g == 8 && d->c_out % 16 == 0 && (d->rscale_stride & 3) == 0 && ((size_t)d->rscale & 15) == 0)) return SN_EINVAL;
     // the input scale is implemented by the matrix-core kernels' 16-byte staging path only
     if (d->iscale && !((d->groups == 1 || (cin_g == 8 && cout_g == 8 && d->c_out % 16 == 0)) && d->n_in == 1 && d->in_mode == 0 && (d->cs_in[0] & 3) == 0 &&
                        (K.cin_total & 3) == 0 && ((size_t)d->in[0] & 15) == 0 && (d->iscale_stride & 3) == 0 && ((size_t)d->iscale & 15) == 0)) return SN_EINVAL;
@@ -829,8 +1084,12 @@ int sn32_conv2d(const sn32_conv_desc* d, void* stream) {
                 const size_t lds = (size_t)SN_1X1_NPX * (ncb1 * 160 + ((ncb1 & 1) ? 0 : 32));
                 const dim3 grid((unsigned)((npix + SN_1X1_NPX - 1) / SN_1X1_NPX));
 #define SN_1X1_CASE(N) case N: \
-                    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv32s_1x1_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH; \
-                    hipLaunchKernelGGL(conv32s_1x1_kernel<N>, grid, dim3(256), lds, st, K, npix); break;
+                    if (d->ln_w) { \
+                        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv32s_1x1_kernel<N, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH; \
+                        hipLaunchKernelGGL((conv32s_1x1_kernel<N, false, true>), grid, dim3(256), lds, st, K, npix, (float*)nullptr, 0); break; \
+                    } \
+                    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv32s_1x1_kernel<N, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH; \
+                    hipLaunchKernelGGL((conv32s_1x1_kernel<N, false, false>), grid, dim3(256), lds, st, K, npix, (float*)nullptr, 0); break;
                 switch (ncb1) { SN_1X1_CASE(1) SN_1X1_CASE(2) SN_1X1_CASE(3) SN_1X1_CASE(4) }
 #undef SN_1X1_CASE
                 return sn_check_launch();
@@ -869,6 +1128,18 @@ int sn32_gsts_gather(const sn_unit_src* s, const int8_t* offs, float* u, float* 
     return sn_check_launch();
 }
 
+int sn32_gsts_shiftconv(const sn_unit_src* s, const int8_t* offs, const float* w, float* vin, float* u, void* stream) {
+    sn_clear_error();
+    if (!s || !s->x || !offs || (!w == !u) || !vin || (s->C & 7) || s->T < 1 || s->mode < 1 || s->mode > 2 || s->wrap < 0 || s->wrap > 2 || (s->wrap == 2 && !s->halo) ||
+        (((size_t)s->x | (size_t)s->halo | (size_t)vin) & 15)) return SN_EINVAL;
+    Unit32 U; U.x = (const float*)s->x; U.halo = (const float*)s->halo; U.T = s->T; U.h = s->h; U.w = s->w; U.C = s->C; U.mode = s->mode; U.wrap = s->wrap;
+    SN_FRAME_RANGE(s, t0, nt);
+    U.t0 = t0;
+    if (w) hipLaunchKernelGGL(shiftconv32_kernel<true>, dim3(1024, nt), dim3(256), 0, (hipStream_t)stream, U, offs, w, vin, u);
+    else hipLaunchKernelGGL(shiftconv32_kernel<false>, dim3(1024, nt), dim3(256), 0, (hipStream_t)stream, U, offs, w, vin, u);
+    return sn_check_launch();
+}
+
 int sn32_layernorm(const float* x, int cs_x, int K, const float* w, const float* b, float* out, int cs_out, long long npix, void* stream) {
     sn_clear_error();
     if (!x || !w || !b || !out || K < 1 || K > 128 || cs_x < K || cs_out < K || npix < 1) return SN_EINVAL;
@@ -887,6 +1158,39 @@ int sn32_gate_sum(const float* a, int C, int cpad, int mode, float* out, int T, 
     sn_clear_error();
     if (!a || !out || !partial || C < 1 || cpad < C || cpad > 256 || nblk < 1 || T < 1 || hw < 1 || mode < 0 || mode > 1) return SN_EINVAL;
     hipLaunchKernelGGL(gate_sum32_kernel, dim3(nblk, T), dim3(256), 0, (hipStream_t)stream, a, C, cpad, mode, hw, out, partial);
+    return sn_check_launch();
+}
+
+int sn32_conv_csum_tiles(int h_out, int w_out) {       // workgroups per frame of the kernel that fills sn32_conv_desc.csum
+    return ((h_out + SN_C32S_TH3 - 1) / SN_C32S_TH3) * ((w_out + 31) / 32);
+}
+
+int sn32_conv1x1_gate2(const float* x, int cs_x, int cin, const void* wsplit, int C, int cpad, float* out, int T, int hw, float* partial, void* stream) {
+    sn_clear_error();
+    const int ncb1 = (cin + 31) / 32;
+    if (!x || !wsplit || !out || !partial || cin < 4 || (cin & 3) || cs_x < cin || (cs_x & 3) || ncb1 > 4 || C < 16 || (C & 15) || cpad < C || (cpad & 3) || T < 1 ||
+        hw < SN_1X1_NPX || (hw % SN_1X1_NPX) || (((size_t)x | (size_t)wsplit | (size_t)out | (size_t)partial) & 15)) return SN_EINVAL;
+    Conv32K K{};
+    K.in0 = x; K.cin0 = cin; K.cs0 = cs_x; K.n_in = 1; K.T = T; K.hin = 1; K.win = hw; K.k = 1; K.stride = 1; K.groups = 1; K.hout = 1; K.wout = hw;
+    K.cout = 2 * C; K.cin_total = cin; K.out = out; K.cs_out = C; K.wsplit = (const uint4*)wsplit;
+    const long long npix = (long long)T * hw;
+    const size_t lds = (size_t)SN_1X1_NPX * (ncb1 * 160 + ((ncb1 & 1) ? 0 : 32));
+    const dim3 grid((unsigned)(npix / SN_1X1_NPX));
+    hipStream_t st = (hipStream_t)stream;
+#define SN_1X1_CASE(N) case N: \
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv32s_1x1_kernel<N, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH; \
+    hipLaunchKernelGGL((conv32s_1x1_kernel<N, true, false>), grid, dim3(256), lds, st, K, npix, partial, cpad); break;
+    switch (ncb1) { SN_1X1_CASE(1) SN_1X1_CASE(2) SN_1X1_CASE(3) SN_1X1_CASE(4) }
+#undef SN_1X1_CASE
+    return sn_check_launch();
+}
+
+int sn32_dw_gate(const float* a, int cs_a, const float* w, int C, int cpad, float* out, int T, int h, int wd, int nblk, float* partial, void* stream) {
+    sn_clear_error();
+    if (!a || !w || !out || C < 4 || (C & 3) || C > 1024 || cs_a < 2 * C || (cs_a & 3) || T < 1 || h < 1 || wd < 1 || nblk < 1 ||
+        (((size_t)a | (size_t)w | (size_t)out) & 15) || (partial && (cpad < C || cpad > 256))) return SN_EINVAL;
+    const int hw = h * wd, chunk = (hw + nblk - 1) / nblk;
+    hipLaunchKernelGGL(dwgate32_kernel, dim3(nblk, T), dim3(256), 0, (hipStream_t)stream, a, cs_a, w, C, cpad, h, wd, chunk, out, partial);
     return sn_check_launch();
 }
 

@@ -72,6 +72,23 @@ class Plan32(Plan):
         return self._wt[key]
 
 
+    def rep_merged(self, rp: str, identity: bool) -> str:
+        """RepConv's parallel branches as ONE 5x5 kernel: conv_1 (5x5) + conv_2 (3x3, zero-padded) [+ the identity at the centre tap]
+        (gshift_deblur1.py:143-157 computes the three terms separately and adds the results; merging the WEIGHTS in fp32 changes each output by a
+        few ulp of its terms).  The identity is merged only for the depthwise form, whose kernel multiplies in exact fp32: in the split-precision
+        grouped kernels a weight 1 + w would keep 16 bits relative to 1, so there the identity stays the epilogue's residual."""
+        key = rp + ("merged_id.weight" if identity else "merged.weight")
+        if key not in self.sd:
+            w5, w3 = self.sd[rp + "conv_1.weight"].float(), self.sd[rp + "conv_2.weight"].float()
+            m = w5.clone()
+            m[:, :, 1:4, 1:4] += w3
+            if identity:
+                assert m.shape[1] == 1
+                m[:, 0, 2, 2] += 1.0
+            self.sd[key] = m
+            self.dsd[key] = m.to(self.device)
+        return key
+
     def wsplit(self, key: str, groups: int) -> torch.Tensor:
         """bf16 hi / lo A fragments of a conv weight for the split-precision path (prep.pack_conv32_split), built on first use."""
         if key not in self._ws:
@@ -91,9 +108,18 @@ class Engine32(Engine):
     split_bf16 = os.environ.get("SN_FP32_EXACT", "0") != "1"
 
     # ---- leaf operators ------------------------------------------------------------------------------------
+    _CONV_FNS = ("sn32_conv2d", "sn32_conv1x1_gate2")
+
+    def _call(self, fn: str, label: str, *args, alg_bytes: float = 0.0) -> None:
+        """Non-conv launches carry their own minimal HBM bytes for bench.py's per-kernel table (convs: the ("conv32", ...) record of _conv32)."""
+        if fn not in self._CONV_FNS:
+            self._meta = ("ew32", float(alg_bytes))
+        super()._call(fn, label, *args)
+
     def _conv32(self, wkey: str, bkey: Optional[str], ins: Sequence[torch.Tensor], cins: Sequence[int], *, k: int, stride: int = 1,
                 pad: Optional[int] = None, groups: int = 1, prelu: Optional[float] = None, res: Optional[torch.Tensor] = None,
                 oscale: Optional[torch.Tensor] = None, oscale_stride: int = 0, iscale: Optional[torch.Tensor] = None,
+                rscale: Optional[torch.Tensor] = None, ln: Optional[Sequence[torch.Tensor]] = None, csum: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None, out_mode: int = 0,
                 in_mode: int = 0, c_out: Optional[int] = None, nchw_out: Optional[torch.Tensor] = None,
                 nchw_sc: Optional[torch.Tensor] = None, label: str = "") -> torch.Tensor:
@@ -125,6 +151,13 @@ class Engine32(Engine):
             d.oscale, d.oscale_stride = oscale.data_ptr(), oscale_stride
         if iscale is not None:                     # [T][stride] per-frame input scale (CALayer of the producer)
             d.iscale, d.iscale_stride = iscale.data_ptr(), iscale.stride(0)
+        if rscale is not None:                     # the same for the residual (RepConv of the denoisers: res = g1 * ca1)
+            d.rscale, d.rscale_stride = rscale.data_ptr(), rscale.stride(0)
+        if ln is not None:                         # LayerNorm2d of the input while it is loaded (split 1x1 kernel; the library refuses other shapes)
+            d.ln_w, d.ln_b = ln[0].data_ptr(), ln[1].data_ptr()
+        if csum is not None:                       # [T][tiles][cpad] channel sums of the output (split dense 3x3 kernel; the library refuses other shapes)
+            assert csum.shape[0] == T and csum.shape[1] == self.lib.sn32_conv_csum_tiles(h_out, w_out) and csum.is_contiguous()
+            d.csum, d.csum_cpad = csum.data_ptr(), csum.shape[2]
         if res is not None:
             d.res, d.cs_res = res.data_ptr(), res.stride(2)
         if out_mode == 2:
@@ -172,9 +205,15 @@ class Engine32(Engine):
         if not self.cab_closed_form or h < 2 or w < 2 or x.t.stride(2) != c:
             return super().cab(pre, x, extra)
         q = self.P.cas[pre + "CA"]
-        mid = self.conv(pre + "body.0", [x], prelu=self.P.scalar(pre + "body.1.weight"))
-        part = self._chan_sum(mid.t)
-        cpad = part.shape[2]
+        cpad = max(16, prep.ceil8(c))
+        if self.fuse_phase1 and self.split_bf16 and c % 4 == 0:      # the sums of mid come out of conv1's epilogue (no pass of sn32_chan_sum over mid)
+            part = torch.empty((T, self.lib.sn32_conv_csum_tiles(h, w), cpad), dtype=torch.float32, device=self.dev)
+            k0 = self.P.convs[pre + "body.0"]["key"]
+            mid = Act(self._conv32(k0 + "weight", k0 + "bias", [x.t], [c], k=3, prelu=self.P.scalar(pre + "body.1.weight"), csum=part,
+                                   label=pre + "body.0"), c)
+        else:
+            mid = self.conv(pre + "body.0", [x], prelu=self.P.scalar(pre + "body.1.weight"))
+            part = self._chan_sum(mid.t)
         scratch = torch.empty((self.lib.sn_cab_ca_scratch_floats(T),), dtype=torch.float32, device=self.dev)
         ca = torch.empty((T, cpad), dtype=torch.float32, device=self.dev)
         self._call("sn32_cab_ca", f"sn32_cab_ca[{pre}]", part.data_ptr(), part.shape[1], cpad, mid.t.data_ptr(), c, q["cr"], h, w,
@@ -194,7 +233,8 @@ class Engine32(Engine):
         cpad = max(16, prep.ceil8(c))
         nblk = 64
         part = torch.empty((T, nblk, cpad), dtype=torch.float32, device=self.dev)
-        self._call("sn32_chan_sum", "sn32_chan_sum", x.data_ptr(), x.stride(2), c, cpad, T, h * w, nblk, part.data_ptr(), self._stream())
+        self._call("sn32_chan_sum", "sn32_chan_sum", x.data_ptr(), x.stride(2), c, cpad, T, h * w, nblk, part.data_ptr(), self._stream(),
+                   alg_bytes=4.0 * T * h * w * c)
         return part
 
     def _gate_sum(self, a: torch.Tensor, out: torch.Tensor, mode: int) -> torch.Tensor:
@@ -203,7 +243,8 @@ class Engine32(Engine):
         cpad = max(16, prep.ceil8(c))
         nblk = 64
         part = torch.empty((T, nblk, cpad), dtype=torch.float32, device=self.dev)
-        self._call("sn32_gate_sum", "sn32_gate_sum", a.data_ptr(), c, cpad, mode, out.data_ptr(), T, h * w, nblk, part.data_ptr(), self._stream())
+        self._call("sn32_gate_sum", "sn32_gate_sum", a.data_ptr(), c, cpad, mode, out.data_ptr(), T, h * w, nblk, part.data_ptr(), self._stream(),
+                   alg_bytes=4.0 * T * h * w * 3 * c)
         return part
 
     def scale_residual(self, r: Act, x: Optional[Act], ca: torch.Tensor, extra: Optional[Act] = None) -> Act:
@@ -247,21 +288,40 @@ class Engine32(Engine):
         u = P.units[pre]
         dsd = P.dsd
         self._meta = ("naf32", T, h, w, c, mode)
-        if mode:
+        if mode and self.fuse_phase1 and c % 8 == 0:
+            vin = self._new(T, h, w, c + c // 2)                                  # cat(shortcut, conv1(shifted)); roll(x) is written once, here
+            w1 = P.wt(pre + "conv1.weight")                                       # [3][3][1][C/2]
+            us = None if self.fuse_shiftconv else self._new(T, h, w, c // 2)      # shift(borrowed half)
+            for wrap, halo, t0, nt in self._split_pieces(x, mode, V.wrap):
+                s = self._unit_src(x, mode, wrap=wrap, halo=halo, t0=t0, nt=nt)
+                self._call("sn32_gsts_shiftconv", "sn32_gsts_shiftconv", C.byref(s), P.offs.data_ptr(), w1.data_ptr() if us is None else None,
+                           vin.data_ptr(), us.data_ptr() if us is not None else None, self._stream(),
+                           alg_bytes=4.0 * (nt or T) * h * w * 2.5 * c)
+            if us is not None:
+                self._conv32(pre + "conv1.weight", None, [us], [c // 2], k=3, groups=c // 2, out=vin[..., c:])
+            shortcut = vin[..., :c]
+            kk = c + c // 2
+        elif mode:
             ug = self._new(T, h, w, c + c // 2)                                   # cat(roll(x), spatial_shift2(borrowed half))
             vin = self._new(T, h, w, c + c // 2)                                  # cat(shortcut, conv1(shifted)): the gather fills [:c] as well, conv1 writes [c:]
             for wrap, halo, t0, nt in self._split_pieces(x, mode, V.wrap):        # (temporal split: the boundary frame after its halo arrived)
                 s = self._unit_src(x, mode, wrap=wrap, halo=halo, t0=t0, nt=nt)
-                self._call("sn32_gsts_gather", "sn32_gsts_gather", C.byref(s), P.offs.data_ptr(), ug.data_ptr(), vin.data_ptr(), self._stream())
+                self._call("sn32_gsts_gather", "sn32_gsts_gather", C.byref(s), P.offs.data_ptr(), ug.data_ptr(), vin.data_ptr(), self._stream(),
+                           alg_bytes=4.0 * (nt or T) * h * w * 3.5 * c)
             shortcut = ug[..., :c]
             self._conv32(pre + "conv1.weight", None, [ug[..., c:]], [c // 2], k=3, groups=c // 2, out=vin[..., c:])
             kk = c + c // 2
         else:
             shortcut, vin, kk = x.t, x.t, c
-        v = self._new(T, h, w, kk)
-        self._call("sn32_layernorm", "sn32_layernorm", vin.data_ptr(), vin.stride(2), kk, dsd[pre + "norm.weight"].data_ptr(),
-                   dsd[pre + "norm.bias"].data_ptr(), v.data_ptr(), kk, npix, st)
-        a = self._conv32(pre + "body.0.weight", None, [v], [kk], k=1)                                             # 1x1 -> 2C
+        if self.fuse_phase1 and self.split_bf16 and kk % 4 == 0 and kk <= 128 and h * w >= 64 and vin.stride(2) % 4 == 0:
+            a = self._conv32(pre + "body.0.weight", None, [vin], [kk], k=1, ln=(dsd[pre + "norm.weight"], dsd[pre + "norm.bias"]))   # LayerNorm + 1x1 -> 2C
+        else:
+            v = self._new(T, h, w, kk)
+            self._call("sn32_layernorm", "sn32_layernorm", vin.data_ptr(), vin.stride(2), kk, dsd[pre + "norm.weight"].data_ptr(),
+                       dsd[pre + "norm.bias"].data_ptr(), v.data_ptr(), kk, npix, st, alg_bytes=8.0 * npix * kk)
+            a = self._conv32(pre + "body.0.weight", None, [v], [kk], k=1)                                         # 1x1 -> 2C
+        if self.fuse_phase1 and c % 4 == 0 and a.stride(2) % 4 == 0:
+            return self._naf_tail(pre, u, a, shortcut, T, h, w, c)
         a = self._conv32(pre + "body.1.conv_2.weight", None, [a], [2 * c], k=3, groups=2 * c, res=a)              # RepConv2
         g1 = self._new(T, h, w, c)
         if V.denoise:                                                                                               # SimpleGate + CALayer2 on g1
@@ -279,6 +339,47 @@ class Engine32(Engine):
         beta = dsd[pre + "beta"].reshape(1, c)
         y = self._conv32(ok + "weight", ok + "bias", [g2], [c], k=1, oscale=beta, oscale_stride=0, res=shortcut,  # shortcut + res * beta
                          iscale=ca2)                                                                                # ... is applied by this conv's loader
+        return Act(y, c)
+
+    # Phase 1 with fewer passes over the activations (SN_FP32_FUSE=0: one kernel per reference module, as _naf lists them):
+    #   * RepConv2 + SimpleGate [+ the channel sums for the denoisers' CALayer2] in one kernel (sn32_dw_gate: a' is never written);
+    #   * RepConv as one 5x5 conv with the merged weights (Plan32.rep_merged) instead of a 5x5 and a 3x3 pass;
+    #   * the denoisers' CALayer2 scale on g1 applied by RepConv's loader and on its residual (iscale / rscale; depthwise: the scale
+    #     commutes with the conv, so it is the output scale) -- g1 * ca1 is never materialised.
+    fuse_phase1 = os.environ.get("SN_FP32_FUSE", "1") != "0"
+    fuse_shiftconv = os.environ.get("SN_FP32_SHIFTCONV", "0") == "1"      # conv1 inside the channel_shift kernel: bit-identical, slower (see sn_f32.hip)
+
+    def _naf_tail(self, pre: str, u: Dict[str, object], a: torch.Tensor, shortcut: torch.Tensor, T: int, h: int, w: int, c: int) -> Act:
+        P, V, st = self.P, self.V, self._stream()
+        cpad = max(16, prep.ceil8(c))
+        nblk = 256 if h * w >= 256 * 64 else 64       # workgroups per frame: T x 256 fills the chip in whole rounds at 480p quadrants (T x 64 left a 25 % tail)
+        g1 = self._new(T, h, w, c)
+        part = torch.empty((T, nblk, cpad), dtype=torch.float32, device=self.dev) if V.denoise else None
+        wdw = P.wt(pre + "body.1.conv_2.weight")                                                                  # [3][3][1][2C]
+        self._call("sn32_dw_gate", "sn32_dw_gate", a.data_ptr(), a.stride(2), wdw.data_ptr(), c, cpad, g1.data_ptr(), T, h, w, nblk,
+                   part.data_ptr() if part is not None else None, st, alg_bytes=4.0 * T * h * w * 3 * c)
+        ca1 = self.ca_mlp(f"{pre}ca1", part, h * w) if V.denoise else None
+        rp = f"{pre}body.{u['rep']}."
+        if V.grouped_rep:
+            r = self._conv32(P.rep_merged(rp, False), None, [g1], [c], k=5, groups=c // 8, res=g1, iscale=ca1, rscale=ca1, label=rp + "merged")
+        else:
+            r = self._conv32(P.rep_merged(rp, True), None, [g1], [c], k=5, groups=c, oscale=ca1, oscale_stride=ca1.stride(0) if ca1 is not None else 0,
+                             label=rp + "merged")
+        g2 = self._new(T, h, w, c)
+        gk = f"{pre}body.{u['gate']}.weight"
+        if self.split_bf16 and (h * w) % 64 == 0 and c % 16 == 0 and r.stride(2) % 4 == 0:
+            # 1x1 -> 2C, SimpleGate2 and the sums for CALayer2 in the GEMM's epilogue: the 2C-channel tensor never reaches HBM
+            part2 = torch.empty((T, (h * w) // 64, cpad), dtype=torch.float32, device=self.dev)
+            self._meta = ("conv32", T, h, w, c, 2 * c, 1, 1, 0, 0)
+            self._call("sn32_conv1x1_gate2", f"sn32_conv1x1_gate2[{gk}]", r.data_ptr(), r.stride(2), c, P.wsplit(gk, 1).data_ptr(), c, cpad,
+                       g2.data_ptr(), T, h * w, part2.data_ptr(), st)
+        else:
+            b = self._conv32(gk, None, [r], [c], k=1)                                                               # 1x1 -> 2C
+            part2 = self._gate_sum(b, g2, 1)
+        ca2 = self.ca_mlp(f"{pre}ca2", part2, h * w)
+        ok = f"{pre}body.{u['out']}."
+        beta = P.dsd[pre + "beta"].reshape(1, c)
+        y = self._conv32(ok + "weight", ok + "bias", [g2], [c], k=1, oscale=beta, oscale_stride=0, res=shortcut, iscale=ca2)
         return Act(y, c)
 
     def _ingest(self, x: torch.Tensor, noise_map: Optional[torch.Tensor]) -> Act:

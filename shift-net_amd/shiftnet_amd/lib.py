@@ -15,14 +15,14 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libshiftnet_hip.so")
 
 SN_F32, SN_F16, SN_BF16 = 0, 1, 2
 
-ABI_VERSION = 12     # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so from before a struct / signature change fails the check in load()
+ABI_VERSION = 13     # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so from before a struct / signature change fails the check in load()
 
 SYMBOLS = [          # include/shiftnet_hip.h, production ABI
     "sn_abi_version", "sn_selftest_mfma", "sn_ingest", "sn_conv2d", "sn_conv_pool_blocks", "sn_ca_mlp",
     "sn_cab_ca", "sn_cab_ca_scratch_floats", "sn_planar_pitch", "sn_nhwc_to_planar", "sn_dw5m_blocks",
     "sn_dw5m_gemm_gate", "sn_gsts_gather", "sn_temporal_roll", "sn_gsts_shiftconv", "sn_gsts_cab2_phase2", "sn_cab1_phase2",
     "sn_ingest_u8", "sn_egress_blocks", "sn_egress_u8", "sn_ssim_blocks", "sn_ssim_u8",
-    "sn32_conv2d", "sn32_gsts_gather", "sn32_layernorm", "sn32_gate", "sn32_gate_sum", "sn32_chan_sum", "sn32_scale_residual", "sn32_ingest", "sn32_cab_ca",
+    "sn32_conv2d", "sn32_gsts_gather", "sn32_layernorm", "sn32_gate", "sn32_gate_sum", "sn32_chan_sum", "sn32_scale_residual", "sn32_ingest", "sn32_cab_ca", "sn32_dw_gate", "sn32_conv1x1_gate2", "sn32_gsts_shiftconv", "sn32_conv_csum_tiles",
     "sn_ln_gemm_gate", "sn_lngate_blocks", "sn_grp5_gemm_gate", "sn_grp5_blocks", "sn_gsts_cab2_phase1", "sn_cab1_phase1", "sn_phase1_pool_blocks",
 ]
 
@@ -73,7 +73,8 @@ class Conv32Desc(C.Structure):
         ("w", C.c_void_p), ("bias", C.c_void_p), ("act", C.c_int), ("prelu", C.c_float),
         ("oscale", C.c_void_p), ("oscale_stride", C.c_int), ("res", C.c_void_p), ("cs_res", C.c_int),
         ("out", C.c_void_p), ("cs_out", C.c_int), ("out_mode", C.c_int), ("nchw_dtype", C.c_int), ("sc", C.c_void_p),
-        ("wsplit", C.c_void_p), ("iscale", C.c_void_p), ("iscale_stride", C.c_int),
+        ("wsplit", C.c_void_p), ("iscale", C.c_void_p), ("iscale_stride", C.c_int), ("rscale", C.c_void_p), ("rscale_stride", C.c_int),
+        ("ln_w", C.c_void_p), ("ln_b", C.c_void_p), ("csum", C.c_void_p), ("csum_cpad", C.c_int),
     ]
 
 
@@ -142,6 +143,10 @@ def load() -> C.CDLL:
     lib.sn32_layernorm.argtypes = [vp, ci, ci, vp, vp, vp, ci, ll, vp]
     lib.sn32_gate.argtypes = [vp, ci, ci, vp, ll, vp]
     lib.sn32_gate_sum.argtypes = [vp, ci, ci, ci, vp, ci, ci, ci, vp, vp]
+    lib.sn32_dw_gate.argtypes = [vp, ci, vp, ci, ci, vp, ci, ci, ci, ci, vp, vp]
+    lib.sn32_conv_csum_tiles.argtypes = [ci, ci]
+    lib.sn32_gsts_shiftconv.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.sn32_conv1x1_gate2.argtypes = [vp, ci, ci, vp, ci, ci, vp, ci, ci, vp, vp]
     lib.sn32_chan_sum.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, vp]
     lib.sn32_scale_residual.argtypes = [vp, vp, vp, ci, vp, ci, ci, ci, vp]
     lib.sn32_ingest.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, vp]

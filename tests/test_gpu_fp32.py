@@ -97,6 +97,56 @@ def test_blocks_fp32(name, engines):
 
 
 @pytest.mark.parametrize("name", list(VARIANTS))
+def test_fused_phase1_fp32_against_one_kernel_per_module(name, engines):
+    """SN_FP32_FUSE (sn32_dw_gate, merged RepConv weights with iscale / rscale, sn32_conv1x1_gate2) against the chain that runs one kernel per
+    reference module, on a tile whose pixel count is a multiple of 64 (the gated 1x1 needs it; 20 x 44 of test_blocks_fp32 takes the fallback)
+    and on a ragged one.  Both against the oracle at the file's tolerance, and against each other ten times tighter: the fusions only
+    reorder fp32 additions (merged 5x5 + 3x3 weights, partial sums)."""
+    from shiftnet_amd.engine32 import Engine32
+    eng, sd = engines(name)
+    V = O.VARIANTS[name]
+    blk = "stage1.decoder_level1."
+    for (T, h, w, seed) in ((3, 16, 48, 83), (2, 13, 70, 84)):
+        x = torch.from_numpy(synth.unit_noise((T, V.c1, h, w), seed=seed))
+        xd = act(to_dev(x))
+        for mode, rev, unit in ((1, False, "encoder_level1.0."), (2, True, "encoder_level1_1.0."), (0, False, "encoder_level1.1.")):
+            pre = blk + unit
+            ref = O.cab2(sd, pre, O.gsts_gather(x, rev, V.wrap), V) if mode else O.cab1(sd, pre, x, V)
+            outs = {}
+            for fuse in (True, False):
+                old = Engine32.fuse_phase1
+                Engine32.fuse_phase1 = fuse
+                try:
+                    with torch.no_grad():
+                        outs[fuse] = to_cpu(eng.naf(pre, xd, mode).t)
+                finally:
+                    Engine32.fuse_phase1 = old
+                close(f"naf_{name}_{mode}_fuse{int(fuse)}_{h}x{w}", outs[fuse], ref)
+            close(f"naf_{name}_{mode}_fused_vs_chain_{h}x{w}", outs[True], outs[False], tol=1e-5)
+            if mode:                               # conv1 inside the channel_shift kernel (SN_FP32_SHIFTCONV=1): same taps in the same order
+                Engine32.fuse_shiftconv = True
+                try:
+                    with torch.no_grad():
+                        sc = to_cpu(eng.naf(pre, xd, mode).t)
+                finally:
+                    Engine32.fuse_shiftconv = False
+                assert torch.equal(sc, outs[True]), f"naf_{name}_{mode}_shiftconv_{h}x{w}"
+    # CAB: the sums of `mid` from conv1's epilogue (sn32_conv_desc.csum) against the sn32_chan_sum pass, ragged tile (partial workgroups)
+    x0 = torch.from_numpy(synth.unit_noise((3, V.c0, 23, 41), seed=85))
+    outs = {}
+    for fuse in (True, False):
+        old = Engine32.fuse_phase1
+        Engine32.fuse_phase1 = fuse
+        try:
+            with torch.no_grad():
+                outs[fuse] = to_cpu(eng.cab("stage1.concat.", act(to_dev(x0))).t)
+        finally:
+            Engine32.fuse_phase1 = old
+        close(f"cab_{name}_fuse{int(fuse)}", outs[fuse], O.cab(sd, "stage1.concat.", x0))
+    close(f"cab_{name}_fused_vs_chain", outs[True], outs[False], tol=1e-5)
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
 def test_whole_net_fp32_vs_reference_fixture(name, golden_dir):
     """float32 module through the drop-in class against the REFERENCE's fp32 output (tests/golden/net_*.npz)."""
     import importlib
