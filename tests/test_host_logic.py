@@ -47,6 +47,51 @@ def test_library_exports_every_declared_symbol():
     assert lib.sn_conv_pool_blocks(ctypes.byref(d)) == 90 * 40            # 8x32 tiles
 
 
+def test_fp32_entry_points_refuse_what_their_kernels_do_not_implement():
+    """The optional operands of sn32_conv_desc exist in specific kernels only; any other shape must come back SN_EINVAL (-22) from the host-side
+    checks (no GPU needed) instead of being silently ignored -- a LayerNorm / residual scale / channel sum that is not applied is a wrong result."""
+    from shiftnet_amd import lib as L
+    lib = L.load()
+    buf = (ctypes.c_char * 4096)()
+    p = (ctypes.addressof(buf) + 63) & ~63                     # a non-NULL, 64-byte aligned address; never dereferenced: validation precedes any launch
+
+    def desc(**kw):
+        d = L.Conv32Desc()
+        d.inp[0], d.c_in[0], d.cs_in[0], d.n_in = p, 80, 80, 1
+        d.T, d.h_in, d.w_in, d.h_out, d.w_out = 2, 16, 48, 16, 48
+        d.k, d.stride, d.pad, d.groups, d.c_out = 1, 1, 0, 1, 160
+        d.w, d.out, d.cs_out, d.wsplit = p, p, 160, p
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+
+    EINVAL = -22
+    # LayerNorm on load: split 1x1 only -- not without wsplit, not for k = 3, not without its bias vector, not together with an input scale
+    assert lib.sn32_conv2d(ctypes.byref(desc(ln_w=p, ln_b=p, wsplit=None)), None) == EINVAL
+    assert lib.sn32_conv2d(ctypes.byref(desc(ln_w=p, ln_b=p, k=3, pad=1)), None) == EINVAL
+    assert lib.sn32_conv2d(ctypes.byref(desc(ln_w=p, ln_b=None)), None) == EINVAL
+    assert lib.sn32_conv2d(ctypes.byref(desc(ln_w=p, ln_b=p, iscale=p, iscale_stride=80)), None) == EINVAL
+    # residual scale: grouped-by-8 only, and only with a residual
+    assert lib.sn32_conv2d(ctypes.byref(desc(rscale=p, rscale_stride=160, res=p, cs_res=160)), None) == EINVAL
+    assert lib.sn32_conv2d(ctypes.byref(desc(rscale=p, rscale_stride=80, k=5, pad=2, groups=10, c_out=80, cs_out=80)), None) == EINVAL
+    # channel sums: split dense 3x3 only, cpad within the kernel's M-tiles
+    assert lib.sn32_conv2d(ctypes.byref(desc(csum=p, csum_cpad=160)), None) == EINVAL
+    assert lib.sn32_conv2d(ctypes.byref(desc(csum=p, csum_cpad=8, k=3, pad=1, c_out=24, cs_out=24, c_in=(ctypes.c_int * 3)(24, 0, 0), cs_in=(ctypes.c_int * 3)(24, 0, 0))), None) == EINVAL
+    assert lib.sn32_conv_csum_tiles(272, 448) == 68 * 14
+    # fused operators
+    assert lib.sn32_dw_gate(p, 120, p, 80, 80, p, 2, 16, 48, 64, None, None) == EINVAL            # pixel stride below 2C
+    assert lib.sn32_dw_gate(p, 160, p, 78, 80, p, 2, 16, 48, 64, None, None) == EINVAL            # C not a multiple of 4
+    assert lib.sn32_dw_gate(p, 160, p, 80, 64, p, 2, 16, 48, 64, p, None) == EINVAL               # sums asked with cpad < C
+    assert lib.sn32_conv1x1_gate2(p, 80, 80, p, 80, 80, p, 2, 16 * 48 + 8, p, None) == EINVAL       # a workgroup would span two frames
+    assert lib.sn32_conv1x1_gate2(p, 80, 80, p, 72, 72, p, 2, 16 * 48, p, None) == EINVAL           # C not a multiple of 16
+    assert lib.sn32_conv1x1_gate2(p, 80, 80, None, 80, 80, p, 2, 16 * 48, p, None) == EINVAL        # exact-fp32 arithmetic has no gated form
+    s = L.UnitSrc(); s.x, s.T, s.h, s.w, s.C, s.mode = p, 2, 16, 48, 80, 1
+    assert lib.sn32_gsts_shiftconv(ctypes.byref(s), p, p, p, p, None) == EINVAL                    # both forms at once
+    assert lib.sn32_gsts_shiftconv(ctypes.byref(s), p, None, p, None, None) == EINVAL              # neither
+    s.C = 76
+    assert lib.sn32_gsts_shiftconv(ctypes.byref(s), p, None, p, p, None) == EINVAL                 # C % 8
+
+
 def test_dropin_class_contract():
     from basicsr.models.archs import gshift_deblur1, gshift_deblur2, gshift_denoise1, gshift_denoise2
     from shiftnet_amd.weights import synth_state_dict
