@@ -429,7 +429,11 @@ __global__ __launch_bounds__(256, 2) void conv32s_kernel(const Conv32K P) {
             const int pix = ec / Q, q = ec - pix * Q, ci = cbase + 4 * q;
             const int ry = pix / RW, rx = pix - ry * RW, gy = iy0 + ry, gx = ix0 + rx;
             const bool in = e < NPATCH * Q && ci < P.cin_total && gy >= 0 && gy < P.hin && gx >= 0 && gx < P.win;
-            v[it] = *(const float4*)(P.in0 + (in ? (((size_t)t * P.hin + gy) * P.win + gx) * P.cs0 + ci : 0));
+            // up to three inputs concatenated along channels (conv_hr0, rconcat): a quad never straddles two of them (every c_in % 4 == 0)
+            const float* src = P.in0; int cs = P.cs0, cl = ci;
+            if (ci >= P.cin0) { src = P.in1; cs = P.cs1; cl = ci - P.cin0; }
+            if (ci >= P.cin0 + P.cin1) { src = P.in2; cs = P.cs2; cl = ci - P.cin0 - P.cin1; }
+            v[it] = *(const float4*)(in ? src + (((size_t)t * P.hin + gy) * P.win + gx) * cs + cl : P.in0);
             if (!in) v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
@@ -1075,10 +1079,11 @@ int sn32_conv2d(const sn32_conv_desc* d, void* stream) {
         hipStream_t st = (hipStream_t)stream;
         const int mt = (d->c_out + 15) / 16;
         // split-precision path (bf16 hi + lo operands, three bf16 MFMAs per k-step): single float4-addressable input, stride 1, NHWC out
-        if (d->wsplit && d->n_in == 1 && d->in_mode == 0 && d->stride == 1 && (d->cs_in[0] & 3) == 0 && (K.cin_total & 3) == 0 &&
-            ((size_t)d->in[0] & 15) == 0 && ((size_t)d->wsplit & 15) == 0) {
+        bool quads = true;                    // every input addressable in aligned 16-byte quads that stay inside one input
+        for (int i = 0; i < d->n_in; ++i) quads = quads && (d->c_in[i] & 3) == 0 && (d->cs_in[i] & 3) == 0 && ((size_t)d->in[i] & 15) == 0;
+        if (d->wsplit && (d->n_in == 1 || (d->groups == 1 && !d->iscale)) && quads && d->in_mode == 0 && d->stride == 1 && ((size_t)d->wsplit & 15) == 0) {
             const int ncb1 = (K.cin_total + 31) / 32;
-            if (d->groups == 1 && d->k == 1 && d->pad == 0 && d->out_mode == 0 && ncb1 <= 4 && d->h_out * d->w_out >= SN_1X1_NPX && (d->c_out & 3) == 0 && (d->cs_out & 3) == 0 &&
+            if (d->n_in == 1 && d->groups == 1 && d->k == 1 && d->pad == 0 && d->out_mode == 0 && ncb1 <= 4 && d->h_out * d->w_out >= SN_1X1_NPX && (d->c_out & 3) == 0 && (d->cs_out & 3) == 0 &&
                 ((size_t)d->out & 15) == 0 && (!d->res || ((d->cs_res & 3) == 0 && ((size_t)d->res & 15) == 0)) && mt > 1) {
                 const long long npix = (long long)d->T * d->h_out * d->w_out;
                 const size_t lds = (size_t)SN_1X1_NPX * (ncb1 * 160 + ((ncb1 & 1) ? 0 : 32));

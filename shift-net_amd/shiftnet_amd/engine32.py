@@ -141,9 +141,12 @@ class Engine32(Engine):
         d.k, d.stride, d.pad, d.groups, d.h_out, d.w_out, d.c_out = k, stride, pad, groups, h_out, w_out, co
         d.w = w.data_ptr()
         cin = sum(cins)
-        if (self.split_bf16 and len(ins) == 1 and in_mode == 0 and out_mode == 0 and stride == 1 and cin % 4 == 0 and ins[0].stride(2) % 4 == 0
-                and ((groups == 1 and k in (1, 3) and pad == k // 2) or (groups > 1 and k in (3, 5) and pad == k // 2 and cin // groups == 8 and co // groups == 8 and co % 16 == 0))
-                and c_out is None):
+        # split-precision kernels: stride 1, no bilinear loader, NHWC or pixel-shuffle output; dense k = 1 / 3 with up to three concatenated inputs
+        # (conv_hr0, rconcat), grouped-by-8 k = 3 / 5 with one.  conv_last (NCHW + shortcut) and the stride-2 / upsampling convs keep exact products.
+        if (self.split_bf16 and in_mode == 0 and out_mode in (0, 1) and stride == 1 and c_out is None
+                and all(c % 4 == 0 for c in cins) and all(t.stride(2) % 4 == 0 for t in ins)
+                and ((groups == 1 and k in (1, 3) and pad == k // 2 and (len(ins) == 1 or iscale is None))
+                     or (len(ins) == 1 and groups > 1 and k in (3, 5) and pad == k // 2 and cin // groups == 8 and co // groups == 8 and co % 16 == 0))):
             d.wsplit = P.wsplit(wkey, groups).data_ptr()
         d.bias = P.dsd[bkey].data_ptr() if bkey is not None and bkey in P.dsd else None
         d.act, d.prelu = (1, prelu) if prelu is not None else (0, 0.0)
