@@ -8,8 +8,14 @@ Why it exists
     agreement with the CPU oracle to fp32 round-off (tests: <= 1e-4 of the tensor scale) pins that control flow and the
     weight bookkeeping independently of bf16 rounding noise.
 
-Leaf operators follow the reference modules one to one (no fusion, no repacking beyond a weight transpose); every
-activation is NHWC fp32 ``[T, H, W, C]`` with C the logical channel count.
+Every activation is NHWC fp32 ``[T, H, W, C]`` with C the logical channel count; weights are the checkpoint's fp32 values
+(transposed, and for the split-precision convs also as bf16 hi / lo fragments).  Two operator chains compute the same network:
+
+  * the default (round 4) removes the passes that only re-read and re-write an activation: gates and channel sums
+    in the producing conv's epilogue, LayerNorm in the consuming conv's loader, CALayer scales on the next conv's loader /
+    residual / epilogue, RepConv2 + SimpleGate in one kernel, RepConv as one merged 5x5;
+  * ``SN_FP32_FUSE=0`` (and ``SN_FP32_CAB_TAIL=0``) runs one kernel per reference module, in the reference's order -- the
+    validation chain: tests/test_gpu_fp32.py holds both to 1e-4 of the oracle and to 1e-5 of each other.
 """
 from __future__ import annotations
 
