@@ -215,7 +215,7 @@ class Engine32(Engine):
             return super().cab(pre, x, extra)
         q = self.P.cas[pre + "CA"]
         cpad = max(16, prep.ceil8(c))
-        if self.fuse_phase1 and self.split_bf16 and c % 4 == 0:      # the sums of mid come out of conv1's epilogue (no pass of sn32_chan_sum over mid)
+        if self.fuse_ops and self.split_bf16 and c % 4 == 0:      # the sums of mid come out of conv1's epilogue (no pass of sn32_chan_sum over mid)
             part = torch.empty((T, self.lib.sn32_conv_csum_tiles(h, w), cpad), dtype=torch.float32, device=self.dev)
             k0 = self.P.convs[pre + "body.0"]["key"]
             mid = Act(self._conv32(k0 + "weight", k0 + "bias", [x.t], [c], k=3, prelu=self.P.scalar(pre + "body.1.weight"), csum=part,
@@ -297,7 +297,7 @@ class Engine32(Engine):
         u = P.units[pre]
         dsd = P.dsd
         self._meta = ("naf32", T, h, w, c, mode)
-        if mode and self.fuse_phase1 and c % 8 == 0:
+        if mode and self.fuse_ops and c % 8 == 0:
             vin = self._new(T, h, w, c + c // 2)                                  # cat(shortcut, conv1(shifted)); roll(x) is written once, here
             w1 = P.wt(pre + "conv1.weight")                                       # [3][3][1][C/2]
             us = None if self.fuse_shiftconv else self._new(T, h, w, c // 2)      # shift(borrowed half)
@@ -322,14 +322,14 @@ class Engine32(Engine):
             kk = c + c // 2
         else:
             shortcut, vin, kk = x.t, x.t, c
-        if self.fuse_phase1 and self.split_bf16 and kk % 4 == 0 and kk <= 128 and h * w >= 64 and vin.stride(2) % 4 == 0:
+        if self.fuse_ops and self.split_bf16 and kk % 4 == 0 and kk <= 128 and h * w >= 64 and vin.stride(2) % 4 == 0:
             a = self._conv32(pre + "body.0.weight", None, [vin], [kk], k=1, ln=(dsd[pre + "norm.weight"], dsd[pre + "norm.bias"]))   # LayerNorm + 1x1 -> 2C
         else:
             v = self._new(T, h, w, kk)
             self._call("sn32_layernorm", "sn32_layernorm", vin.data_ptr(), vin.stride(2), kk, dsd[pre + "norm.weight"].data_ptr(),
                        dsd[pre + "norm.bias"].data_ptr(), v.data_ptr(), kk, npix, st, alg_bytes=8.0 * npix * kk)
             a = self._conv32(pre + "body.0.weight", None, [v], [kk], k=1)                                         # 1x1 -> 2C
-        if self.fuse_phase1 and c % 4 == 0 and a.stride(2) % 4 == 0:
+        if self.fuse_ops and c % 4 == 0 and a.stride(2) % 4 == 0:
             return self._naf_tail(pre, u, a, shortcut, T, h, w, c)
         a = self._conv32(pre + "body.1.conv_2.weight", None, [a], [2 * c], k=3, groups=2 * c, res=a)              # RepConv2
         g1 = self._new(T, h, w, c)
@@ -355,7 +355,7 @@ class Engine32(Engine):
     #   * RepConv as one 5x5 conv with the merged weights (Plan32.rep_merged) instead of a 5x5 and a 3x3 pass;
     #   * the denoisers' CALayer2 scale on g1 applied by RepConv's loader and on its residual (iscale / rscale; depthwise: the scale
     #     commutes with the conv, so it is the output scale) -- g1 * ca1 is never materialised.
-    fuse_phase1 = os.environ.get("SN_FP32_FUSE", "1") != "0"
+    fuse_ops = os.environ.get("SN_FP32_FUSE", "1") != "0"
     fuse_shiftconv = os.environ.get("SN_FP32_SHIFTCONV", "0") == "1"      # conv1 inside the channel_shift kernel: bit-identical, slower (see sn_f32.hip)
 
     def _naf_tail(self, pre: str, u: Dict[str, object], a: torch.Tensor, shortcut: torch.Tensor, T: int, h: int, w: int, c: int) -> Act:

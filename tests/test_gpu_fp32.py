@@ -114,13 +114,13 @@ def test_fused_phase1_fp32_against_one_kernel_per_module(name, engines):
             ref = O.cab2(sd, pre, O.gsts_gather(x, rev, V.wrap), V) if mode else O.cab1(sd, pre, x, V)
             outs = {}
             for fuse in (True, False):
-                old = Engine32.fuse_phase1
-                Engine32.fuse_phase1 = fuse
+                old = Engine32.fuse_ops
+                Engine32.fuse_ops = fuse
                 try:
                     with torch.no_grad():
                         outs[fuse] = to_cpu(eng.naf(pre, xd, mode).t)
                 finally:
-                    Engine32.fuse_phase1 = old
+                    Engine32.fuse_ops = old
                 close(f"naf_{name}_{mode}_fuse{int(fuse)}_{h}x{w}", outs[fuse], ref)
             close(f"naf_{name}_{mode}_fused_vs_chain_{h}x{w}", outs[True], outs[False], tol=1e-5)
             if mode:                               # conv1 inside the channel_shift kernel (SN_FP32_SHIFTCONV=1): same taps in the same order
@@ -135,13 +135,13 @@ def test_fused_phase1_fp32_against_one_kernel_per_module(name, engines):
     x0 = torch.from_numpy(synth.unit_noise((3, V.c0, 23, 41), seed=85))
     outs = {}
     for fuse in (True, False):
-        old = Engine32.fuse_phase1
-        Engine32.fuse_phase1 = fuse
+        old = Engine32.fuse_ops
+        Engine32.fuse_ops = fuse
         try:
             with torch.no_grad():
                 outs[fuse] = to_cpu(eng.cab("stage1.concat.", act(to_dev(x0))).t)
         finally:
-            Engine32.fuse_phase1 = old
+            Engine32.fuse_ops = old
         close(f"cab_{name}_fuse{int(fuse)}", outs[fuse], O.cab(sd, "stage1.concat.", x0))
     close(f"cab_{name}_fused_vs_chain", outs[True], outs[False], tol=1e-5)
 

@@ -399,3 +399,37 @@ def test_phase1r_emulation_of_the_denoisers_two_passes(name):
         got, _ = emu.cab_phase1r(nhwc(x), None, pk, 0, V.wrap, ca_in=ca.numpy())
         err = (nchw(got, C) - ref).abs().max().item()
         assert err < 0.02 * max(1.0, ref.abs().max().item()), (name, err)
+
+
+@pytest.mark.parametrize("name", ["gshift_deblur1", "gshift_deblur2", "gshift_denoise1", "gshift_denoise2"])
+def test_fp32_plan_merged_repconv_weights(name):
+    """Plan32.rep_merged (the fp32 engine's single 5x5 RepConv): conv(g, merged) [+ g] equals the reference's three terms conv_1(g) + g +
+    conv_2(g) (gshift_deblur1.py:143-165) to fp32 round-off, for the grouped 8 -> 8 form (identity left to the kernel's residual) and the
+    depthwise form (identity merged at the centre tap); and the denoisers' per-frame channel scale commutes the way the engine applies it:
+    loader + residual scale (grouped), output scale (depthwise)."""
+    import torch.nn.functional as F
+    from shiftnet_amd.engine32 import Plan32
+    V = VARIANTS[name]
+    sd = synth_state_dict(name)
+    P = Plan32(V, sd, torch.device("cpu"))
+    pre = "stage1.decoder_level1.encoder_level1.0."
+    rp = f"{pre}body.{P.units[pre]['rep']}."
+    c = V.c1
+    grp = c // 8 if V.grouped_rep else c
+    g = torch.from_numpy(synth.unit_noise((2, c, 12, 20), seed=7)).double()
+    w5, w3 = sd[rp + "conv_1.weight"].double(), sd[rp + "conv_2.weight"].double()
+    ref = F.conv2d(g, w5, padding=2, groups=grp) + g + F.conv2d(g, w3, padding=1, groups=grp)
+    key = P.rep_merged(rp, identity=not V.grouped_rep)
+    m = P.sd[key]
+    assert m.dtype == torch.float32 and m.shape == sd[rp + "conv_1.weight"].shape
+    got = F.conv2d(g, m.double(), padding=2, groups=grp) + (g if V.grouped_rep else 0)
+    assert (got - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
+    assert P.rep_merged(rp, identity=not V.grouped_rep) == key and torch.equal(P.dsd[key], m)            # cached under one key, host and device copies
+    # RepConv of g * s[t, c] (CALayer2 of the denoisers, gshift_denoise1.py): what the engine computes instead of materialising g * s
+    sc = torch.rand(2, c, 1, 1, dtype=torch.float64) + 0.5
+    ref_s = F.conv2d(g * sc, w5, padding=2, groups=grp) + g * sc + F.conv2d(g * sc, w3, padding=1, groups=grp)
+    if V.grouped_rep:       # iscale on the loader, rscale on the residual
+        got_s = F.conv2d(g * sc, m.double(), padding=2, groups=grp) + g * sc
+    else:                   # depthwise: one input channel per output channel, the scale is an output scale
+        got_s = F.conv2d(g, m.double(), padding=2, groups=grp) * sc
+    assert (got_s - ref_s).abs().max().item() <= 2e-6 * max(1.0, ref_s.abs().max().item())
