@@ -69,6 +69,39 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
+def kernel_sources():
+    """{source file: names of the __global__ kernels it defines} for shift-net_amd/csrc/*.hip (template kernels by their base name)."""
+    import re
+    d = os.path.join(ROOT, "shift-net_amd", "csrc")
+    out = {}
+    for f in sorted(os.listdir(d)):
+        if f.endswith(".hip"):
+            out[f] = set(re.findall(r"__global__[^;{]*?\bvoid\s+(\w+)\s*\(", open(os.path.join(d, f)).read(), flags=re.S))
+    return out
+
+
+def csrc_files(kernel_names):
+    """Identity of the sources a set of traced kernels was compiled from: sha256[:16] of every translation unit that defines one of them, plus
+    the headers every unit includes.  Each .hip is compiled on its own (build.py), so a change in a unit none of whose kernels ran in the
+    trace cannot change what the trace measured -- and a change anywhere else voids it."""
+    import hashlib
+    import re
+    d = os.path.join(ROOT, "shift-net_amd", "csrc")
+    base = {re.sub(r"^.*::", "", k.split("<")[0].split("(")[0]).strip() for k in kernel_names}
+    files = [f for f, ks in kernel_sources().items() if ks & base]
+    files += [f for f in sorted(os.listdir(d)) if f.endswith(".h")] + [os.path.join("..", "..", "include", "shiftnet_hip.h")]
+    return {os.path.basename(f): hashlib.sha256(open(os.path.join(d, f), "rb").read()).hexdigest()[:16] for f in files}
+
+
+def pmc_sources_changed(doc):
+    """Source files of the kernels in a PMC summary (tools/pmc_summary.py) whose content differs from what the summary was measured on."""
+    want = doc.get("csrc_files")
+    if not want:                                   # files written before the per-unit record: the whole tree must match
+        return [] if doc.get("csrc_hash") == csrc_hash() else ["(whole tree: csrc_hash)"]
+    have = csrc_files(doc["kernels_per_window"].keys())
+    return sorted(f for f in set(want) | set(have) if want.get(f) != have.get(f))
+
+
 def symbol_key(sym):
     """rocprofv3 kernel name -> the key bench.py aggregates the same kernel under (None: not one of ours)."""
     import re
@@ -388,7 +421,8 @@ def main():
         # HBM traffic from the committed PMC passes of THIS command line run with --no-parity --no-cpu-baseline (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE, separate passes, tools/make_profiles_r04.sh -> tools/pmc_summary.py): bytes per WINDOW per kernel = sum over the kernel's
         # launches / windows in the trace, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950.  The file
-        # names the sources it was measured on (csrc_hash); after any kernel change the figure is reported as null until the passes are re-run.
+        # names the sources its kernels were compiled from (csrc_files: per translation unit + shared headers); after a change to any of them the
+        # figure is reported as null until the passes are re-run.
         # A figure below 0.9 x the algorithmic bytes cannot be right either (every input is read at least once).
         pmc, pmc_note = None, "no PMC passes for this configuration under profiles/"
         preset = args.config if args.config is not None else (2 if (args.variant, h, w, L, len(quads)) == (VARIANT, H, W, ONE_LEN, 1) else None)
@@ -396,8 +430,9 @@ def main():
         if pmc_file:
             try:
                 doc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
-                if doc.get("csrc_hash") != csrc_hash():
-                    pmc_note = f"profiles/{pmc_file} was measured on other kernel sources (csrc_hash {doc.get('csrc_hash')} != {csrc_hash()}): re-run tools/make_profiles_r04.sh"
+                changed = pmc_sources_changed(doc)
+                if changed:
+                    pmc_note = f"profiles/{pmc_file} was measured on other sources of its kernels (changed since: {', '.join(changed)}): re-run tools/make_profiles_r04.sh"
                 else:
                     pmc = {}
                     for sym, v in doc["kernels_per_window"].items():
@@ -406,7 +441,8 @@ def main():
                             e = pmc.setdefault(k, {"FETCH_SIZE_KB": 0.0, "WRITE_SIZE_KB": 0.0})
                             e["FETCH_SIZE_KB"] += v.get("FETCH_SIZE_KB", 0.0); e["WRITE_SIZE_KB"] += v.get("WRITE_SIZE_KB", 0.0)
                     pmc_note = (f"profiles/{pmc_file}: 2 x FETCH_SIZE + WRITE_SIZE summed over the kernel's launches of one window "
-                                f"({doc.get('windows_in_trace')} full windows in the trace, no parity sample, csrc_hash {doc.get('csrc_hash')})")
+                                f"({doc.get('windows_in_trace')} full windows in the trace, no parity sample, sources of its kernels unchanged: "
+                                f"{', '.join(sorted(doc.get('csrc_files', {'csrc_hash': 0})))})")
             except Exception as e:                                      # noqa: BLE001
                 pmc_note = f"PMC file unreadable: {e}"
 

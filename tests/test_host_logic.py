@@ -92,6 +92,28 @@ def test_fp32_entry_points_refuse_what_their_kernels_do_not_implement():
     assert lib.sn32_gsts_shiftconv(ctypes.byref(s), p, None, p, p, None) == EINVAL                 # C % 8
 
 
+def test_pmc_summaries_are_bound_to_the_sources_of_their_kernels():
+    """bench.py reports PMC traffic only while every translation unit that defines a kernel of the trace (and the shared headers) is unchanged."""
+    import copy
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    ks = bench.kernel_sources()
+    assert "cab_phase1r_kernel" in ks["sn_phase1r.hip"] and "scale_gemm_res_kernel" in ks["sn_gsts.hip"] and "conv32s_kernel" in ks["sn_f32.hip"]
+    assert not set.intersection(*[ks["sn_f32.hip"], set().union(*(v for f, v in ks.items() if f != "sn_f32.hip"))])     # a kernel name maps to one unit
+    doc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_hbm_traffic_cfg2.json")))
+    files = doc["csrc_files"]
+    assert {"sn_phase1r.hip", "sn_gsts.hip", "sn_conv.hip", "sn_common.h", "shiftnet_hip.h"} <= set(files)
+    assert "sn_f32.hip" not in files                       # a bf16 window launches nothing from the fp32 engine's unit
+    assert files == bench.csrc_files(doc["kernels_per_window"].keys()) or bench.pmc_sources_changed(doc)     # consistent either way
+    stale = copy.deepcopy(doc)
+    stale["csrc_files"]["sn_gsts.hip"] = "0" * 16
+    assert bench.pmc_sources_changed(stale) == ["sn_gsts.hip"]
+    old = {k: v for k, v in doc.items() if k != "csrc_files"}           # summaries from before the per-unit record: whole tree or nothing
+    old["csrc_hash"] = "0" * 16
+    assert bench.pmc_sources_changed(old) == ["(whole tree: csrc_hash)"]
+
+
 def test_dropin_class_contract():
     from basicsr.models.archs import gshift_deblur1, gshift_deblur2, gshift_denoise1, gshift_denoise2
     from shiftnet_amd.weights import synth_state_dict

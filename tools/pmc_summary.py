@@ -53,8 +53,9 @@ def main(out, windows, note, dirs):
             e["launches_per_window"] = round(n / windows, 3)
         by_grid[k] = e
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from bench import csrc_hash          # the kernels these counters were measured on: bench.py ignores the file once the sources change
-    doc = {"note": note, "csrc_hash": csrc_hash(), "windows_in_trace": windows, "kernels_per_window": per_win, "by_grid_per_launch": by_grid}
+    from bench import csrc_files, csrc_hash   # the sources these kernels were compiled from: bench.py ignores the file once one of them changes
+    doc = {"note": note, "csrc_hash": csrc_hash(), "csrc_files": csrc_files(per_win.keys()), "windows_in_trace": windows,
+           "kernels_per_window": per_win, "by_grid_per_launch": by_grid}
     if any("FETCH_SIZE_KB" in e and "WRITE_SIZE_KB" in e for e in per_win.values()):
         gb = lambda e: (2 * e.get("FETCH_SIZE_KB", 0.0) + e.get("WRITE_SIZE_KB", 0.0)) * 1024 / 1e9
         mine = {k: e for k, e in per_win.items() if "at::" not in k and "rocclr" not in k and "elementwise" not in k}
