@@ -336,11 +336,7 @@ __global__ __launch_bounds__(256) void conv32m_kernel(const Conv32K P) {
                     const float* os = P.oscale + (size_t)t * P.oscale_stride + c0;
                     a[0] *= os[0]; a[1] *= os[1]; a[2] *= os[2]; a[3] *= os[3];
                 }
-                if (P.res) {
-                    float4 rr = *(const float4*)(P.res + pix * P.cs_res + c0);
-                    if (P.rscale) { const float4 q = *(const float4*)(P.rscale + (size_t)t * P.rscale_stride + c0); rr.x *= q.x; rr.y *= q.y; rr.z *= q.z; rr.w *= q.w; }
-                    a[0] += rr.x; a[1] += rr.y; a[2] += rr.z; a[3] += rr.w;
-                }
+                if (P.res) { const float4 rr = *(const float4*)(P.res + pix * P.cs_res + c0); a[0] += rr.x; a[1] += rr.y; a[2] += rr.z; a[3] += rr.w; }
                 *(float4*)((float*)P.out + pix * P.cs_out + c0) = make_float4(a[0], a[1], a[2], a[3]);
                 continue;
             }
@@ -352,7 +348,7 @@ __global__ __launch_bounds__(256) void conv32m_kernel(const Conv32K P) {
                 if (P.bias) a += P.bias[c];
                 if (P.act == 1) a = a >= 0.f ? a : a * P.prelu;
                 if (P.oscale) a *= P.oscale[(size_t)t * P.oscale_stride + c];
-                if (P.res) a += P.res[pix * P.cs_res + c] * (P.rscale ? P.rscale[(size_t)t * P.rscale_stride + c] : 1.0f);
+                if (P.res) a += P.res[pix * P.cs_res + c];
                 if (P.out_mode == 0) {
                     ((float*)P.out)[pix * P.cs_out + c] = a;
                 } else if (P.out_mode == 1) {
@@ -563,10 +559,12 @@ int launch_conv32s(const Conv32K& K, hipStream_t st) {
 // a wave takes the M-tile PAIRS (m, m + C/16), gates in registers and stores the C-channel result -- the 2C-channel tensor is neither written
 // nor read back -- and leaves the per-workgroup channel sums of the result for the CALayer2 behind the gate (partial [npix / NPX][cpad];
 // a workgroup must not span two frames: hw % NPX == 0, checked by the entry point).
-// LNF: LayerNorm2d (gshift_deblur1.py:19-28) of the input pixel while it is staged -- the eight lanes that load a pixel's 32-channel blocks hold all of
+// LOAD 2: the input is [T][hin/2][win/2] and is upsampled x2 bilinearly while it is staged (SkipUpSample, gshift_deblur1.py:341-350: four 16-byte loads per
+// staged quad, the arithmetic of ld_bilinear32) -- the exact-product kernel did this with four scalar loads per ELEMENT, 0.66 ms per launch for 1 GB.
+// LOAD 1 (LNF): LayerNorm2d (gshift_deblur1.py:19-28) of the input pixel while it is staged -- the eight lanes that load a pixel's 32-channel blocks hold all of
 // its channels in registers, so mean and variance (two-pass, as layernorm32_kernel) cost three lane exchanges each and the normalised tensor
 // is neither written nor read.
-template <int NCB, bool GATE, bool LNF>
+template <int NCB, bool GATE, int LOAD>
 __global__ __launch_bounds__(256, 2) void conv32s_1x1_kernel(const Conv32K P, const long long npix, float* partial, const int cpad) {
     constexpr int ncb = NCB;                                         // compile-time: the k-loop unrolls and a group's weight fragments load up front
     extern __shared__ __attribute__((aligned(16))) float smem32[];
@@ -577,7 +575,40 @@ __global__ __launch_bounds__(256, 2) void conv32s_1x1_kernel(const Conv32K P, co
     const long long pix0 = (long long)blockIdx.x * NPX;
     const int hw = P.hout * P.wout;
     const int t0 = (int)(pix0 / hw), prem = (int)(pix0 - (long long)t0 * hw);     // frame of the first pixel (a workgroup spans at most two: hw >= 128)
-    if constexpr (LNF) {
+    constexpr bool LNF = LOAD == 1;
+    if constexpr (LOAD == 2) {
+        const int hs = P.hin >> 1, ws = P.win >> 1;
+#pragma unroll
+        for (int cb = 0; cb < ncb; ++cb) {
+#pragma unroll
+            for (int it = 0; it < NPX * 8 / 256; ++it) {
+                const int e = tid + it * 256, pl = e >> 3, q = e & 7, ci = cb * 32 + 4 * q;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ci < P.cin_total && pix0 + pl < npix) {
+                    int rem = prem + pl, t = t0;
+                    if (rem >= hw) { rem -= hw; ++t; }
+                    const int gy = rem / P.win, gx = rem - gy * P.win;
+                    // nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False): src = dst * 0.5 - 0.25, clamped at 0 (as ld_bilinear32)
+                    float sy = gy * 0.5f - 0.25f; if (sy < 0.f) sy = 0.f;
+                    float sx = gx * 0.5f - 0.25f; if (sx < 0.f) sx = 0.f;
+                    const int y0 = (int)sy, x0 = (int)sx, y1 = min(y0 + 1, hs - 1), x1 = min(x0 + 1, ws - 1);
+                    const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+                    const float* b = P.in0 + (size_t)t * hs * ws * P.cs0 + ci;
+                    const float4 v00 = *(const float4*)(b + ((size_t)y0 * ws + x0) * P.cs0), v01 = *(const float4*)(b + ((size_t)y0 * ws + x1) * P.cs0);
+                    const float4 v10 = *(const float4*)(b + ((size_t)y1 * ws + x0) * P.cs0), v11 = *(const float4*)(b + ((size_t)y1 * ws + x1) * P.cs0);
+                    x.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+                    x.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+                    x.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+                    x.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+                }
+                const uint32_t h01 = pack_bf2(x.x, x.y), h23 = pack_bf2(x.z, x.w);
+                const uint32_t l01 = pack_bf2(x.x - __uint_as_float(h01 << 16), x.y - __uint_as_float(h01 & 0xffff0000u));
+                const uint32_t l23 = pack_bf2(x.z - __uint_as_float(h23 << 16), x.w - __uint_as_float(h23 & 0xffff0000u));
+                *(uint2*)(lds + pl * PSK + cb * 160 + 8 * q) = make_uint2(h01, h23);
+                *(uint2*)(lds + pl * PSK + cb * 160 + 64 + 8 * q) = make_uint2(l01, l23);
+            }
+        }
+    } else if constexpr (LNF) {
         constexpr int IT = NPX * 8 / 256;
         const int q = tid & 7;
         float4 v[NCB][IT];
@@ -1070,8 +1101,11 @@ int sn32_conv2d(const sn32_conv_desc* d, void* stream) {
         // channel sums of the output: the split dense 3x3 kernel only
         if (d->csum && !(split1 && d->k == 3 && d->pad == 1 && d->csum_cpad >= d->c_out && d->csum_cpad <= 16 * mt0)) return SN_EINVAL;
     }
-    // the residual scale exists in the grouped-by-8 matrix-core kernels only (the "+" RepConv of the denoisers: res = g1 * ca1, never materialised)
-    if (d->rscale && !(d->res && d->groups > 1 && cin_g == 8 && cout_g == 8 && d->c_out % 16 == 0 && (d->rscale_stride & 3) == 0 && ((size_t)d->rscale & 15) == 0)) return SN_EINVAL;
+    // the residual scale exists in the SPLIT-PRECISION grouped-by-8 kernels only (the "+" RepConv of the denoisers: res = g1 * ca1, never materialised;
+    // in the exact kernels its operand cost conv32m_kernel<5, 8, 32> a wave of occupancy: 115 -> 188 VGPRs): same conditions as the dispatch below
+    if (d->rscale && !(d->res && d->wsplit && ((size_t)d->wsplit & 15) == 0 && d->groups > 1 && cin_g == 8 && cout_g == 8 && d->c_out % 16 == 0 && d->n_in == 1 &&
+                       d->in_mode == 0 && d->stride == 1 && (d->c_in[0] & 3) == 0 && (d->cs_in[0] & 3) == 0 && ((size_t)d->in[0] & 15) == 0 &&
+                       ((d->k == 5 && d->pad == 2) || (d->k == 3 && d->pad == 1)) && (d->rscale_stride & 3) == 0 && ((size_t)d->rscale & 15) == 0)) return SN_EINVAL;
     // the input scale is implemented by the matrix-core kernels' 16-byte staging path only
     if (d->iscale && !((d->groups == 1 || (cin_g == 8 && cout_g == 8 && d->c_out % 16 == 0)) && d->n_in == 1 && d->in_mode == 0 && (d->cs_in[0] & 3) == 0 &&
                        (K.cin_total & 3) == 0 && ((size_t)d->in[0] & 15) == 0 && (d->iscale_stride & 3) == 0 && ((size_t)d->iscale & 15) == 0)) return SN_EINVAL;
@@ -1081,6 +1115,21 @@ int sn32_conv2d(const sn32_conv_desc* d, void* stream) {
         // split-precision path (bf16 hi + lo operands, three bf16 MFMAs per k-step): single float4-addressable input, stride 1, NHWC out
         bool quads = true;                    // every input addressable in aligned 16-byte quads that stay inside one input
         for (int i = 0; i < d->n_in; ++i) quads = quads && (d->c_in[i] & 3) == 0 && (d->cs_in[i] & 3) == 0 && ((size_t)d->in[i] & 15) == 0;
+        // SkipUpSample: bilinear x2 on load + 1x1 (+ residual) on the flat-pixel split kernel; anything it does not cover keeps the exact kernel below
+        if (d->wsplit && d->in_mode == 1 && d->n_in == 1 && quads && d->stride == 1 && ((size_t)d->wsplit & 15) == 0 && d->groups == 1 && d->k == 1 && d->pad == 0 &&
+            d->out_mode == 0 && !d->iscale && !d->ln_w && !d->csum && (K.cin_total + 31) / 32 <= 4 && d->h_out * d->w_out >= SN_1X1_NPX && (d->c_out & 3) == 0 &&
+            (d->cs_out & 3) == 0 && ((size_t)d->out & 15) == 0 && (!d->res || ((d->cs_res & 3) == 0 && ((size_t)d->res & 15) == 0)) && mt > 1) {
+            const int ncb1 = (K.cin_total + 31) / 32;
+            const long long npix = (long long)d->T * d->h_out * d->w_out;
+            const size_t lds = (size_t)SN_1X1_NPX * (ncb1 * 160 + ((ncb1 & 1) ? 0 : 32));
+            const dim3 grid((unsigned)((npix + SN_1X1_NPX - 1) / SN_1X1_NPX));
+#define SN_1X1_CASE(N) case N: \
+            if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv32s_1x1_kernel<N, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH; \
+            hipLaunchKernelGGL((conv32s_1x1_kernel<N, false, 2>), grid, dim3(256), lds, st, K, npix, (float*)nullptr, 0); break;
+            switch (ncb1) { SN_1X1_CASE(1) SN_1X1_CASE(2) SN_1X1_CASE(3) SN_1X1_CASE(4) }
+#undef SN_1X1_CASE
+            return sn_check_launch();
+        }
         if (d->wsplit && (d->n_in == 1 || (d->groups == 1 && !d->iscale)) && quads && d->in_mode == 0 && d->stride == 1 && ((size_t)d->wsplit & 15) == 0) {
             const int ncb1 = (K.cin_total + 31) / 32;
             if (d->n_in == 1 && d->groups == 1 && d->k == 1 && d->pad == 0 && d->out_mode == 0 && ncb1 <= 4 && d->h_out * d->w_out >= SN_1X1_NPX && (d->c_out & 3) == 0 && (d->cs_out & 3) == 0 &&
@@ -1090,11 +1139,11 @@ int sn32_conv2d(const sn32_conv_desc* d, void* stream) {
                 const dim3 grid((unsigned)((npix + SN_1X1_NPX - 1) / SN_1X1_NPX));
 #define SN_1X1_CASE(N) case N: \
                     if (d->ln_w) { \
-                        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv32s_1x1_kernel<N, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH; \
-                        hipLaunchKernelGGL((conv32s_1x1_kernel<N, false, true>), grid, dim3(256), lds, st, K, npix, (float*)nullptr, 0); break; \
+                        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv32s_1x1_kernel<N, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH; \
+                        hipLaunchKernelGGL((conv32s_1x1_kernel<N, false, 1>), grid, dim3(256), lds, st, K, npix, (float*)nullptr, 0); break; \
                     } \
-                    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv32s_1x1_kernel<N, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH; \
-                    hipLaunchKernelGGL((conv32s_1x1_kernel<N, false, false>), grid, dim3(256), lds, st, K, npix, (float*)nullptr, 0); break;
+                    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv32s_1x1_kernel<N, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH; \
+                    hipLaunchKernelGGL((conv32s_1x1_kernel<N, false, 0>), grid, dim3(256), lds, st, K, npix, (float*)nullptr, 0); break;
                 switch (ncb1) { SN_1X1_CASE(1) SN_1X1_CASE(2) SN_1X1_CASE(3) SN_1X1_CASE(4) }
 #undef SN_1X1_CASE
                 return sn_check_launch();
@@ -1183,8 +1232,8 @@ int sn32_conv1x1_gate2(const float* x, int cs_x, int cin, const void* wsplit, in
     const dim3 grid((unsigned)(npix / SN_1X1_NPX));
     hipStream_t st = (hipStream_t)stream;
 #define SN_1X1_CASE(N) case N: \
-    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv32s_1x1_kernel<N, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH; \
-    hipLaunchKernelGGL((conv32s_1x1_kernel<N, true, false>), grid, dim3(256), lds, st, K, npix, partial, cpad); break;
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv32s_1x1_kernel<N, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH; \
+    hipLaunchKernelGGL((conv32s_1x1_kernel<N, true, 0>), grid, dim3(256), lds, st, K, npix, partial, cpad); break;
     switch (ncb1) { SN_1X1_CASE(1) SN_1X1_CASE(2) SN_1X1_CASE(3) SN_1X1_CASE(4) }
 #undef SN_1X1_CASE
     return sn_check_launch();

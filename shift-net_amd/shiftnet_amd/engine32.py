@@ -149,10 +149,12 @@ class Engine32(Engine):
         cin = sum(cins)
         # split-precision kernels: stride 1, no bilinear loader, NHWC or pixel-shuffle output; dense k = 1 / 3 with up to three concatenated inputs
         # (conv_hr0, rconcat), grouped-by-8 k = 3 / 5 with one.  conv_last (NCHW + shortcut) and the stride-2 / upsampling convs keep exact products.
-        if (self.split_bf16 and in_mode == 0 and out_mode in (0, 1) and stride == 1 and c_out is None
+        # The bilinear x2 loader (SkipUpSample) exists in the flat 1x1 split kernel; shapes it does not cover fall back to exact products in the library.
+        if (self.split_bf16 and out_mode in (0, 1) and stride == 1 and c_out is None
                 and all(c % 4 == 0 for c in cins) and all(t.stride(2) % 4 == 0 for t in ins)
-                and ((groups == 1 and k in (1, 3) and pad == k // 2 and (len(ins) == 1 or iscale is None))
-                     or (len(ins) == 1 and groups > 1 and k in (3, 5) and pad == k // 2 and cin // groups == 8 and co // groups == 8 and co % 16 == 0))):
+                and ((in_mode == 0 and groups == 1 and k in (1, 3) and pad == k // 2 and (len(ins) == 1 or iscale is None))
+                     or (in_mode == 0 and len(ins) == 1 and groups > 1 and k in (3, 5) and pad == k // 2 and cin // groups == 8 and co // groups == 8 and co % 16 == 0)
+                     or (in_mode == 1 and self.split_bilinear and len(ins) == 1 and groups == 1 and k == 1 and pad == 0 and out_mode == 0 and iscale is None))):
             d.wsplit = P.wsplit(wkey, groups).data_ptr()
         d.bias = P.dsd[bkey].data_ptr() if bkey is not None and bkey in P.dsd else None
         d.act, d.prelu = (1, prelu) if prelu is not None else (0, 0.0)
@@ -356,6 +358,7 @@ class Engine32(Engine):
     #   * the denoisers' CALayer2 scale on g1 applied by RepConv's loader and on its residual (iscale / rscale; depthwise: the scale
     #     commutes with the conv, so it is the output scale) -- g1 * ca1 is never materialised.
     fuse_ops = os.environ.get("SN_FP32_FUSE", "1") != "0"
+    split_bilinear = os.environ.get("SN_FP32_SPLIT_BILINEAR", "1") != "0"   # SkipUpSample's 1x1 on the split-precision kernel (0: the exact-product kernel of round 3)
     fuse_shiftconv = os.environ.get("SN_FP32_SHIFTCONV", "0") == "1"      # conv1 inside the channel_shift kernel: bit-identical, slower (see sn_f32.hip)
 
     def _naf_tail(self, pre: str, u: Dict[str, object], a: torch.Tensor, shortcut: torch.Tensor, T: int, h: int, w: int, c: int) -> Act:
@@ -369,8 +372,11 @@ class Engine32(Engine):
                    part.data_ptr() if part is not None else None, st, alg_bytes=4.0 * T * h * w * 3 * c)
         ca1 = self.ca_mlp(f"{pre}ca1", part, h * w) if V.denoise else None
         rp = f"{pre}body.{u['rep']}."
-        if V.grouped_rep:
+        if V.grouped_rep and (ca1 is None or self.split_bf16):
             r = self._conv32(P.rep_merged(rp, False), None, [g1], [c], k=5, groups=c // 8, res=g1, iscale=ca1, rscale=ca1, label=rp + "merged")
+        elif V.grouped_rep:                       # exact products: the residual scale lives in the split-precision kernels only, g1 * ca1 is a pass of its own
+            g1 = self.scale_residual(Act(g1, c), None, ca1).t
+            r = self._conv32(P.rep_merged(rp, False), None, [g1], [c], k=5, groups=c // 8, res=g1, label=rp + "merged")
         else:
             r = self._conv32(P.rep_merged(rp, True), None, [g1], [c], k=5, groups=c, oscale=ca1, oscale_stride=ca1.stride(0) if ca1 is not None else 0,
                              label=rp + "merged")

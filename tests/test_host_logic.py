@@ -74,6 +74,7 @@ def test_fp32_entry_points_refuse_what_their_kernels_do_not_implement():
     # residual scale: grouped-by-8 only, and only with a residual
     assert lib.sn32_conv2d(ctypes.byref(desc(rscale=p, rscale_stride=160, res=p, cs_res=160)), None) == EINVAL
     assert lib.sn32_conv2d(ctypes.byref(desc(rscale=p, rscale_stride=80, k=5, pad=2, groups=10, c_out=80, cs_out=80)), None) == EINVAL
+    assert lib.sn32_conv2d(ctypes.byref(desc(rscale=p, rscale_stride=80, k=5, pad=2, groups=10, c_out=80, cs_out=80, res=p, cs_res=80, wsplit=None)), None) == EINVAL   # exact products
     # channel sums: split dense 3x3 only, cpad within the kernel's M-tiles
     assert lib.sn32_conv2d(ctypes.byref(desc(csum=p, csum_cpad=160)), None) == EINVAL
     assert lib.sn32_conv2d(ctypes.byref(desc(csum=p, csum_cpad=8, k=3, pad=1, c_out=24, cs_out=24, c_in=(ctypes.c_int * 3)(24, 0, 0), cs_in=(ctypes.c_int * 3)(24, 0, 0))), None) == EINVAL
