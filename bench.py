@@ -327,7 +327,10 @@ def main():
         hh, ww, quads = h, w, [(0, h, 0, w)]
     sigma_map = torch.full((1, L + 4, 1, hh, ww), 30.0 / 255.0, dtype=dt, device=dev) if denoise else None
 
-    gather_ms = []          # per step: host-visible time of the halo all-gather (N > 1), measured with events on the launch stream
+    gather_ms = []          # per step: time of the halo exchange (N > 1), measured with events on the stream it is issued on
+    # The exchange of a window's raw edge frames depends on nothing the previous window computes: it is issued on a side stream, where it
+    # overlaps the tail of the previous window's kernels, and the compute stream waits for it only before the window's first launch.
+    side = torch.cuda.Stream(dev) if world > 1 else None
 
     def step(local_only=False, timed=False):
         # local_only: rank 0's extra per-kernel profiling step must not enter a collective the other ranks are not in
@@ -335,9 +338,13 @@ def main():
             win = fr if local_only else assemble_window(own, first_edge, last_edge, rank, world)
         else:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            win = assemble_window(own, first_edge, last_edge, rank, world)
-            e1.record()
+            main_stream = torch.cuda.current_stream(dev)
+            with torch.cuda.stream(side):
+                e0.record()
+                win = assemble_window(own, first_edge, last_edge, rank, world)
+                e1.record()
+            main_stream.wait_stream(side)
+            win.record_stream(main_stream)
             if timed:
                 gather_ms.append((e0, e1))
         outs = []
@@ -375,7 +382,7 @@ def main():
         mine = torch.tensor([own_elapsed / args.steps * 1e3, g_ms], device=dev, dtype=torch.float64)
         allv = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
-        per_rank = {"ms_per_step": [round(v[0].item(), 3) for v in allv], "halo_all_gather_ms": [round(v[1].item(), 3) for v in allv]}
+        per_rank = {"ms_per_step": [round(v[0].item(), 3) for v in allv], "halo_exchange_ms": [round(v[1].item(), 3) for v in allv]}
 
     result = None
     if rank == 0:
@@ -417,7 +424,20 @@ def main():
                     unit_bytes += 2 * meta[ui + 1] * meta[ui + 2] * meta[ui + 3] * meta[ui + 4] * 4
                     n_cabs += 1
         eng.prof = None
-        dom = max(agg, key=lambda k: agg[k]["ms"])
+        # the dominant kernel BY GPU TEMPLATE: both phase-1 entry points run cab_phase1r_kernel, every sn_conv2d instance is
+        # one of two conv templates; the per-entry-point rows stay in "kernels"
+        def template_of(k):
+            if k in ("sn_gsts_cab2_phase1", "sn_cab1_phase1"):
+                return "cab_phase1r_kernel (sn_gsts_cab2_phase1 + sn_cab1_phase1)"
+            if k.startswith("sn_conv2d<"):
+                return "sn_conv2d (conv3_fast_kernel + conv_mfma_kernel, every instance)"
+            return k
+        groups = {}
+        for k, v in agg.items():
+            gk = groups.setdefault(template_of(k), {"ms": 0.0, "n": 0, "bytes": 0.0, "members": []})
+            gk["ms"] += v["ms"]; gk["n"] += v["n"]; gk["bytes"] += v["bytes"]; gk["members"].append(k)
+        total_kernel_ms = sum(v["ms"] for v in agg.values())
+        dom = max(groups, key=lambda k: groups[k]["ms"])
         # HBM traffic from the committed PMC passes of THIS command line run with --no-parity --no-cpu-baseline (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE, separate passes, tools/make_profiles_r04.sh -> tools/pmc_summary.py): bytes per WINDOW per kernel = sum over the kernel's
         # launches / windows in the trace, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950.  The file
@@ -460,16 +480,18 @@ def main():
             if traffic_gb < 0.9 * alg_gb:
                 return None, f"PMC file stale or diluted: {what} measured {traffic_gb:.4f} GB < 0.9 x algorithmic {alg_gb:.4f} GB"
             return round(traffic_gb, 4), pmc_note
-        dom_alg = agg[dom]["bytes"] / agg[dom]["n"] / 1e9
-        dw = window_gb(dom)
-        dom_traffic, dom_note = checked(None if dw is None else dw / agg[dom]["n"], dom_alg, dom)
+        G = groups[dom]
+        dom_alg = G["bytes"] / G["n"] / 1e9
+        dws = [window_gb(k) for k in G["members"]]
+        dw = None if any(v is None for v in dws) else sum(dws)
+        dom_traffic, dom_note = checked(None if dw is None else dw / G["n"], dom_alg, dom)
         n_units = max(n_cabs // 2, 1)
         gw = [window_gb(k) for k, v in agg.items() if v["gsts"]]
         if pmc is not None and args.dtype == "fp32":      # fp32 engine: the unit's kernels are generic operators, told apart by launch order, not by symbol:
             gw = []                                         # the unit share of the window's traffic is not separable -> whole-net traffic only (below)
         unit_alg = unit_bytes / n_units / 1e9
         unit_traffic, unit_note = checked(None if (not gw or any(g is None for g in gw)) else sum(gw) / n_units, unit_alg, "GSTS kernels per unit")
-        ach_dom = agg[dom]["bytes"] / (agg[dom]["ms"] * 1e-3) / 1e9
+        ach_dom = G["bytes"] / (G["ms"] * 1e-3) / 1e9
         ach_unit = unit_bytes / max(unit_ms, 1e-9) / 1e6
         kernels = {k: {"ms_total": round(v["ms"], 3), "launches": v["n"],
                        "gbps_algorithmic": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)} for k, v in agg.items()}
@@ -502,8 +524,13 @@ def main():
             "dominant_kernel": {"kernel": dom, "bound": "hbm", "achieved": round(ach_dom, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(ach_dom / HBM_PEAK_GBS, 4), "traffic": dom_traffic, "traffic_note": "GB per launch: " + dom_note,
                                 "algorithmic_gb_per_launch": round(dom_alg, 4),
-                                "avg_launch_ms": round(agg[dom]["ms"] / agg[dom]["n"], 4), "launches": agg[dom]["n"],
-                                "note": "kernel-local figure: its inputs / outputs include intermediates that the fused-unit model counts as zero bytes"},
+                                "avg_launch_ms": round(G["ms"] / G["n"], 4), "launches": G["n"], "ms_per_window": round(G["ms"], 3),
+                                "share_of_kernel_time": round(G["ms"] / max(total_kernel_ms, 1e-9), 4),
+                                "by_template": {k: {"ms_per_window": round(v["ms"], 3), "share": round(v["ms"] / max(total_kernel_ms, 1e-9), 4),
+                                                    "gbps_algorithmic": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
+                                                for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])[:6]},
+                                "note": "kernel-local figure of the GPU template with the largest share of the window (averaged over its launches at all pyramid "
+                                        "levels): its inputs / outputs include intermediates that the fused-unit model counts as zero bytes"},
             "whole_net_roofline": {"achieved": round(win_bytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(win_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_gb_per_window": round(win_bytes / 1e9, 1),
                                    "traffic": (round(sum((2 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) for v in pmc.values()) * 1024 / 1e9, 1) if pmc else None),

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 13     /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
+#define SN_ABI_VERSION 14     /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
 
 /* element types of NCHW tensors exchanged with the PyTorch side */
 #define SN_F32 0
@@ -82,9 +82,11 @@ int sn_conv2d(const sn_conv_desc* d, void* stream);   /* d is a HOST pointer, re
 int sn_conv_pool_blocks(const sn_conv_desc* d);
 
 /* CALayer / CALayer2 squeeze-excite: mean -> 1x1 -> ReLU -> 1x1 -> sigmoid (gshift_deblur1.py:61-70,84-87).
- * partial:[T][nblk][cpad] f32 sums, wa:[cr][c], wb:[c][cr] f32, ca:[T][cpad] f32 out (pad entries 0). */
+ * partial:[T][nblk][cpad] f32 sums, wa:[cr][c], wb:[c][cr] f32, ca:[T][cpad] f32 out (pad entries 0).
+ * bad: NULL, or one u32 that is set to 1 when a channel sum is not finite -- the range guard of the half-precision intermediates of the
+ * producer (an overflowed fp16 value upstream turns its channel sum into inf / NaN); the caller zeroes it and reads it back when it likes. */
 int sn_ca_mlp(const float* partial, int nblk, int cpad, int c, int cr, float inv_hw,
-              const float* wa, const float* wb, float* ca, int T, void* stream);
+              const float* wa, const float* wb, float* ca, int T, unsigned* bad, void* stream);
 
 /* CALayer of a CAB computed BEFORE its second conv runs: the pooled mean of res = conv2(mid) is linear in mid,
  *   sum_p res[co](p) = sum_ci sum_tap W2[co][ci][tap] * S_tap[ci],   S_tap = sum of mid over the pixels the tap can reach
@@ -172,33 +174,26 @@ int sn_dw5m_gemm_gate(const void* g1p, const float* ca_in, const void* ttab, con
  * The global average pool of CALayer2 (gshift_deblur1.py:76-87) is the one grid-wide dependency inside CAB2 / CAB1, so a block is two
  * passes over the frame: phase 1 up to g2 and its channel sums, [sn_ca_mlp on the sums], phase 2 from g2 to the block's output.
  *
- * PHASE 1, fused (the variants without the inner CALayer2: both deblur models), two kernels behind the same entry points:
+ * PHASE 1, fused, every variant (csrc/sn_phase1r.hip):
  *   g2 = SimpleGate2(body[4](RepConv(SimpleGate(RepConv2(body[0](norm(u)))))))   (gshift_deblur1.py:183-211 CAB1, :212-255 CAB2; gshift_deblur2.py:186-258)
- * in ONE kernel: u is read once, g2 written once; `a`, g1 and r never reach HBM.  (The denoisers, whose inner CALayer2 needs the global pool
- * of g1, run phase 1 as sn_ln_gemm_gate + sn_dw5m_gemm_gate / sn_grp5_gemm_gate with g1 in HBM.)  sn_gsts_cab2_phase1: s->mode 1 / 2, hw =
- * sn_gsts_shiftconv's output; sn_cab1_phase1: s->mode 0.
- *   layout 0 (csrc/sn_phase1.hip, C = 64 depthwise RepConv on the VALU), weights prep.pack_phase1 --
- *     wfrag1  bf16 A fragments of body[0] (LayerNorm affine folded, gate-paired rows) [8][K/32][64][8];
- *     wfragx  bf16 [8][16][8]: k-slots 0..7 of the LayerNorm k-step of every row: (W1 hi, W1 lo, W1 hi, W1 lo, b hi, b lo, b hi, b lo), W1 = the
- *             row sum of the bf16 weights, b = the folded bias: the kernel feeds the RAW input to the MFMA and normalises afterwards;
- *     w3 / w5 packed-fp16 stencil tables in accumulator-lane order; wfrag2: fp16 A fragments of body[4] (sigmoid rows times -log2 e).
- *   layout 1 (csrc/sn_phase1r.hip, role-split, C = 64 or 80, RepConv depthwise or grouped 8 -> 8 ON THE MATRIX CORES), weights prep.pack_phase1r --
+ * in ONE kernel: u is read once, g2 written once; `a`, g1 and r never reach HBM.  (The denoisers, whose inner CALayer2 needs the global pool of g1,
+ * run it twice: sn_phase1_opts.  sn_ln_gemm_gate + sn_dw5m_gemm_gate / sn_grp5_gemm_gate above are the same phase 1 in two kernels with g1 in bf16 in HBM:
+ * the engine's fallback for a checkpoint whose activations leave the fp16 range of `a`, g1 and r inside the fused kernel.)
+ * sn_gsts_cab2_phase1: s->mode 1 / 2, hw = sn_gsts_shiftconv's output; sn_cab1_phase1: s->mode 0.  C = 64 or 80, RepConv depthwise or grouped 8 -> 8 ON THE
+ * MATRIX CORES; weights prep.pack_phase1r --
  *     wfrag1  bf16 [C/8][KS1][64][8]: body[0] with the LayerNorm scale folded, wave-paired rows (M-tiles 2q, 2q+1 = channels 16q.. and their gate
  *             partners), the folded bias as bf16 hi + lo in the columns of k-slots K, K+1 (the kernel feeds the normalised input and a constant 1);
  *     w3      uint32 [C/16][4][9][4] packed-fp16 taps of RepConv2 (+identity) per (wave, lane group, tap, packed register);
  *     wgrp    fp16 [C/16][2][8][64][8]: RepConv (5x5 + 3x3 + identity) of every group as an x-pair Toeplitz GEMM (row = output channel + 8 * pixel of a
  *             pair; k = kernel row, input column 0..5 relative to the pair, input channel);
- *     wfrag2  fp16 [C/8][KS2][64][8]: body[4], wave-paired rows, sigmoid rows times -log2 e;   wfragx / w5 unused (NULL).
- * g2: [T][h][w][C] NHWC bf16.  pool: NULL or [T][sn_phase1_pool_blocks(T,h,w,layout)][C] f32 partial channel sums of g2 (CALayer2, finished by
- * sn_ca_mlp or by the sn_se_fold tail).  sn_phase1_pool_blocks queries the current device (the work split depends on its CU count); < 0 on error. */
+ *     wfrag2  fp16 [C/8][KS2][64][8]: body[4], wave-paired rows, sigmoid rows times -log2 e.
+ * g2: [T][h][w][C] NHWC bf16.  pool: NULL or [T][sn_phase1_pool_blocks(T,h,w)][C] f32 partial channel sums of g2 (CALayer2, finished by sn_ca_mlp or by
+ * the sn_se_fold tail); EVERY row is written (rows no workgroup owns receive zeros), the layout does not depend on the frame range of the launch. */
 typedef struct sn_phase1_weights {
     const void* wfrag1;
-    const void* wfragx;
     const uint32_t* w3;
-    const uint32_t* w5;
-    const void* wfrag2;
     const void* wgrp;
-    int layout;          /* 0: csrc/sn_phase1.hip (C = 64), 1: csrc/sn_phase1r.hip (C = 64 / 80) */
+    const void* wfrag2;
 } sn_phase1_weights;
 /* Optional fold of CALayer2's squeeze-excite MLP (gshift_deblur1.py:76-87) into phase 1: the LAST workgroup of a frame to finish reduces
  * the frame's partial sums in a fixed order (bit-reproducible whichever workgroup that is) and writes ca[t][C] = sigmoid(wb relu(wa mean)),
@@ -210,21 +205,30 @@ typedef struct sn_se_fold {
     int c, cr;
     unsigned* ticket;
     float* ca;
+    unsigned* bad;       /* NULL, or the range guard of sn_ca_mlp: set to 1 when a channel sum of the frame is not finite */
 } sn_se_fold;
-/* The denoisers' inner CALayer2 on g1 = SimpleGate(...) (gshift_denoise1.py:224,257; gshift_denoise2.py:194,227), layout 1 only.  Its global average
+/* The denoisers' inner CALayer2 on g1 = SimpleGate(...) (gshift_denoise1.py:224,257; gshift_denoise2.py:194,227).  Its global average
  * pool sits INSIDE phase 1, so phase 1 runs twice over the input and g1 still never reaches HBM:
  *   pass 1, g1_sums = 1: LayerNorm -> 1x1 -> dw3x3 -> gate only; pool receives the partial channel sums of g1 (finish them with sn_ca_mlp, or pass
  *           the inner CALayer2's weights as `se`: se->ca is then that layer's scale); g2 is not touched (may be NULL);
  *   pass 2, g1_scale = that scale [T][C] f32: the whole phase 1 with g1 multiplied by it before the RepConv.
- * NULL / zeros: the deblur models (no inner CALayer2). */
+ * NULL / zeros: the deblur models (no inner CALayer2).
+ * team: 0 = the library chooses how many workgroups walk consecutive frames of the same rows in lock step (1, 2, 4 or 8: csrc/sn_phase1r.hip,
+ * P1RPlan); a fixed value is for measurements only.  Results do not depend on it beyond the summation order of the pool rows. */
 typedef struct sn_phase1_opts {
     const float* g1_scale;
     int g1_sums;
+    int team;
 } sn_phase1_opts;
-int sn_phase1_pool_blocks(int T, int h, int w, int layout);
+int sn_phase1_pool_blocks(int T, int h, int w);
 int sn_gsts_cab2_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se,
                         const sn_phase1_opts* opt, void* stream);
 int sn_cab1_phase1(const sn_unit_src* s, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se, const sn_phase1_opts* opt, void* stream);
+/* The work decomposition of a phase-1 launch over nfr frames of h x w on a device with ncu compute units (host only, no device access): out7 =
+ * {strips, slack / strip, slack remainder, team size F, frame blocks, rows per team chunk, teams}; sn_p1r_strip_begin: first own column of strip s
+ * (s == strips: w).  Exposed for the host-logic tests and for tools that size measurements; the launch uses exactly this plan. */
+int sn_p1r_plan(int nfr, int h, int w, int ncu, int team, int* out7);
+int sn_p1r_strip_begin(const int* plan7, int s, int w);
 
 /* PHASE 2, all variants (C = 64 / 80): y = shortcut + beta * body[7](ca * g2) (gshift_deblur1.py:201,210,254): beta and the optional bias
  * are folded into wfrag / bias; the shortcut is the ROLLED tensor for CAB2 (s->mode 1 / 2: sn_gsts_cab2_phase2) and x itself for CAB1

@@ -132,15 +132,20 @@ __device__ __forceinline__ SnSlabs<E> sn_unit_slabs(const E* x, const E* halo, i
 // cdna_hip_programming.md Guideline 16, counter form): partial sums leave as sc1 (write-through) stores -> every wave waits for
 // its stores (vmcnt(0)) -> workgroup barrier -> lane 0 takes the ticket with a relaxed agent-scope fetch_add; the last arriver issues an
 // agent-scope ACQUIRE fence, re-arms the counter and reads the partial sums with sc1 loads.
-struct SeFold { const float* wa; const float* wb; float* ca; unsigned* ticket; float inv_hw; int c, cr; };
+struct SeFold { const float* wa; const float* wb; float* ca; unsigned* ticket; unsigned* bad; float inv_hw; int c, cr; };
+// the range guard of the half-precision intermediates: a channel sum that is not finite (an fp16 `a`, g1 or r overflowed upstream) raises *bad
+__device__ __forceinline__ void sn_flag_nonfinite(unsigned* bad, float v) {
+    if (bad && !(fabsf(v) <= 3.0e38f)) __hip_atomic_store(bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void sn_pool_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// pool_t: [nblk][cpad] partial sums of frame t (this workgroup's row already stored with sn_pool_store); lds: >= 16 + nthreads + 2 * 128
+// pool_t: [nblk][cpad] partial sums of frame t (this workgroup's row already stored with sn_pool_store; rows nobody owns hold zeros);
+// narrive: how many calls are made for frame t by the whole launch (each after storing its row); lds: >= 16 + nthreads + 2 * 128
 // floats, no longer read by anybody in the workgroup once its first barrier is passed; cpad <= 128, cr <= 128.  Called by ALL threads.
-__device__ __forceinline__ void sn_se_tail(const SeFold& S, const float* pool_t, int nblk, int cpad, int t, float* lds, int tid, int nthreads) {
+__device__ __forceinline__ void sn_se_tail(const SeFold& S, const float* pool_t, int nblk, int narrive, int cpad, int t, float* lds, int tid, int nthreads) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's partial-sum stores are acknowledged by memory
     __syncthreads();
     unsigned* flag = (unsigned*)lds;
-    if (tid == 0) *flag = __hip_atomic_fetch_add(S.ticket + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nblk - 1) ? 1u : 0u;
+    if (tid == 0) *flag = __hip_atomic_fetch_add(S.ticket + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(narrive - 1) ? 1u : 0u;
     __syncthreads();
     if (!*flag) return;                                              // workgroup-uniform
     if (tid == 0) {
@@ -161,6 +166,7 @@ __device__ __forceinline__ void sn_se_tail(const SeFold& S, const float* pool_t,
     if (tid < cpad) {
         float m = 0.f;
         for (int q = 0; q < parts; ++q) m += acc[q * cpad + tid];
+        sn_flag_nonfinite(S.bad, m);
         mean[tid] = m * S.inv_hw;
     }
     __syncthreads();

@@ -573,7 +573,7 @@ __global__ void ingest_kernel(const void* src, int dt, const void* noise, uint4*
 }
 
 __global__ __launch_bounds__(1024) void ca_mlp_kernel(const float* partial, int nblk, int cpad, int c, int cr, float inv_hw,
-                                                   const float* wa, const float* wb, float* ca) {
+                                                   const float* wa, const float* wb, float* ca, unsigned* bad) {
     __shared__ float acc[1024];
     __shared__ float mean[128];
     __shared__ float hid[128];
@@ -590,6 +590,7 @@ __global__ __launch_bounds__(1024) void ca_mlp_kernel(const float* partial, int 
     if (tid < cpad) {
         float m = 0.f;
         for (int q = 0; q < nsplit; ++q) m += acc[q * cpad + tid];
+        sn_flag_nonfinite(bad, m);
         mean[tid] = m * inv_hw;
     }
     __syncthreads();
@@ -817,10 +818,10 @@ int sn_conv2d(const sn_conv_desc* d, void* stream) {
 
 
 int sn_ca_mlp(const float* partial, int nblk, int cpad, int c, int cr, float inv_hw,
-              const float* wa, const float* wb, float* ca, int T, void* stream) {
+              const float* wa, const float* wb, float* ca, int T, unsigned* bad, void* stream) {
     sn_clear_error();
     if (!partial || !wa || !wb || !ca || cpad < 16 || cpad > 128 || c > cpad || cr > 128 || cr < 1 || nblk < 1) return SN_EINVAL;
-    hipLaunchKernelGGL(ca_mlp_kernel, dim3(T), dim3(1024), 0, (hipStream_t)stream, partial, nblk, cpad, c, cr, inv_hw, wa, wb, ca);
+    hipLaunchKernelGGL(ca_mlp_kernel, dim3(T), dim3(1024), 0, (hipStream_t)stream, partial, nblk, cpad, c, cr, inv_hw, wa, wb, ca, bad);
     return sn_check_launch();
 }
 

@@ -25,6 +25,7 @@ import argparse
 import glob
 import math
 import os
+import sys
 import time
 from typing import List, Optional, Sequence, Tuple
 
@@ -269,7 +270,7 @@ class Inference:
                 x32 = None
                 if self.denoise and dev_io:     # uint8 frames up, float32 conversion and the AWGN on the device, quadrants stitched there
                     sigma = a.sigma / 255.0
-                    x32 = ingest_u8(torch.from_numpy(np.stack(inputs)).to("cuda"), torch.float32)
+                    x32 = ingest_u8(torch.from_numpy(np.stack(inputs)).to(self.device), torch.float32)
                     x32 = x32 + torch.empty_like(x32).normal_(mean=0, std=sigma)
                     x = x32.to(self.dtype)
                     t1 = time.time()
@@ -277,18 +278,18 @@ class Inference:
                 elif self.denoise:              # upstream's host path (test_denoise.py:145-173)
                     x32 = numpy2tensor(inputs)
                     sigma = a.sigma / 255.0
-                    x32 = (x32 + torch.empty_like(x32).normal_(mean=0, std=sigma)).to("cuda")
+                    x32 = (x32 + torch.empty_like(x32).normal_(mean=0, std=sigma)).to(self.device)
                     x = x32.to(self.dtype)
                     t1 = time.time()
                     output = quadrant_forward(self.net, x, sigma, x32=x32)
                 elif dev_io:
-                    u8 = torch.from_numpy(np.stack(inputs)).to("cuda")
+                    u8 = torch.from_numpy(np.stack(inputs)).to(self.device)
                     x = ingest_u8(u8, self.dtype)
                     x32 = ingest_u8(u8, torch.float32) if self.dtype != torch.float32 else None     # exact v / 255 for the final "+ x"
                     t1 = time.time()
                     output = self.net.forward_fp32_out(x, shortcut=x32)
                 else:
-                    x32 = numpy2tensor(inputs).to("cuda")
+                    x32 = numpy2tensor(inputs).to(self.device)
                     x = x32.to(self.dtype)
                     t1 = time.time()
                     output = self.net.forward_fp32_out(x, shortcut=x32 if self.dtype != torch.float32 else None)
@@ -297,7 +298,7 @@ class Inference:
                 psnr = ssim = float("nan")
                 img_u8 = psnrs = ssims = None
                 if dev_io:      # clamp * 255, rounding, the PSNR sums and the SSIM statistics all on the device: no float frame goes back
-                    gt_dev = torch.from_numpy(np.stack(gtf)).to("cuda")
+                    gt_dev = torch.from_numpy(np.stack(gtf)).to(self.device)
                     img_u8, psnrs = egress_u8(output, gt_dev, want_image=a.save_image)
                     ssims = ssim_u8(output, gt_dev)
                     img_u8 = img_u8.cpu().numpy() if img_u8 is not None else None
@@ -352,10 +353,17 @@ def main(variant: str, argv: Optional[Sequence[str]] = None) -> Tuple[float, flo
     a = ap.parse_args(argv)
     if a.fp32_exact:
         os.environ["SN_FP32_EXACT"] = "1"
-    a.rank, a.world, a.local_device = 0, 1, 0
+    a.rank, a.world = 0, 1
+    a.local_device = torch.cuda.current_device() if torch.cuda.is_available() else 0      # an embedding process may have chosen another device
     ngpus = getattr(a, "gpus", 1)
+    if (ngpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1) and not denoise:
+        # clip-parallel takes its halo from ONE neighbour window and keeps the frames on the device
+        if a.one_len < 2:
+            ap.error("--gpus N / a multi-rank launch needs --one_len >= 2 (a window's two halo frames come from one neighbour window)")
+        if a.host_io:
+            ap.error("--host_io is a single-process mode (upstream's host path); it cannot be combined with --gpus / a multi-rank launch")
     if ngpus > 1 and "RANK" not in os.environ:
-        return _spawn_ranks(ngpus, argv)                 # this process only launches and waits; rank 0 prints the log
+        return _spawn_ranks(variant, ngpus, sys.argv[1:] if argv is None else argv)      # this process only launches and waits; rank 0 prints the log
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not denoise:
         import torch.distributed as dist
         a.rank, a.world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -383,31 +391,63 @@ def main(variant: str, argv: Optional[Sequence[str]] = None) -> Tuple[float, flo
     a.result_path = a.result_path or rp
     if not a.model_path:
         ap.error("choose --default_data, or --synthetic H W N, or give --checkpoint")
+    import torch.distributed as dist
     try:
-        return Inference(a, variant).infer()
-    finally:
-        if a.world > 1:
-            import torch.distributed as dist
-            if dist.is_initialized():
-                dist.barrier()
+        res = Inference(a, variant).infer()
+    except BaseException:
+        # This rank failed while the others may sit in a collective: no barrier here (it would never complete and hide the error behind the
+        # process-group timeout).  Leaving the group un-synchronised makes the launcher / _spawn_ranks see a non-zero exit at once.
+        if a.world > 1 and dist.is_initialized():
+            try:
                 dist.destroy_process_group()
+            except Exception:                                   # noqa: BLE001
+                pass
+        raise
+    if a.world > 1 and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    return res
 
 
-def _spawn_ranks(n: int, argv: Optional[Sequence[str]]) -> Tuple[float, float]:
-    """--gpus N outside a launcher: start N copies of this very command line, one rank each (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
-    the environment, rendezvous on 127.0.0.1), and wait for them.  The metrics are in rank 0's log."""
+def _spawn_ranks(variant: str, n: int, argv: Sequence[str]) -> Tuple[float, float]:
+    """--gpus N outside a launcher: start N ranks of THIS CLI (``python -m shiftnet_amd.cli <variant> <argv>``: independent of how the caller was
+    started -- the drop-in script, pytest, bench.py), one rank each (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment,
+    rendezvous on 127.0.0.1), and wait for them.  As soon as one rank exits non-zero the others are stopped: they would otherwise wait in a
+    collective until the process-group timeout.  The metrics are in rank 0's log."""
     import socket
     import subprocess
-    import sys
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, sys.argv[0]] + list(sys.argv[1:] if argv is None else argv)
+    pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "shiftnet_amd.cli", variant] + list(argv)
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env["PYTHONPATH"] = os.pathsep.join([pkg_parent] + [p for p in env.get("PYTHONPATH", "").split(os.pathsep) if p])
         procs.append(subprocess.Popen(cmd, env=env))
-    rc = [p.wait() for p in procs]
+    rc = [None] * n
+    while any(c is None for c in rc):
+        for i, p in enumerate(procs):
+            if rc[i] is None:
+                rc[i] = p.poll()
+        if any(c not in (None, 0) for c in rc):
+            for i, p in enumerate(procs):
+                if rc[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if rc[i] is None:
+                    try:
+                        rc[i] = p.wait(timeout=30)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rc[i] = p.wait()
+            break
+        time.sleep(0.2)
     if any(rc):
         raise SystemExit("clip-parallel ranks exited with codes %s" % rc)
     return float("nan"), float("nan")
+
+
+if __name__ == "__main__":          # python -m shiftnet_amd.cli <variant> [flags]: the rank entry point of _spawn_ranks
+    main(sys.argv[1], sys.argv[2:])

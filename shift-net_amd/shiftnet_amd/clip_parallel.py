@@ -3,8 +3,10 @@
 The reference CLI restores frames ``[kL+2, kL+2+L)`` of a clip from input frames ``[kL, kL+L+4)`` (test_deblur.py:
 111-120).  Rank r therefore OWNS the L frames it restores and needs the last two owned frames of rank r-1 and the first
 two of rank r+1; rank 0 / the last rank additionally hold the clip's first / last two frames, which nobody restores.
-That is the only communication on the path: one all-gather of ``[4,3,H,W]`` raw input frames per rank over RCCL (xGMI);
-no feature map ever crosses GPUs, because the result must equal the single-GPU CLI run with the same ``one_len``.
+That is the only communication on the path: two raw input frames ``[2,3,H,W]`` to each neighbour (one batched send / recv pair per side,
+RCCL point-to-point over the xGMI link to that neighbour; round 4 all-gathered every rank's 4 frames to every rank: 8 x 50 MB at
+1080p where 2 x 25 MB suffice); no feature map ever crosses GPUs, because the result must equal the single-GPU CLI run with the
+same ``one_len``.
 """
 from __future__ import annotations
 
@@ -22,26 +24,49 @@ def window_ranges(n_frames: int, one_len: int) -> List[Tuple[range, range]]:
 
 
 def assemble_window(own: torch.Tensor, first_edge: Optional[torch.Tensor], last_edge: Optional[torch.Tensor],
-                    rank: int = 0, world: int = 1, group=None, active: Optional[int] = None) -> Optional[torch.Tensor]:
+                    rank: int = 0, world: int = 1, group=None, active: Optional[int] = None, all_gather: bool = False) -> Optional[torch.Tensor]:
     """own:[L,3,H,W] -> this rank's input window [L+4,3,H,W].
 
     ``first_edge`` ([2,3,H,W]) is required on rank 0, ``last_edge`` on the last ACTIVE rank (``active`` ranks hold a window in this round,
-    default all; the others still take part in the collective -- ``own`` is then any tensor of the right shape -- and get None).  Without a
-    process group (plain single-GPU run) there is no communication at all.  The collective runs where ``own`` lives (RCCL for device
-    tensors; a gloo group -- several ranks sharing one device in the tests -- needs host tensors: pass them as such).
+    default all; the others get None and -- point-to-point -- take no part at all).  Without a process group (plain single-GPU run) there is
+    no communication.  The exchange runs where ``own`` lives (RCCL for device tensors; a gloo group -- several ranks sharing one device in the
+    tests -- needs host tensors: pass them as such).  L >= 2: a window's halo is two frames of ONE neighbour (a shorter window would need
+    the neighbour's neighbour; the CLI refuses one_len < 2 under --gpus).
+    all_gather=True keeps round 4's collective form (every rank's 4 edge frames to every rank); a one-rank group uses it so that the RCCL
+    path is exercised on a single-GPU box (tests/test_gpu_multirank.py), where point-to-point has nobody to talk to.
     """
     if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return torch.cat((first_edge, own, last_edge), 0)
     active = world if active is None else active
-    # (a one-rank process group still goes through the collective: the RCCL path is exercised on a single-GPU box too)
-    send = torch.cat((own[:2], own[-2:]), 0).contiguous()
-    bufs = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(bufs, send, group=group)
+    if own.shape[0] < 2:
+        raise ValueError("clip-parallel windows need one_len >= 2: the two halo frames of a side come from ONE neighbour rank")
+    if all_gather or world == 1:
+        send = torch.cat((own[:2], own[-2:]), 0).contiguous()
+        bufs = [torch.empty_like(send) for _ in range(world)]
+        dist.all_gather(bufs, send, group=group)
+        if rank >= active:
+            return None
+        head = first_edge if rank == 0 else bufs[rank - 1][2:4]
+        tail = last_edge if rank == active - 1 else bufs[rank + 1][0:2]
+        return torch.cat((head, own, tail), 0)
     if rank >= active:
         return None
-    head = first_edge if rank == 0 else bufs[rank - 1][2:4]
-    tail = last_edge if rank == active - 1 else bufs[rank + 1][0:2]
-    return torch.cat((head, own, tail), 0)
+    staged = dist.get_backend(group) == "gloo" and own.is_cuda      # gloo moves host memory: stage through the CPU (ranks sharing one device in tests)
+    edge = lambda t: (t.cpu() if staged else t.contiguous())         # noqa: E731
+    recv = lambda: torch.empty((2,) + tuple(own.shape[1:]), dtype=own.dtype, device="cpu" if staged else own.device)      # noqa: E731
+    ops, head, tail = [], first_edge, last_edge
+    if rank > 0:                                    # my first two frames are the left neighbour's tail; its last two are my head
+        head = recv()
+        ops.append(dist.P2POp(dist.isend, edge(own[:2]), rank - 1, group))
+        ops.append(dist.P2POp(dist.irecv, head, rank - 1, group))
+    if rank < active - 1:
+        tail = recv()
+        ops.append(dist.P2POp(dist.isend, edge(own[-2:]), rank + 1, group))
+        ops.append(dist.P2POp(dist.irecv, tail, rank + 1, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return torch.cat((head.to(own.device), own, tail.to(own.device)), 0)
 
 
 def rounds(n_windows: int, world: int) -> List[List[int]]:

@@ -121,16 +121,12 @@ class Plan:
             u["w_toep5"] = self._dev(prep.pack_toeplitz(w5, 5))           # K3m: 5x5 on the matrix cores
         i += 1
         u["w_gate"] = self._dev(prep.pack_gate_gemm(sd[f"{pre}body.{i}.weight"], c))
-        if True:               # fused phase 1 (sn_gsts_cab2_phase1 / sn_cab1_phase1); the denoisers run it twice (inner CALayer2: sn_phase1_opts)
-            args = (sd[f"{pre}body.0.weight"], sd[pre + "norm.weight"], sd[pre + "norm.bias"], sd[f"{pre}body.1.conv_2.weight"],
-                    sd[f"{pre}body.{i - 1}.conv_1.weight"], sd[f"{pre}body.{i - 1}.conv_2.weight"], sd[f"{pre}body.{i}.weight"], c)
-            if c == 64 and not V.grouped_rep and not V.denoise:      # layout 0: csrc/sn_phase1.hip, depthwise stencils on the VALU
-                d = {k: self._dev(v) for k, v in prep.pack_phase1(*args).items()}
-                d["desc"] = L.Phase1Weights(*(d[k].data_ptr() for k in ("wfrag1", "wfragx", "w3", "w5", "wfrag2")), None, 0)   # the tensors stay referenced in d
-                u["p1"] = d
-            d = {k: self._dev(v) for k, v in prep.pack_phase1r(*args).items()}   # layout 1: csrc/sn_phase1r.hip, role-split, RepConv on the matrix cores
-            d["desc"] = L.Phase1Weights(d["wfrag1"].data_ptr(), None, d["w3"].data_ptr(), None, d["wfrag2"].data_ptr(), d["wgrp"].data_ptr(), 1)
-            u["p1r"] = d
+        # fused phase 1 (sn_gsts_cab2_phase1 / sn_cab1_phase1, csrc/sn_phase1r.hip); the denoisers run it twice (inner CALayer2: sn_phase1_opts)
+        d = {k: self._dev(v) for k, v in prep.pack_phase1r(
+            sd[f"{pre}body.0.weight"], sd[pre + "norm.weight"], sd[pre + "norm.bias"], sd[f"{pre}body.1.conv_2.weight"],
+            sd[f"{pre}body.{i - 1}.conv_1.weight"], sd[f"{pre}body.{i - 1}.conv_2.weight"], sd[f"{pre}body.{i}.weight"], c).items()}
+        d["desc"] = L.Phase1Weights(d["wfrag1"].data_ptr(), d["w3"].data_ptr(), d["wgrp"].data_ptr(), d["wfrag2"].data_ptr())   # the tensors stay referenced in d
+        u["p1r"] = d
         i += 1
         i += 1
         self.add_ca(f"{pre}ca2", f"{pre}body.{i}."); i += 1
@@ -216,6 +212,10 @@ class Engine:
         self.split = None                     # temporal_split.TemporalSplit: this engine holds a frame range of a longer window
         self._side = None                     # side stream of the halo exchanges (created on first use)
         self._tickets = None                  # sn_se_fold frame counters: zero between launches (the kernels re-arm them)
+        self._bad = None                      # the range guard's device flag (one u32), created on first use
+        self.fallbacks = 0                    # how often the guard moved this engine from the fused phase 1 to the bf16 chain (0 or 1)
+        if self.phase1 not in ("auto", "r", "0"):
+            raise ValueError(f"SN_PHASE1={self.phase1!r}: expected auto, r (fused kernel) or 0 (two-kernel bf16 chain)")
         # hipGraph replay of the whole forward (~1400 launches per window), opt-in with SN_GRAPH=1: the first call with a given input
         # signature runs eagerly, the second one is captured, later ones replay, so the Python / ctypes / allocator work per launch
         # disappears.  Measured on MI355X: neutral at 1280x720 (126.4 vs 126.0 ms per window: the GPU is never starved there, kernels
@@ -303,18 +303,20 @@ class Engine:
         T, nblk, cpad = pool.shape
         ca = torch.empty((T, cpad), dtype=torch.float32, device=self.dev)
         self._call("sn_ca_mlp", f"sn_ca_mlp[{name}]", pool.data_ptr(), nblk, cpad, p["c"], p["cr"], 1.0 / npix, p["wa"].data_ptr(),
-                                   p["wb"].data_ptr(), ca.data_ptr(), T, self._stream())
+                                   p["wb"].data_ptr(), ca.data_ptr(), T, None, self._stream())
         return ca
 
     # ---- blocks (oracle/shiftnet_oracle.py has the same names) ----------------------------------------------
     fold_se = True             # fused phase 1: CALayer2's MLP is finished by the frame's last workgroup (sn_se_fold) instead of an sn_ca_mlp launch
-    # Phase 1 of CAB2 / CAB1 of the deblur models.  "r": role-split fused kernel (csrc/sn_phase1r.hip, C = 64 / 80, RepConv on the matrix cores);
-    # "v": fused kernel with the stencils on the VALU (csrc/sn_phase1.hip, C = 64 only); "0": the two-kernel chain sn_ln_gemm_gate + sn_dw5m_gemm_gate /
-    # sn_grp5_gemm_gate (g1 through HBM; what the denoisers always run).  SN_PHASE1 overrides it, e.g. for a checkpoint whose activations leave
-    # the fp16 range the fused kernels carry `a`, g1 and r in (the chain keeps g1 in bf16).
+    # Phase 1 of CAB2 / CAB1.  "r": the role-split fused kernel (csrc/sn_phase1r.hip, every variant; `a`, g1 = a1 a2 2^-4 and r are fp16 inside it);
+    # "0": the two-kernel chain sn_ln_gemm_gate + sn_dw5m_gemm_gate / sn_grp5_gemm_gate (g1 in bf16 through HBM: a product of two activations
+    # cannot leave ITS range).  SN_PHASE1 picks one; "auto" starts fused and lets the range guard decide.
+    # C = 64, 20 x 360 x 640, CAB1 / CAB2: "r" 565 / 696 us (round 4), chain 837 / 950 us
     phase1 = os.environ.get("SN_PHASE1", "auto")
-    PHASE1_AUTO = {64: "r", 80: "r"}     # (the denoisers run the kernel twice: sums of g1 for the inner CALayer2, then the whole phase 1)
-    # C = 64, 20 x 360 x 640, CAB1 / CAB2: "r" 565 / 696 us, "v" 826 / 725 us, chain 837 / 950 us (one box)
+    # Range guard of the half-precision intermediates: every squeeze-excite reduction of the GSTS path (the sn_se_fold tail, sn_ca_mlp)
+    # raises a device flag when a channel sum is not finite -- what an overflowed fp16 `a`, g1 or r upstream turns into.  forward() reads the flag
+    # once per call; a raised flag on the fused path switches THIS engine to the chain for good, warns, and recomputes the window.
+    range_guard = os.environ.get("SN_RANGE_GUARD", "1") != "0"
     fused_cab_tail = True      # bf16 engine: always.  Engine32 (one kernel per reference module) runs conv, conv, pool, MLP, scale + residual instead
 
     def cab(self, pre: str, x: Act, extra: Optional[Act] = None) -> Act:
@@ -395,79 +397,75 @@ class Engine:
         """Shift_CAB (gshift_denoise1.py:157-186)."""
         return self.cab(pre, self.temporal_roll(x, reverse))
 
-    def naf(self, pre: str, x: Act, mode: int) -> Act:
+    def _guard_ptr(self) -> Optional[int]:
+        if not self.range_guard:
+            return None
+        if self._bad is None:
+            self._bad = torch.zeros((1,), dtype=torch.int32, device=self.dev)
+        return self._bad.data_ptr()
+
+    def _fused_phase1(self, T: int) -> bool:
+        """Does phase 1 of this engine's CAB2 / CAB1 run as the fused kernel?  (The denoisers' two passes rely on the squeeze-excite tail for
+        the inner scale, whose frame counters cover MAX_TICKETS frames.)"""
+        if self.phase1 == "0":
+            return False
+        return not (self.V.denoise and (not self.fold_se or T > self.MAX_TICKETS))
+
+    def naf(self, pre: str, x: Act, mode: int, *, frames: Optional[Tuple[int, int]] = None, bufs: Optional[Dict[str, torch.Tensor]] = None) -> Act:
         """CAB2 (mode 1/2, fed by the GSTS gather of x) or CAB1 (mode 0) (gshift_deblur1.py:183-255).
 
-        Phase 1: [K0 sn_gsts_shiftconv (CAB2 only)] -> sn_gsts_cab2_phase1 / sn_cab1_phase1 (Shift-Net-s deblur: ONE kernel up to g2), or K12 sn_ln_gemm_gate -> K3
-        (sn_dw5m_gemm_gate depthwise with the inner CALayer2 of the denoisers, sn_grp5_gemm_gate for the grouped "+" RepConv); then sn_ca_mlp
-        and phase 2, K4 sn_gsts_cab2_phase2 / sn_cab1_phase2.  The global average pool of CALayer2 sits between the phases and forbids a single pass
-        (DESIGN.md section 3).  Every frame is independent inside a CAB (the pool is per frame), so on a temporally split window the chain
-        runs in two pieces: all frames but the boundary one while the halo exchange is in flight, then the boundary frame."""
+        Phase 1: [K0 sn_gsts_shiftconv (CAB2 only)] -> sn_gsts_cab2_phase1 / sn_cab1_phase1 (ONE kernel up to g2; the denoisers run it twice, the first
+        pass for the channel sums of g1 behind their inner CALayer2), or -- phase1 "0" -- K12 sn_ln_gemm_gate -> K3 (sn_dw5m_gemm_gate depthwise,
+        sn_grp5_gemm_gate for the grouped "+" RepConv) with g1 in bf16 through HBM; then the squeeze-excite MLP (folded into phase 1's last
+        workgroup per frame, or sn_ca_mlp) and phase 2, K4 sn_gsts_cab2_phase2 / sn_cab1_phase2.  The global average pool of CALayer2 sits
+        between the phases and forbids a single pass.  Every frame is independent inside a CAB (the pool is per frame), so
+        on a temporally split window the chain runs in two pieces: all frames but the boundary one while the halo exchange is in flight, then
+        the boundary frame.  frames = (t0, nt) / bufs: one frame range of a block whose tensors the caller owns (the frame-wavefront schedule)."""
         lib, V, P = self.lib, self.V, self.P
         u = P.units[pre]
         T, h, w, c = x.dims
         self._meta = ("naf", T, h, w, c, mode)
-        mode1 = self.PHASE1_AUTO.get(c, "0") if self.phase1 == "auto" else self.phase1
-        p1key = {"r": "p1r", "v": "p1"}.get(mode1)
-        if p1key == "p1" and "p1" not in u:
-            p1key = "p1r"                                # the VALU kernel exists for C = 64 depthwise without the inner CALayer2 only
-        if V.denoise and (not self.fold_se or T > self.MAX_TICKETS):
-            p1key = None                                 # the denoisers' two-pass phase 1 relies on the squeeze-excite tail for the inner scale
-        fused = p1key is not None and p1key in u         # phase 1 in ONE kernel: neither a, g1 nor r leave the CU
-        layout = 1 if p1key == "p1r" else 0
-        mstencil = not V.grouped_rep                     # depthwise RepConv (C = 64): Toeplitz-MFMA 5x5 on a channel-planar g1
-        hwb = self._new(T, h, w, c // 2) if mode else None
-        g2 = self._new(T, h, w, c)
-        y = self._new(T, h, w, c)
-        g1 = pool1 = ca1 = None
-        if fused:
-            nb2 = lib.sn_phase1_pool_blocks(T, h, w, layout)
-            if nb2 < 1:
-                raise L.ShiftNetLibError(f"sn_phase1_pool_blocks failed with code {nb2}")
-            if V.denoise:
-                ca1 = torch.empty((T, c), dtype=torch.float32, device=self.dev)
-                if self._tickets is None:
-                    self._tickets = torch.zeros((self.MAX_TICKETS,), dtype=torch.int32, device=self.dev)
-        else:
-            g1 = (torch.empty((T, h, c, lib.sn_planar_pitch(w)), dtype=torch.bfloat16, device=self.dev) if mstencil else self._new(T, h, w, c))
-            nb2 = lib.sn_dw5m_blocks(h, w) if mstencil else lib.sn_grp5_blocks(h, w)
-            if V.denoise:      # CALayer2 on g1.  ca1 / pool1 stay referenced until the end of this method: a temporary would go back to the
-                # caching allocator at once and g2 / pool2, which K3 WRITES, could be carved out of the block K3 still READS its scale
-                # from (intermittent wrong frames at the small pyramid levels; found by the full-size determinism check of config 4)
-                pool1 = torch.empty((T, lib.sn_lngate_blocks(h, w), c), dtype=torch.float32, device=self.dev)
-                ca1 = torch.empty((T, c), dtype=torch.float32, device=self.dev)
-        pool2 = torch.empty((T, nb2, c), dtype=torch.float32, device=self.dev)
-        ca2 = torch.empty((T, c), dtype=torch.float32, device=self.dev)
+        fused = self._fused_phase1(T)                    # phase 1 in ONE kernel: neither a, g1 nor r leave the CU
+        mstencil = not V.grouped_rep                     # chain: depthwise RepConv (C = 64) as a Toeplitz-MFMA 5x5 on a channel-planar g1
+        B = bufs if bufs is not None else self.naf_buffers(T, h, w, c, mode)
+        hwb, g2, y, pool2, ca2, ca1, g1, pool1 = (B.get(k) for k in ("hwb", "g2", "y", "pool2", "ca2", "ca1", "g1", "pool1"))
+        nb2 = pool2.shape[1]
+        if self._tickets is None and fused and self.fold_se:
+            self._tickets = torch.zeros((self.MAX_TICKETS,), dtype=torch.int32, device=self.dev)
         b_out = u["b_out"].data_ptr() if u["b_out"] is not None else None
         es = 2                                           # bytes per activation element
+        bad = self._guard_ptr()
 
         def ca_mlp(name: str, pool: torch.Tensor, ca: torch.Tensor, f0: int, n: int) -> None:
             q = P.cas[name]
             nblk = pool.shape[1]
             self._call("sn_ca_mlp", f"sn_ca_mlp[{name}]", pool.data_ptr() + f0 * nblk * c * 4, nblk, c, q["c"], q["cr"], 1.0 / (h * w),
-                       q["wa"].data_ptr(), q["wb"].data_ptr(), ca.data_ptr() + f0 * c * 4, n, self._stream())
+                       q["wa"].data_ptr(), q["wb"].data_ptr(), ca.data_ptr() + f0 * c * 4, n, bad, self._stream())
 
-        folded = False
-        for wrap, halo, t0, nt in (self._split_pieces(x, mode, V.wrap) if mode else [(0, None, 0, 0)]):
+        if frames is not None:
+            assert self.split is None
+            pieces = [(self._wrap_flag(mode, V.wrap) if mode else 0, None, frames[0], frames[1])]
+        else:
+            pieces = self._split_pieces(x, mode, V.wrap) if mode else [(0, None, 0, 0)]
+        for wrap, halo, t0, nt in pieces:
             st = self._stream()
             src = self._unit_src(x, mode, wrap=wrap, halo=halo, t0=t0, nt=nt)
             f0, n = (t0, nt) if nt else (0, T)           # frame range of this piece for the operators that take plain pointers
             if mode:
                 self._call("sn_gsts_shiftconv", "sn_gsts_shiftconv", C.byref(src), P.offs.data_ptr(), u["w1"].data_ptr(), hwb.data_ptr(), st)
             hw_ptr = hwb.data_ptr() if mode else None
+            folded = False
             if fused:
-                wt = C.byref(u[p1key]["desc"])
+                wt = C.byref(u["p1r"]["desc"])
                 sep = None
                 if self.fold_se and T <= self.MAX_TICKETS:
-                    if self._tickets is None:
-                        self._tickets = torch.zeros((self.MAX_TICKETS,), dtype=torch.int32, device=self.dev)
                     q = P.cas[pre + "ca2"]
-                    se = L.SeFold(q["wa"].data_ptr(), q["wb"].data_ptr(), q["c"], q["cr"], self._tickets.data_ptr(), ca2.data_ptr())
+                    se = L.SeFold(q["wa"].data_ptr(), q["wb"].data_ptr(), q["c"], q["cr"], self._tickets.data_ptr(), ca2.data_ptr(), bad)
                     sep = C.byref(se)
                 opt = None
                 if V.denoise:      # inner CALayer2 on g1 (gshift_denoise1.py:224,257): pass 1 = the channel sums of g1 and, by the tail, its scale ca1
                     q1 = P.cas[pre + "ca1"]
-                    se1 = L.SeFold(q1["wa"].data_ptr(), q1["wb"].data_ptr(), q1["c"], q1["cr"], self._tickets.data_ptr(), ca1.data_ptr())
+                    se1 = L.SeFold(q1["wa"].data_ptr(), q1["wb"].data_ptr(), q1["c"], q1["cr"], self._tickets.data_ptr(), ca1.data_ptr(), bad)
                     o1 = L.Phase1Opts(None, 1)
                     fn1 = "sn_gsts_cab2_phase1" if mode else "sn_cab1_phase1"
                     a1 = (C.byref(src), hw_ptr, wt, None, pool2.data_ptr(), C.byref(se1), C.byref(o1), st) if mode else \
@@ -491,11 +489,40 @@ class Engine:
                 k3 = "sn_dw5m_gemm_gate" if mstencil else "sn_grp5_gemm_gate"
                 self._call(k3, k3, g1.data_ptr() + fr1, ca1_ptr, u["w_toep5" if mstencil else "w_grp"].data_ptr(), u["w_gate"].data_ptr(),
                            g2.data_ptr() + fr2, pool2.data_ptr() + f0 * nb2 * c * 4, n, h, w, c, st)
-            if not (fused and folded):
+            if not folded:
                 ca_mlp(pre + "ca2", pool2, ca2, f0, n)
             k4 = "sn_gsts_cab2_phase2" if mode else "sn_cab1_phase2"
             self._call(k4, k4, C.byref(src), g2.data_ptr(), ca2.data_ptr(), u["w_out"].data_ptr(), b_out, y.data_ptr(), st)
         return Act(y, c)
+
+    def naf_buffers(self, T: int, h: int, w: int, c: int, mode: int) -> Dict[str, torch.Tensor]:
+        """The tensors one CAB2 / CAB1 writes: hwb (conv1 of the shifted half, CAB2), g2, y, the partial channel sums and the squeeze-excite
+        scales; chain only: g1 (bf16, channel-planar for the depthwise RepConv) and the inner pool of the denoisers.  All of them stay
+        referenced by the caller until the block's launches are issued: a temporary would go back to the caching allocator at once and a
+        tensor K3 WRITES could be carved out of the block K3 still READS its scale from (intermittent wrong frames at the small pyramid
+        levels; found by the full-size determinism check of config 4)."""
+        lib, V = self.lib, self.V
+        fused = self._fused_phase1(T)
+        mstencil = not V.grouped_rep
+        B: Dict[str, torch.Tensor] = {}
+        if mode:
+            B["hwb"] = self._new(T, h, w, c // 2)
+        B["g2"] = self._new(T, h, w, c)
+        B["y"] = self._new(T, h, w, c)
+        if fused:
+            nb2 = lib.sn_phase1_pool_blocks(T, h, w)
+            if nb2 < 1:
+                raise L.ShiftNetLibError(f"sn_phase1_pool_blocks failed with code {nb2}")
+        else:
+            B["g1"] = (torch.empty((T, h, c, lib.sn_planar_pitch(w)), dtype=torch.bfloat16, device=self.dev) if mstencil else self._new(T, h, w, c))
+            nb2 = lib.sn_dw5m_blocks(h, w) if mstencil else lib.sn_grp5_blocks(h, w)
+            if V.denoise:
+                B["pool1"] = torch.empty((T, lib.sn_lngate_blocks(h, w), c), dtype=torch.float32, device=self.dev)
+        if V.denoise:
+            B["ca1"] = torch.empty((T, c), dtype=torch.float32, device=self.dev)
+        B["pool2"] = torch.empty((T, nb2, c), dtype=torch.float32, device=self.dev)
+        B["ca2"] = torch.empty((T, c), dtype=torch.float32, device=self.dev)
+        return B
 
     def gsts_unit(self, pre: str, x: Act, reverse: bool) -> Act:
         return self.naf(pre + "1.", self.naf(pre + "0.", x, 2 if reverse else 1), 0)
@@ -596,10 +623,43 @@ class Engine:
         shortcut: optional [T,3,H,W] tensor added instead of x in "return output_features + shortcut[...]" (gshift_deblur1.py:791): the
         un-rounded float32 frames when x had to be rounded to a half-precision module dtype."""
         with torch.cuda.device(self.dev):      # launches, events and allocations all belong to the engine's device
-            if (not self.use_graph or self.split is not None or self.prof is not None or out_dtype is not None or shortcut is not None
-                    or torch.cuda.is_current_stream_capturing()):
-                return self._forward(x, noise_map, past, future, out_dtype, shortcut)
-            return self._forward_graphed(x, noise_map, past, future)
+            eager = (not self.use_graph or self.split is not None or self.prof is not None or out_dtype is not None or shortcut is not None
+                     or torch.cuda.is_current_stream_capturing())
+            out = self._forward(x, noise_map, past, future, out_dtype, shortcut) if eager else self._forward_graphed(x, noise_map, past, future)
+            if self._guard_tripped():
+                out = self._recover(lambda: self._forward(x, noise_map, past, future, out_dtype, shortcut), out)
+            return out
+
+    def _guard_tripped(self) -> bool:
+        """Reads (and re-arms) the range guard's flag: one 4-byte device-to-host copy per forward.  On a temporally split window the ranks
+        agree first -- a rank that recomputed on its own would leave the others alone in the halo exchanges."""
+        if self._bad is None or torch.cuda.is_current_stream_capturing():
+            return False
+        v = int(self._bad.item())
+        if self.split is not None:
+            v = self.split.any_rank(v)
+        if v:
+            self._bad.zero_()
+        return bool(v)
+
+    def _recover(self, rerun, out):
+        import warnings
+        if self._fused_phase1(1) and self.phase1 != "0":
+            warnings.warn(f"shiftnet_amd: {self.V.name}: a channel sum of the GSTS path is not finite -- an activation left the fp16 range of the fused "
+                          "phase-1 kernel (`a`, g1, r).  This module now runs phase 1 as the two-kernel chain with g1 in bf16 (SN_PHASE1=0) and the "
+                          "window is recomputed.")
+            self.phase1 = "0"
+            self.fallbacks += 1
+            for v in self._graphs.values():
+                if isinstance(v, tuple):
+                    v[0].reset()
+            self._graphs.clear()
+            out = rerun()
+            if not self._guard_tripped():
+                return out
+        warnings.warn(f"shiftnet_amd: {self.V.name}: non-finite channel sums on the bf16 chain as well (its `a` is fp16): the result of this window is "
+                      "not reliable -- run the module in float32 (net.float(): the fp32 engine has no half-precision intermediates).")
+        return out
 
     def _forward_graphed(self, x, noise_map, past, future):
         key = (tuple(x.shape), x.dtype, None if noise_map is None else (tuple(noise_map.shape), noise_map.dtype), past, future)

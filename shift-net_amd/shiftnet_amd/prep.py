@@ -217,66 +217,6 @@ def _h2_words(lo: np.ndarray, hi: np.ndarray) -> np.ndarray:
     return l16 | (h16 << 16)
 
 
-def pack_phase1(w1: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, w_dw3: torch.Tensor, w_dw5: torch.Tensor, w_dw5_3: torch.Tensor,
-                w2: torch.Tensor, c: int) -> Dict[str, torch.Tensor]:
-    """Operands of sn_cab_phase1 for one CAB1 / CAB2 (depthwise RepConv, C = 64).
-
-    w1: body[0] 1x1 [2C, K, 1, 1]; ln_w / ln_b: LayerNorm2d affine [K]; w_dw3: RepConv2.conv_2 [2C, 1, 3, 3]; w_dw5 / w_dw5_3: RepConv.conv_1
-    [C, 1, 5, 5] / conv_2 [C, 1, 3, 3]; w2: body[4] 1x1 [2C, C, 1, 1]  (gshift_deblur2.py:186-258).
-
-    * wfrag1: as pack_ln_gemm (LayerNorm affine folded, gate-paired rows).  The kernel feeds the RAW input to the MFMA and applies the
-      normalisation afterwards: W (v - mu) rstd + b = rstd (W v - mu (W 1) + sigma b) with W 1 = the row sums of the bf16-ROUNDED weights
-      (what the MFMA multiplies by).  The two correction terms are one more k-step of the same MFMA chain, whose A fragment is
-      wfragx: bf16 [8 M-tiles][16 rows][8]: k-slots 0..7 of every row = (W1 hi, W1 lo, W1 hi, W1 lo, b hi, b lo, b hi, b lo), hi = bf16(v),
-      lo = bf16(v - hi); the kernel supplies (-mu hi, -mu hi, -mu lo, -mu lo, sigma hi, sigma hi, sigma lo, sigma lo) per pixel.
-    * Wave q, lane group g, accumulator register r of M-tiles (2q, 2q+1) = a-channels c and C + c with c = 16 g + 4 q + r (rows_gate).  Packed
-      fp16 register k of a lane: k = 0: (r0, r1), 1: (r2, r3) of the first half, 2 / 3: the same of the gate partners.
-      w3: uint32 [4 q][4 g][2 pass][3 ty][8]: pass kp handles registers (kp, kp + 2); word 2 tx + kk = taps (ty, tx) of register kp + 2 kk
-          (identity folded into the centre tap, first-half channels scaled by P1_G1_SCALE); words 6, 7 unused.
-      w5: uint32 [4 q][4 g][2 k][5 ty][8]: word tx = taps (ty, tx) of g1 register k = channels c(r = 2k), c(r = 2k + 1); 3x3 and identity folded.
-    * wfrag2: body[4] / P1_G1_SCALE as fp16 fragments, gate-paired rows, natural K (r is stored in natural channel order); the rows of the
-      sigmoid half additionally times -log2(e)."""
-    g = pack_ln_gemm(w1, ln_w, ln_b, c)
-    assert c == 64
-    mt = c // 8
-    # row sums of the bf16-rounded, LayerNorm-folded weights, in bias (= storage position) order
-    w = w1.detach().float().cpu().numpy().reshape(2 * c, -1)
-    wf = torch.from_numpy(w * ln_w.detach().float().cpu().numpy()[None, :]).to(torch.bfloat16).float().numpy()
-    def hi_lo(v: np.ndarray):
-        hi = torch.from_numpy(v.astype(np.float32)).to(torch.bfloat16).float().numpy()
-        lo = torch.from_numpy((v - hi).astype(np.float32)).to(torch.bfloat16).float().numpy()
-        return hi, lo
-    (s_hi, s_lo), (b_hi, b_lo) = hi_lo(wf.sum(1)), hi_lo(w @ ln_b.detach().float().cpu().numpy())
-    wx = np.zeros((16 * mt, 8), np.float32)
-    wx[rows_gate(c)] = np.stack([s_hi, s_lo, s_hi, s_lo, b_hi, b_lo, b_hi, b_lo], 1)
-    # 3x3 on a (2C channels), identity folded
-    d3 = w_dw3.detach().float().cpu().numpy().reshape(2 * c, 9).copy()
-    d3[:, 4] += 1.0
-    d3[:c] *= P1_G1_SCALE
-    t3 = np.zeros((4, 4, 2, 3, 8), np.uint32)
-    d5 = pack_dw5(w_dw5, w_dw5_3).numpy()                       # [25][C], 3x3 + identity folded
-    t5 = np.zeros((4, 4, 2, 5, 8), np.uint32)
-    for q in range(4):
-        for gg in range(4):
-            c0 = 16 * gg + 4 * q
-            for kp in range(2):
-                for ty in range(3):
-                    for tx in range(3):
-                        for kk in range(2):
-                            o = kk * c + c0 + 2 * kp
-                            t3[q, gg, kp, ty, 2 * tx + kk] = _h2_words(d3[o, ty * 3 + tx], d3[o + 1, ty * 3 + tx])
-            for k in range(2):
-                for ty in range(5):
-                    for tx in range(5):
-                        t5[q, gg, k, ty, tx] = _h2_words(d5[ty * 5 + tx, c0 + 2 * k], d5[ty * 5 + tx, c0 + 2 * k + 1])
-    w2n = w2.detach().float().cpu().numpy().reshape(2 * c, c) / P1_G1_SCALE
-    w2n[c:] *= -np.log2(np.e)          # SimpleGate2 = b1 * sigmoid(b2) = b1 / (1 + 2^(-log2(e) b2)): the gate rows carry the factor, the kernel runs v_exp_f32 directly
-    wp = np.zeros((16 * mt, 32 * ((c + 31) // 32)), np.float32)
-    wp[rows_gate(c), :c] = w2n
-    return {"wfrag1": g["wfrag"], "wfragx": torch.from_numpy(wx.reshape(mt, 16, 8)).to(torch.bfloat16),
-            "w3": torch.from_numpy(t3.view(np.int32).copy()), "w5": torch.from_numpy(t5.view(np.int32).copy()), "wfrag2": pack_frag_f16(wp)}
-
-
 def pack_conv32_split(w: torch.Tensor, groups: int = 1) -> torch.Tensor:
     """fp32 conv weight [co][ci/groups][k][k] -> bf16 A fragments [2 (hi | lo)][MT][KS][64][8] of the split-precision fp32 conv
     (csrc/sn_f32.hip: conv32s_kernel): hi = bf16(w), lo = bf16(w - hi); rows in natural order (M-tile m = output channels 16 m ..).

@@ -73,6 +73,14 @@ class TemporalSplit:
         if int(flag.item()):
             raise ValueError("temporal split: every rank must hold at least one frame of the window (the halo exchanges are collective)")
 
+    def any_rank(self, flag: int) -> int:
+        """Collective OR of a per-rank flag (the engine's range guard: all ranks recompute a window together or none does)."""
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        if dist.get_backend(self.group) != "gloo":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
+
     def exchange(self, x: torch.Tensor, mode: int, circular: bool) -> Optional[torch.Tensor]:
         """One halo exchange for a unit of direction ``mode`` on input ``x`` ([T,h,w,C], NHWC): returns the neighbour's half-frame as a
         contiguous [h,w,C/2] tensor (None where this rank has no neighbour on that side) and feeds the other neighbour.

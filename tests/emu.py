@@ -306,101 +306,6 @@ def _h2(words):
     return lo, hi
 
 
-def cab_phase1(x, hwb, pk, mode, wrap):
-    """sn_cab_phase1 (csrc/sn_phase1.hip) on whole frames: raw-operand 1x1 + LayerNorm epilogue, 3x3 / gate / 5x5 in the accumulator layout
-    (wave q, lane group g, register r <-> channel 16 g + 4 q + r), fp16-packed stencil tables, fp16 second 1x1.  Strips, row segments and the
-    DPP neighbour fetches are index arithmetic of the kernel and not emulated; everything the HOST prepares (prep.pack_phase1) is decoded
-    exactly as the kernel addresses it.  x [T,h,w,C] (bf16-representable), hwb [T,h,w,C/2] or None -> (g2 [T,h,w,C], sums [T,C])."""
-    w1 = frag_to_np(pk["wfrag1"]); MT, KS = w1.shape[:2]
-    wx = np.zeros((MT, 1, 64, 8), np.float32); wx[:, 0, :16] = pk["wfragx"].float().numpy()      # LayerNorm k-step: only k-slots 0..7 (lanes 0..15)
-    w1x = np.concatenate([w1, wx], 1)
-    w2 = pk["wfrag2"].float().numpy()
-    t3 = pk["w3"].numpy().view(np.uint32); t5 = pk["w5"].numpy().view(np.uint32)
-    T, h, w, C = x.shape; Ch = C // 2
-    K = C + Ch if hwb is not None else C
-    assert C == 64 and KS * 32 == K
-    bf = lambda v: torch.tensor(v, dtype=torch.float32).to(torch.bfloat16).float().numpy()      # noqa: E731
-    xf = x.reshape(T, h * w, C)
-    hf = hwb.reshape(T, h * w, Ch) if hwb is not None else None
-    a = np.zeros((T, h * w, 2 * C), np.float32)           # natural a-channel order: first half | gate partners
-    for t in range(T):
-        f0, o0, f1, o1, _, _ = unit_slabs(T, C, t, mode, wrap)
-        for i0 in range(0, h * w, 16):
-            bfrag = np.zeros((KS + 1, 64, 8), np.float32)
-            rstd = np.zeros(16, np.float32)
-            for p in range(16):
-                i = min(i0 + p, h * w - 1)
-                u = np.concatenate([xf[f0, i, o0:o0 + Ch], xf[f1, i, o1:o1 + Ch]] + ([hf[t, i]] if hf is not None else []))
-                mean = np.float32(u.sum() / K); var = np.float32(max((u * u).sum() / K - mean * mean, 0.0))
-                ve = np.float32(var + np.float32(1e-6))
-                rstd[p] = np.float32(1.0) / np.sqrt(ve)
-                sigma = np.float32(ve * rstd[p])
-                m_hi = bf(-mean); m_lo = bf(np.float32(-mean - m_hi)); s_hi = bf(sigma); s_lo = bf(np.float32(sigma - s_hi))
-                bfrag[KS, p] = (m_hi, m_hi, m_lo, m_lo, s_hi, s_hi, s_lo, s_lo)            # lane group 0; groups 1..3 read the zero slot
-                for g in range(4):
-                    for s in range(KS):
-                        bfrag[s, g * 16 + p] = u[s * 32 + g * 8: s * 32 + g * 8 + 8]          # RAW operands
-            regs = mfma_tiles(w1x, bfrag)
-            for lane in range(64):
-                g, p = lane >> 4, lane & 15
-                if i0 + p >= h * w:
-                    continue
-                for q in range(4):
-                    for half in range(2):
-                        v = rstd[p] * regs[2 * q + half, lane]
-                        c0 = half * C + 16 * g + 4 * q
-                        a[t, i0 + p, c0:c0 + 4] = v.astype(np.float16).astype(np.float32)
-    a = a.reshape(T, h, w, 2 * C)
-    # decode the stencil tables: per-channel taps exactly as lane (g), wave (q), pass and word address them
-    k3 = np.zeros((2 * C, 3, 3), np.float32); k5 = np.zeros((C, 5, 5), np.float32)
-    for q in range(4):
-        for g in range(4):
-            c0 = 16 * g + 4 * q
-            for kp in range(2):
-                for ty in range(3):
-                    for tx in range(3):
-                        for kk in range(2):
-                            lo, hi = _h2(t3[q, g, kp, ty, 2 * tx + kk])
-                            k3[kk * C + c0 + 2 * kp, ty, tx] = lo; k3[kk * C + c0 + 2 * kp + 1, ty, tx] = hi
-            for k in range(2):
-                for ty in range(5):
-                    for tx in range(5):
-                        lo, hi = _h2(t5[q, g, k, ty, tx])
-                        k5[c0 + 2 * k, ty, tx] = lo; k5[c0 + 2 * k + 1, ty, tx] = hi
-    ap = np.zeros((T, h + 2, w + 2, 2 * C), np.float32); ap[:, 1:-1, 1:-1] = a
-    o = np.zeros_like(a)
-    for ty in range(3):
-        for tx in range(3):
-            o += k3[:, ty, tx][None, None, None, :] * ap[:, ty:ty + h, tx:tx + w]
-    o = o.astype(np.float16).astype(np.float32)
-    g1 = (o[..., :C] * o[..., C:]).astype(np.float16).astype(np.float32)          # carries P1_G1_SCALE
-    gp = np.zeros((T, h + 4, w + 4, C), np.float32); gp[:, 2:-2, 2:-2] = g1
-    r = np.zeros_like(g1)
-    for ty in range(5):
-        for tx in range(5):
-            r += k5[:, ty, tx][None, None, None, :] * gp[:, ty:ty + h, tx:tx + w]
-    rf = r.astype(np.float16).astype(np.float32).reshape(T, h * w, C)
-    g2 = np.zeros((T, h * w, C), np.float32)
-    for t in range(T):
-        for i0 in range(0, h * w, 16):
-            bfrag = np.zeros((2, 64, 8), np.float32)
-            for lane in range(64):
-                g, p = lane >> 4, lane & 15
-                i = min(i0 + p, h * w - 1)
-                for s in range(2):
-                    bfrag[s, lane] = rf[t, i, s * 32 + g * 8: s * 32 + g * 8 + 8]
-            regs = mfma_tiles(w2, bfrag)
-            for lane in range(64):
-                g, p = lane >> 4, lane & 15
-                if i0 + p >= h * w:
-                    continue
-                for q in range(4):
-                    b1, b2 = regs[2 * q, lane], regs[2 * q + 1, lane]
-                    c0 = 16 * g + 4 * q
-                    g2[t, i0 + p, c0:c0 + 4] = b1 / (1.0 + np.exp2(b2))          # the gate rows carry -log2(e)
-    return g2.reshape(T, h, w, C), g2.sum(1)
-
-
 def cab_phase1r(x, hwb, pk, mode, wrap, ca_in=None, want_g1_sums=False):
     """Role-split fused phase 1 (csrc/sn_phase1r.hip) on whole frames, C = 64 / 80: the stager's two-pass LayerNorm + constant-one bias slots,
     first 1x1 with wave-paired rows (wave q, lane group g, register r <-> channel 16 q + 4 g + r), packed-fp16 3x3 table addressed by

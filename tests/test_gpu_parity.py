@@ -104,7 +104,7 @@ def test_mfma_lane_layout():
     check("mfma_selftest", d, a @ b, 1e-5)
 
 
-@pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_deblur1"])
+@pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_deblur1", "gshift_denoise2", "gshift_denoise1"])      # C = 64 circular / 80 keep / 64 keep / 80 keep
 @pytest.mark.parametrize("hw", [(24, 24), (6, 10)])
 def test_gsts_gather_bit_exact(name, hw):
     from shiftnet_amd import lib as L
@@ -261,13 +261,15 @@ def _gsts_pieces(eng_sd, name, tag):
     check(f"unit_fwd_ragged{tag}_{name}", to_cpu(out.t, C), O.gsts_unit(sd, blk + "encoder_level1.", x2, False, V), 1.2e-2)
 
 
-@pytest.mark.parametrize("name,p1key", [("gshift_deblur2", "p1"), ("gshift_deblur2", "p1r"), ("gshift_deblur1", "p1r")])
-@pytest.mark.parametrize("T,h,w", [(3, 7, 21), (2, 5, 9), (2, 13, 70), (3, 40, 200), (2, 97, 130), (1, 64, 42), (1, 3, 40)])
-def test_cab_phase1_fused_kernel(T, h, w, name, p1key, engines):
+@pytest.mark.parametrize("name,p1key", [("gshift_deblur2", "p1r"), ("gshift_deblur1", "p1r")])
+@pytest.mark.parametrize("team", [0, 1])
+@pytest.mark.parametrize("T,h,w", [(3, 7, 21), (2, 5, 9), (2, 13, 70), (3, 40, 200), (2, 97, 130), (1, 64, 42), (1, 3, 40), (4, 33, 64), (5, 21, 122), (2, 9, 123)])
+def test_cab_phase1_fused_kernel(T, h, w, name, p1key, team, engines):
     """sn_gsts_cab2_phase1 / sn_cab1_phase1 (fused LayerNorm -> 1x1 -> dw3x3 -> gate -> RepConv -> 1x1 -> gate2) alone against the reference's g2 and its
-    channel sums, CAB1 and both CAB2 directions -- the VALU kernel (csrc/sn_phase1.hip, "p1": C = 64) and the role-split kernel with the RepConv on
-    the matrix cores (csrc/sn_phase1r.hip, "p1r": C = 64 depthwise and C = 80 grouped, gshift_deblur1.py:157-165,183-255): maps smaller than the
-    warm-up rows / the pixel region, one strip, several strips with a ragged last one, several row segments."""
+    channel sums, CAB1 and both CAB2 directions -- the role-split kernel with the RepConv on the matrix cores (csrc/sn_phase1r.hip: C = 64 depthwise
+    and C = 80 grouped, gshift_deblur1.py:157-165,183-255): maps smaller than the warm-up rows / the pixel region, one strip (w <= 64: the region
+    starts AT the image edge), two border strips (61 + 61 = 122 columns exactly, and 123 = three strips), several strips, row chunks that cross
+    strip and frame boundaries, teams of 4 / 2 frames in lock step with a ragged last frame block (T = 5) and one workgroup per walk (team 1)."""
     from shiftnet_amd import lib as L
     eng, sd = engines(name)
     V = O.VARIANTS[name]
@@ -283,7 +285,6 @@ def test_cab_phase1_fused_kernel(T, h, w, name, p1key, engines):
         a1, a2 = a.chunk(2, dim=1)
         b1, b2 = O._conv(sd, f"{q}body.4.", O._rep_conv(sd, f"{q}body.3.", a1 * a2, groups=(C // 8 if V.grouped_rep else C))).chunk(2, dim=1)
         return b1 * torch.sigmoid(b2)
-    layout = 1 if p1key == "p1r" else 0
     for mode, rev, unit in ((0, False, "encoder_level1.1."), (1, False, "encoder_level1.0."), (2, True, "encoder_level1_1.0.")):
         pre = blk + unit
         with torch.no_grad():
@@ -297,11 +298,12 @@ def test_cab_phase1_fused_kernel(T, h, w, name, p1key, engines):
                 hwd = None
         p1 = eng.P.units[pre][p1key]
         src = L.UnitSrc(xd.data_ptr(), T, h, w, C, mode, 1 if (V.wrap and mode) else 0)
-        nblk = eng.lib.sn_phase1_pool_blocks(T, h, w, layout)
+        nblk = eng.lib.sn_phase1_pool_blocks(T, h, w)
         assert nblk >= 1
         g2 = torch.full((T, h, w, C), float("nan"), dtype=torch.bfloat16, device=DEV)
         pool = torch.full((T, nblk, C), float("nan"), dtype=torch.float32, device=DEV)
-        L.check(L.cab_phase1(eng.lib, src, hwd.data_ptr() if hwd is not None else None, p1["desc"], g2.data_ptr(), pool.data_ptr(), st), "phase 1")
+        L.check(L.cab_phase1(eng.lib, src, hwd.data_ptr() if hwd is not None else None, p1["desc"], g2.data_ptr(), pool.data_ptr(), st,
+                             None, L.Phase1Opts(None, 0, team)), "phase 1")
         check(f"phase1_g2_{name}_{p1key}_{mode}_{T}x{h}x{w}", to_cpu(g2, C), ref, 1.2e-2)
         sums = pool.sum(1).cpu()
         rs = ref.sum((2, 3))
@@ -327,6 +329,105 @@ def test_unit_parity_at_production_tile_counts(name, T, h, w, engines):
     for unit, rev in (("encoder_level1.", False), ("encoder_level1_1.", True)):
         out = eng.gsts_unit(blk + unit, act(to_dev(x), V.c1), rev)
         check(f"unit_{'rev' if rev else 'fwd'}_{name}_{T}x{h}x{w}", to_cpu(out.t, V.c1), O.gsts_unit(sd, blk + unit, x, rev, V), 1.2e-2)
+
+
+def _sibling_engine(eng, **attrs):
+    """A second Engine on the SAME prepared weights with other switches (phase 1 as the bf16 chain, fewer squeeze-excite counters ...)."""
+    from shiftnet_amd.engine import Engine
+    e2 = Engine(eng.P)
+    for k, v in attrs.items():
+        setattr(e2, k, v)
+    return e2
+
+
+@pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_denoise2", "gshift_deblur1", "gshift_denoise1"])
+def test_gsts_pieces_bf16_chain(name, engines):
+    """The chain the range guard falls back to (SN_PHASE1=0: sn_ln_gemm_gate + sn_dw5m_gemm_gate / sn_grp5_gemm_gate, g1 in bf16 through HBM,
+    sn_ca_mlp between the phases) for all four variants: CAB2 both directions, CAB1, a unit, a whole Encoder_shift_block, ragged sizes --
+    the same checks and tolerances as the fused default."""
+    eng, sd = engines(name)
+    chain = _sibling_engine(eng, phase1="0")
+    assert not chain._fused_phase1(4)
+    _gsts_pieces((chain, sd), name, "_chain")
+
+
+@pytest.mark.parametrize("name,T,h,w", [("gshift_deblur2", 3, 184, 328), ("gshift_deblur1", 3, 184, 328), ("gshift_denoise1", 3, 136, 224)])
+def test_unit_parity_bf16_chain_at_production_tile_counts(name, T, h, w, engines):
+    eng, sd = engines(name)
+    chain = _sibling_engine(eng, phase1="0")
+    V = O.VARIANTS[name]
+    x = bf(torch.from_numpy(synth.unit_noise((T, V.c1, h, w), seed=83)))
+    blk = "stage1.decoder_level1."
+    for unit, rev in (("encoder_level1.", False), ("encoder_level1_1.", True)):
+        out = chain.gsts_unit(blk + unit, act(to_dev(x), V.c1), rev)
+        check(f"unit_chain_{'rev' if rev else 'fwd'}_{name}_{T}x{h}x{w}", to_cpu(out.t, V.c1), O.gsts_unit(sd, blk + unit, x, rev, V), 1.2e-2)
+
+
+@pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_denoise1"])
+def test_gsts_pieces_with_more_frames_than_squeeze_excite_counters(name, engines):
+    """T > Engine.MAX_TICKETS (4096 frames in production; 2 here): the deblur models keep the fused kernel and finish CALayer2 with sn_ca_mlp,
+    the denoisers -- whose two-pass phase 1 needs the fold for the inner scale -- run the chain (engine.py: _fused_phase1)."""
+    eng, sd = engines(name)
+    few = _sibling_engine(eng, MAX_TICKETS=2)
+    assert few._fused_phase1(4) == (not O.VARIANTS[name].denoise)
+    _gsts_pieces((few, sd), name, "_fewtickets")
+
+
+def _hot_state_dict(name, gain):
+    """The synthetic checkpoint with the first 1x1 of every CAB2 / CAB1 of stage 1 times `gain`: `a` grows by gain, g1 = a1 a2 by gain^2."""
+    sd = synth_state_dict(name)
+    for k in list(sd):
+        if k.startswith("stage1.") and k.endswith(".body.0.weight") and sd[k].shape[-1] == 1 and sd[k].shape[0] == 2 * O.VARIANTS[name].c1:
+            sd[k] = sd[k] * gain
+    return sd
+
+
+@pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_denoise1"])
+def test_range_guard_moves_a_module_to_the_bf16_chain(name):
+    """ADVICE r04 / VERDICT r04 item 3b: a checkpoint whose activations leave the fp16 range of the fused phase-1 kernel (body.0.weight x 300:
+    g1 = a1 a2 2^-4 ~ 1e5 .. 1e6 overflows fp16) must not produce inf / NaN silently.  The squeeze-excite reductions flag the non-finite channel
+    sums; forward() then warns, switches the module to the two-kernel chain (g1 in bf16) for good and recomputes the window: the result is
+    finite, bit-identical to a module that ran the chain from the start, and within the block tolerance of the oracle on the same weights."""
+    import importlib
+    import warnings
+    from shiftnet_amd.engine import Engine, Plan
+    mod = importlib.import_module(f"basicsr.models.archs.{name}")
+    V = O.VARIANTS[name]
+    sd = _hot_state_dict(name, 300.0)
+    T, H, W = 5, 32, 48
+    blur, _ = synth.blurred_clip(T, H, W, seed=3)
+    x = O.frames_to_tensor(list(blur)).bfloat16().cuda()
+    nm = torch.full((1, T, 1, H, W), 30.0 / 255.0, device="cuda", dtype=torch.bfloat16) if V.denoise else None
+    net = mod.GShiftNet(future_frames=2, past_frames=2)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(torch.bfloat16).cuda().eval()
+    eng = net.prepare()
+    assert eng.range_guard and eng._fused_phase1(T)
+    with torch.no_grad():
+        with pytest.warns(UserWarning, match="fp16 range"):
+            y = net(x, nm) if V.denoise else net(x)
+        assert eng.fallbacks == 1 and eng.phase1 == "0" and torch.isfinite(y.float()).all()
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                   # the second window runs the chain quietly
+            y2 = net(x, nm) if V.denoise else net(x)
+        assert torch.equal(y, y2) and eng.fallbacks == 1
+        # a module on the chain from the start
+        chain = Engine(Plan(VARIANTS[name], {k: v.bfloat16() for k, v in sd.items()}, DEV))
+        chain.phase1 = "0"
+        y3 = chain.forward(x[0], nm[0] if nm is not None else None, 2, 2)
+        assert torch.equal(y, y3)
+        # and the chain is right on these weights: one Encoder_shift_block against the oracle
+        C = V.c1
+        xb = bf(torch.from_numpy(synth.unit_noise((3, C, 20, 44), seed=81)))
+        blk = "stage1.decoder_level1."
+        out = chain.shift_block(blk, act(to_dev(xb), C))
+        ref = O.shift_block({k: v.float() for k, v in sd.items()}, blk, xb, V)
+        check(f"shift_block_hot_chain_{name}", to_cpu(out.t, C), ref, 4e-2)
+        # the fused kernel on the same block does overflow (otherwise this test would not test the guard)
+        hot = Engine(chain.P)
+        hot.range_guard = False
+        bad = hot.shift_block(blk, act(to_dev(xb), C)).t.float()
+        assert not torch.isfinite(bad).all()
 
 
 @pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_deblur1", "gshift_denoise1", "gshift_denoise2"])
@@ -465,6 +566,8 @@ def test_full_size_properties():
 
 
 FULL_SIZE = {
+    # BASELINE config 2 (the bench's headline workload): Shift-Net-s, 1280x720, one_len 16 -> T_in 20
+    "config2": ("gshift_deblur2", 20, 720, 1280),
     # BASELINE config 3: Shift-Net+ deblur, 1280x720, one_len 48 -> T_in 52 (three levels, 56 GSTS units)
     "config3": ("gshift_deblur1", 52, 720, 1280),
     # BASELINE config 4: Shift-Net+ denoise sigma 30, 852x480 T=32 -> T_in 36, ONE of the CLI's 4 quadrants of 272x448
@@ -531,17 +634,17 @@ def test_denoise_unit_is_reproducible_under_allocator_churn():
                     assert torch.equal(ref, y), (T, h, w, mode)
 
 
-@pytest.mark.parametrize("name,p1key", [("gshift_deblur2", "p1"), ("gshift_deblur2", "p1r"), ("gshift_deblur1", "p1r")])
+@pytest.mark.parametrize("name,p1key", [("gshift_deblur2", "p1r"), ("gshift_deblur1", "p1r")])
 def test_squeeze_excite_fold_matches_ca_mlp_and_is_reproducible(name, p1key, engines):
     """sn_se_fold: the last workgroup of each frame of the fused phase-1 launch finishes CALayer2 (fixed-order reduction of the partial sums
     + the MLP).  Against sn_ca_mlp on the very same partial sums (another summation order: 1e-6), bit-identical over repeated launches
-    whichever workgroup arrives last, counters left at zero -- at a production size (184 workgroups per frame) and a small one."""
+    whichever workgroup arrives last, counters left at zero -- at a production size (6 x 360 x 640: row chunks that cross strips and frames,
+    two or three walks per strip and frame) and a small one."""
     from shiftnet_amd import lib as L
     eng, sd = engines(name)
     lib, P = eng.lib, eng.P
     st = torch.cuda.current_stream().cuda_stream
     C_ = O.VARIANTS[name].c1
-    layout = 1 if p1key == "p1r" else 0
     for (T, h, w), reps in (((6, 360, 640), 12), ((3, 20, 44), 4)):
         x = torch.from_numpy(synth.unit_noise((T, h, w, C_), seed=7)).to(torch.bfloat16).to(DEV)
         hwb = torch.from_numpy(synth.unit_noise((T, h, w, C_ // 2), seed=8)).to(torch.bfloat16).to(DEV)
@@ -549,21 +652,21 @@ def test_squeeze_excite_fold_matches_ca_mlp_and_is_reproducible(name, p1key, eng
             pre = "stage1.decoder_level1." + unit
             p1, q = P.units[pre][p1key], P.cas[pre + "ca2"]
             src = L.UnitSrc(x.data_ptr(), T, h, w, C_, mode, 1 if mode else 0)
-            nblk = lib.sn_phase1_pool_blocks(T, h, w, layout)
+            nblk = lib.sn_phase1_pool_blocks(T, h, w)
             g2 = torch.empty((T, h, w, C_), dtype=torch.bfloat16, device=DEV)
             tickets = torch.zeros((T,), dtype=torch.int32, device=DEV)
             ref = first = None
             for r in range(reps):
                 pool = torch.full((T, nblk, C_), float("nan"), dtype=torch.float32, device=DEV)
                 ca = torch.full((T, C_), float("nan"), dtype=torch.float32, device=DEV)
-                se = L.SeFold(q["wa"].data_ptr(), q["wb"].data_ptr(), q["c"], q["cr"], tickets.data_ptr(), ca.data_ptr())
+                se = L.SeFold(q["wa"].data_ptr(), q["wb"].data_ptr(), q["c"], q["cr"], tickets.data_ptr(), ca.data_ptr(), None)
                 L.check(L.cab_phase1(lib, src, hwb.data_ptr() if mode else None, p1["desc"], g2.data_ptr(), pool.data_ptr(), st, se), "phase 1 + fold")
                 torch.cuda.synchronize()
                 assert int(tickets.abs().sum()) == 0, "counters not re-armed"
                 if ref is None:
                     ref = torch.empty_like(ca)
                     L.check(lib.sn_ca_mlp(pool.data_ptr(), nblk, C_, q["c"], q["cr"], 1.0 / (h * w), q["wa"].data_ptr(), q["wb"].data_ptr(),
-                                          ref.data_ptr(), T, st), "sn_ca_mlp")
+                                          ref.data_ptr(), T, None, st), "sn_ca_mlp")
                     torch.cuda.synchronize()
                     first = ca.clone()
                     assert torch.isfinite(ca).all() and (ca - ref).abs().max().item() <= 2e-6, (T, h, w, mode, (ca - ref).abs().max().item())
@@ -686,7 +789,6 @@ def test_cab_phase1_layernorm_with_large_mean(name, p1key, ratio, engines):
     xd, hwd = to_dev(x), to_dev(hw_in)
     st = torch.cuda.current_stream().cuda_stream
     groups = C // 8 if V.grouped_rep else C
-    layout = 1 if p1key == "p1r" else 0
 
     def ref_g2(q, v):
         a = O._conv(sd, f"{q}body.0.", v)
@@ -705,7 +807,7 @@ def test_cab_phase1_layernorm_with_large_mean(name, p1key, ratio, engines):
                 ref = ref_g2(pre, O.layer_norm_2d(x.double(), sd[pre + "norm.weight"].double(), sd[pre + "norm.bias"].double()).float())
         p1 = eng.P.units[pre][p1key]
         src = L.UnitSrc(xd.data_ptr(), T, h, w, C, mode, 1 if (V.wrap and mode) else 0)
-        nblk = eng.lib.sn_phase1_pool_blocks(T, h, w, layout)
+        nblk = eng.lib.sn_phase1_pool_blocks(T, h, w)
         g2 = torch.full((T, h, w, C), float("nan"), dtype=torch.bfloat16, device=DEV)
         pool = torch.zeros((T, nblk, C), dtype=torch.float32, device=DEV)
         L.check(L.cab_phase1(eng.lib, src, hwd.data_ptr() if mode else None, p1["desc"], g2.data_ptr(), pool.data_ptr(), st), "phase 1")
@@ -814,7 +916,7 @@ def test_cab_phase1_fused_kernel_denoisers_two_passes(T, h, w, name, engines):
             ref = b1 * torch.sigmoid(b2)
         p1, q1 = eng.P.units[pre]["p1r"], eng.P.cas[pre + "ca1"]
         src = L.UnitSrc(xd.data_ptr(), T, h, w, C, mode, 0)
-        nblk = eng.lib.sn_phase1_pool_blocks(T, h, w, 1)
+        nblk = eng.lib.sn_phase1_pool_blocks(T, h, w)
         pool = torch.full((T, nblk, C), float("nan"), dtype=torch.float32, device=DEV)
         ca1 = torch.full((T, C), float("nan"), dtype=torch.float32, device=DEV)
         se1 = L.SeFold(q1["wa"].data_ptr(), q1["wb"].data_ptr(), q1["c"], q1["cr"], tickets.data_ptr(), ca1.data_ptr())

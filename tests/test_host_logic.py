@@ -47,6 +47,74 @@ def test_library_exports_every_declared_symbol():
     assert lib.sn_conv_pool_blocks(ctypes.byref(d)) == 90 * 40            # 8x32 tiles
 
 
+def _p1r_walks(plan, nfr, h, w, lib):
+    """The walks every workgroup of a phase-1 launch makes, re-derived from the plan exactly as cab_phase1r_kernel does (csrc/sn_phase1r.hip:
+    team chunk of the (strip, frame block) row list -> (frame, strip, rows, pool slot))."""
+    nsx, sd, sr, F, nfb, q, nteam = plan
+    rows_all = nsx * nfb * h
+    plan7 = (ctypes.c_int * 7)(*plan)
+    out = []
+    for team in range(nteam):
+        r0, r1 = team * q, min(team * q + q, rows_all)
+        for fm in range(F):
+            for u in range(r0 // h, (r1 + h - 1) // h):
+                s, fb = divmod(u, nfb)
+                f = fb * F + fm
+                if f >= nfr:
+                    continue
+                b0, b1 = lib.sn_p1r_strip_begin(plan7, s, w), lib.sn_p1r_strip_begin(plan7, s + 1, w)
+                xo = 0 if s == 0 else b0 - 3
+                k = team - (u * h) // q
+                cu = ((u + 1) * h - 1) // q - (u * h) // q + 1
+                out.append(dict(f=f, s=s, Y0=max(r0 - u * h, 0), Y1=min(r1 - u * h, h), k=k, cu=cu, xo=xo, olo=b0 - xo, ohi=b1 - xo))
+    return out
+
+
+@pytest.mark.parametrize("ncu", [256, 304, 64, 8])
+def test_phase1_work_plan_covers_every_row_once(ncu):
+    """sn_p1r_plan (the launch's own decomposition, csrc/sn_phase1r.hip): for the level sizes of every BASELINE config, ragged and tiny maps and
+    every team size, each row of each strip of each frame is walked exactly once; strips tile the width with own columns the 64-pixel region can
+    produce (3 halo columns towards every neighbour strip, none towards the image edge); pool slots stay below P1R_KCAP = 16 and the walks of
+    a (frame, strip) occupy slots 0 .. cu-1 exactly once (the squeeze-excite tail counts cu arrivals per strip)."""
+    from shiftnet_amd import lib as L
+    lib = L.load()
+    sizes = [(20, 360, 640), (20, 180, 320), (52, 360, 640), (52, 180, 320), (52, 90, 160), (16, 540, 960), (16, 270, 480), (16, 135, 240),
+             (36, 136, 224), (36, 68, 112), (36, 34, 56), (1, 360, 640), (19, 360, 640), (3, 7, 21), (2, 5, 9), (5, 21, 122), (2, 9, 123), (1, 3, 40),
+             (4, 33, 64), (3, 40, 65), (7, 1, 700), (4097, 8, 8)]
+    for (nfr, h, w) in sizes:
+        for team in (0, 1, 2, 4, 8):
+            o = (ctypes.c_int * 7)()
+            rc = lib.sn_p1r_plan(nfr, h, w, ncu, team, o)
+            if team and (team > max(ncu // 8, 1) or max(ncu // 8, 1) % team):
+                assert rc == -22, (nfr, h, w, ncu, team)
+                continue
+            assert rc == 0, (nfr, h, w, ncu, team)
+            plan = list(o)
+            nsx, sd, sr, F, nfb, q, nteam = plan
+            assert lib.sn_phase1_pool_blocks(nfr, h, w) == nsx * 16
+            assert F in (1, 2, 4, 8) and (team == 0 or F == team) and nfb == -(-nfr // F) and F * nteam <= 8 * max(ncu // 8, 1)
+            b = [lib.sn_p1r_strip_begin(o, s, w) for s in range(nsx + 1)]
+            assert b[0] == 0 and b[-1] == w and all(b[i] < b[i + 1] for i in range(nsx))
+            seen = {}
+            slots = {}
+            for wk in _p1r_walks(plan, nfr, h, w, lib):
+                assert 0 <= wk["Y0"] < wk["Y1"] <= h and 0 <= wk["k"] < wk["cu"] <= 16
+                assert 0 <= wk["olo"] < wk["ohi"] <= 64 and wk["xo"] >= 0
+                assert wk["olo"] == (0 if wk["s"] == 0 else 3)                                          # halo towards the left neighbour
+                assert wk["ohi"] <= (64 if wk["s"] == nsx - 1 else 61)                                   # ... and towards the right one
+                key = (wk["f"], wk["s"])
+                rows = seen.setdefault(key, [0] * h)
+                for y in range(wk["Y0"], wk["Y1"]):
+                    rows[y] += 1
+                sl = slots.setdefault(key, set())
+                assert wk["k"] not in sl
+                sl.add(wk["k"])
+                slots[key + ("cu",)] = wk["cu"]
+            assert len(seen) == nfr * nsx, (nfr, h, w, ncu, team, len(seen))
+            assert all(all(c == 1 for c in rows) for rows in seen.values()), (nfr, h, w, ncu, team)
+            assert all(slots[k] == set(range(slots[k + ("cu",)])) for k in seen)
+
+
 def test_fp32_entry_points_refuse_what_their_kernels_do_not_implement():
     """The optional operands of sn32_conv_desc exist in specific kernels only; any other shape must come back SN_EINVAL (-22) from the host-side
     checks (no GPU needed) instead of being silently ignored -- a LayerNorm / residual scale / channel sum that is not applied is a wrong result."""
@@ -102,11 +170,12 @@ def test_pmc_summaries_are_bound_to_the_sources_of_their_kernels():
     ks = bench.kernel_sources()
     assert "cab_phase1r_kernel" in ks["sn_phase1r.hip"] and "scale_gemm_res_kernel" in ks["sn_gsts.hip"] and "conv32s_kernel" in ks["sn_f32.hip"]
     assert not set.intersection(*[ks["sn_f32.hip"], set().union(*(v for f, v in ks.items() if f != "sn_f32.hip"))])     # a kernel name maps to one unit
-    doc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_hbm_traffic_cfg2.json")))
+    doc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_hbm_traffic_cfg2.json")))      # a real summary: its kernel list, re-bound to today's sources
+    doc["csrc_files"] = bench.csrc_files(doc["kernels_per_window"].keys())
     files = doc["csrc_files"]
     assert {"sn_phase1r.hip", "sn_gsts.hip", "sn_conv.hip", "sn_common.h", "shiftnet_hip.h"} <= set(files)
     assert "sn_f32.hip" not in files                       # a bf16 window launches nothing from the fp32 engine's unit
-    assert files == bench.csrc_files(doc["kernels_per_window"].keys()) or bench.pmc_sources_changed(doc)     # consistent either way
+    assert bench.pmc_sources_changed(doc) == []
     stale = copy.deepcopy(doc)
     stale["csrc_files"]["sn_gsts.hip"] = "0" * 16
     assert bench.pmc_sources_changed(stale) == ["sn_gsts.hip"]
@@ -173,28 +242,49 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _halo_worker(rank, world, port, L):
+def _halo_worker(rank, world, port, L, active, all_gather):
     sys.path.insert(0, os.path.join(ROOT, "shift-net_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from shiftnet_amd.clip_parallel import assemble_window, window_ranges
-    n = world * L + 4
+    n = active * L + 4                              # a round in which only the first `active` ranks hold a window (the last round of a clip)
     # a 1080p-shaped (16:9) clip, small; frame f is identifiable from any of its pixels
     clip = torch.arange(n * 3 * 9 * 16, dtype=torch.float32).reshape(n, 3, 9, 16)
-    own = clip[rank * L + 2: rank * L + 2 + L]
-    win = assemble_window(own, clip[:2] if rank == 0 else None, clip[-2:] if rank == world - 1 else None, rank, world)
-    # window r of the clip-parallel run == window r of the single-GPU CLI loop (inference/test_deblur.py:111-120)
-    rin, rout = window_ranges(n, L)[rank]
-    assert torch.equal(win, clip[rin.start:rin.stop]), rank
-    assert torch.equal(win[2:-2], clip[rout.start:rout.stop]) and torch.equal(win[2:-2], own), rank
+    r = rank if rank < active else 0                # idle ranks hold filler frames, as the CLI does
+    own = clip[r * L + 2: r * L + 2 + L]
+    win = assemble_window(own, clip[:2] if rank == 0 else None, clip[-2:] if rank == active - 1 else None, rank, world, active=active,
+                          all_gather=all_gather)
+    if rank >= active:
+        assert win is None
+    else:
+        # window r of the clip-parallel run == window r of the single-GPU CLI loop (inference/test_deblur.py:111-120)
+        rin, rout = window_ranges(n, L)[rank]
+        assert torch.equal(win, clip[rin.start:rin.stop]), rank
+        assert torch.equal(win[2:-2], clip[rout.start:rout.stop]) and torch.equal(win[2:-2], own), rank
+    if rank == 0 and world > 1:
+        with pytest.raises(ValueError):             # one_len 1: the halo would span two neighbours
+            assemble_window(own[:1], clip[:2], None, rank, world)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,L", [(2, 5), (4, 16), (8, 12)])     # 8 x one_len 12 = BASELINE config 5's partition of 96 frames
-def test_halo_exchange_gloo(world, L):
+# 8 x one_len 12 = BASELINE config 5's partition of 96 frames; (4, 16, 3): a last round with an idle rank; the last case: round 4's all-gather form
+@pytest.mark.parametrize("world,L,active,all_gather", [(2, 5, 2, False), (4, 16, 4, False), (8, 12, 8, False), (4, 16, 3, False), (3, 2, 3, False),
+                                                       (4, 6, 4, True)])
+def test_halo_exchange_gloo(world, L, active, all_gather):
+    """clip_parallel.assemble_window: two raw frames to / from each neighbour (batch_isend_irecv), world 2 / 3 / 4 / 8."""
     port = _free_port()
-    mp.spawn(_halo_worker, args=(world, port, L), nprocs=world, join=True)
+    mp.spawn(_halo_worker, args=(world, port, L, active, all_gather), nprocs=world, join=True)
+
+
+def test_cli_refuses_clip_parallel_modes_it_cannot_run():
+    """--gpus N with one_len < 2 (a halo would span two neighbour windows) or with --host_io (a single-process mode) must stop in the argument
+    parser of EVERY rank, before any process group exists (the single-process CLI accepts both)."""
+    from shiftnet_amd import cli
+    for extra in (["--one_len", "1"], ["--one_len", "4", "--host_io"]):
+        with pytest.raises(SystemExit) as e:
+            cli.main("gshift_deblur2", ["--synthetic", "32", "32", "12", "--gpus", "2"] + extra)
+        assert e.value.code == 2
 
 
 def test_bench_refuses_fewer_gpus_than_asked():

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Fused phase-1 kernel (sn_gsts_cab2_phase1 / sn_cab1_phase1) against the oracle, with a breakdown of where any error sits (row / column / channel -> wave q,
 lane group g, register r), then its time at the level-1 and level-2 sizes of config 2 next to sn_ln_gemm_gate + sn_dw5m_gemm_gate.
-usage: check_phase1.py [--no-time] [--name gshift_deblur1|gshift_deblur2] [--key p1|p1r] [--sizes T,h,w;T,h,w]
-p1 = csrc/sn_phase1.hip (VALU stencils, C = 64), p1r = csrc/sn_phase1r.hip (role-split, RepConv on the matrix cores, C = 64 / 80)."""
+usage: check_phase1.py [--no-time] [--name gshift_deblur1|gshift_deblur2] [--sizes T,h,w;T,h,w] [--teams 0,1,2,4,8]
+The kernel is csrc/sn_phase1r.hip (role-split, RepConv on the matrix cores, C = 64 / 80); --teams times sn_phase1_opts.team values (0 = the library's choice)."""
 import ctypes as C
 import os
 import sys
@@ -23,8 +23,7 @@ def main():
     def arg(k, d):
         return sys.argv[sys.argv.index(k) + 1] if k in sys.argv else d
     name = arg("--name", "gshift_deblur2")
-    key = arg("--key", "p1" if name == "gshift_deblur2" else "p1r")
-    layout = 1 if key == "p1r" else 0
+    key = "p1r"
     dev = torch.device("cuda:0")
     V, OV = VARIANTS[name], O.VARIANTS[name]
     sd = synth_state_dict(name)
@@ -47,7 +46,7 @@ def main():
         T, h, w, c = xd.shape
         src = L.UnitSrc(xd.data_ptr(), T, h, w, c, mode, 1 if (V.wrap and mode) else 0)
         g2 = torch.full((T, h, w, c), float("nan"), dtype=torch.bfloat16, device=dev)
-        nblk = lib.sn_phase1_pool_blocks(T, h, w, layout)
+        nblk = lib.sn_phase1_pool_blocks(T, h, w)
         pool = torch.zeros((T, nblk, c), dtype=torch.float32, device=dev)
         L.check(L.cab_phase1(lib, src, hwb.data_ptr() if hwb is not None else None, u["desc"], g2.data_ptr(), pool.data_ptr(), st), "phase 1")
         torch.cuda.synchronize()
@@ -109,12 +108,11 @@ def main():
             k3 = lib.sn_dw5m_gemm_gate if mst else lib.sn_grp5_gemm_gate
             calls = {}
             pools = {}
-            for kk in ("p1", "p1r"):
-                if kk in u:
-                    lay = 1 if kk == "p1r" else 0
-                    nb = lib.sn_phase1_pool_blocks(T, h, w, lay)
-                    pools[kk] = torch.zeros((T, nb, Cc), dtype=torch.float32, device=dev)
-                    calls[f"phase1 fused {kk}"] = (lambda kk=kk: L.cab_phase1(lib, src, hp, u[kk]["desc"], g2.data_ptr(), pools[kk].data_ptr(), st))
+            nb = lib.sn_phase1_pool_blocks(T, h, w)
+            for team in [int(v) for v in arg("--teams", "0").split(",")]:
+                pools[team] = torch.zeros((T, nb, Cc), dtype=torch.float32, device=dev)
+                calls[f"phase1 fused team {team}"] = (lambda team=team: L.cab_phase1(lib, src, hp, u["p1r"]["desc"], g2.data_ptr(), pools[team].data_ptr(), st,
+                                                                                   None, L.Phase1Opts(None, 0, team)))
             calls["K12"] = lambda: lib.sn_ln_gemm_gate(C.byref(src), hp, u["w_ln"].data_ptr(), u["b_ln"].data_ptr(), u["w_dw3_h2"].data_ptr(), g1.data_ptr(), None, 2 if mst else 0, st)
             calls["K3"] = lambda: k3(g1.data_ptr(), None, u["w_toep5" if mst else "w_grp"].data_ptr(), u["w_gate"].data_ptr(), g2.data_ptr(), pool2.data_ptr(), T, h, w, Cc, st)
             for k, f in calls.items():

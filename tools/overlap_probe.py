@@ -53,7 +53,7 @@ def main():
     for label, pl in libs.items():
         nblk = pl.sn_phase1_pool_blocks(T, h, w)
         pool = torch.zeros((T, nblk, c), dtype=torch.float32, device=dev)
-        p1 = lambda st: L.check(L.cab_phase1(pl, srca, None, u1["p1"]["desc"], g2a.data_ptr(), pool.data_ptr(), st), "p1")          # noqa: E731
+        p1 = lambda st: L.check(L.cab_phase1(pl, srca, None, u1["p1r"]["desc"], g2a.data_ptr(), pool.data_ptr(), st), "p1")          # noqa: E731
         k4 = lambda st: L.check(lib.sn_cab1_phase2(C.byref(srcb), g2b.data_ptr(), ca.data_ptr(), u1["w_out"].data_ptr(), b_out, ya.data_ptr(), st), "k4")   # noqa: E731
         cur = torch.cuda.current_stream().cuda_stream
         t_p1, t_k4 = timed(lambda: p1(cur)), timed(lambda: k4(cur))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B builds of the role-split fused phase-1 kernel (csrc/sn_phase1r.hip): each variant is a mini library (sn_phase1.hip + sn_phase1r.hip with
+"""A/B builds of the role-split fused phase-1 kernel (csrc/sn_phase1r.hip): each variant is a mini library (sn_phase1r.hip with
 -D flags) timed on the level-1 sizes of configs 3 / 2.  Variants with P1R_SKIP switch off parts of the roles (wrong results) to show which role paces a step.
   build (CPU, no GPU needed):  python tools/p1r_variants.py build
   time (GPU box):              python tools/p1r_variants.py time [name ...]"""
@@ -19,7 +19,7 @@ VARIANTS = {
     "barriers_only": ["-DP1R_SKIP=63"],
     "noAV": ["-DP1R_AV=0"], "noBV": ["-DP1R_BV=0"], "noAVBV": ["-DP1R_AV=0", "-DP1R_BV=0"], "d86": ["-DP1R_DB=8", "-DP1R_DA=6"], "d22": ["-DP1R_DB=2", "-DP1R_DA=2"],
     "AV6": ["-DP1R_AV=6"], "BV2": ["-DP1R_BV=2"],
-    "timing": ["-DP1R_TIMING=1"], "da2": ["-DP1R_DA=2"],
+    "da2": ["-DP1R_DA=2"], "nsw2": ["-DP1R_NSW64=2"],
     "prio000": ["-DP1R_PRIO_S=0", "-DP1R_PRIO_B=0", "-DP1R_PRIO_A=0"], "prio300": ["-DP1R_PRIO_S=3", "-DP1R_PRIO_B=0", "-DP1R_PRIO_A=0"],
     "prio311": ["-DP1R_PRIO_S=3", "-DP1R_PRIO_B=1", "-DP1R_PRIO_A=1"], "prio312": ["-DP1R_PRIO_S=3", "-DP1R_PRIO_B=1", "-DP1R_PRIO_A=2"],
     "prio210": ["-DP1R_PRIO_S=2", "-DP1R_PRIO_B=1", "-DP1R_PRIO_A=0"], "prio231": ["-DP1R_PRIO_S=2", "-DP1R_PRIO_B=3", "-DP1R_PRIO_A=1"],
@@ -34,13 +34,11 @@ def build(only=None):
     os.makedirs(DEV, exist_ok=True)
     csrc = os.path.join(ROOT, "shift-net_amd", "csrc")
     base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wno-unused-function"]
-    p1o = os.path.join(DEV, "sn_phase1.o")                      # the entry points (csrc/sn_phase1.hip) are the same for every variant
-    subprocess.run(base + ["-c", "-o", p1o, os.path.join(csrc, "sn_phase1.hip")], check=True)
     for name, flags in VARIANTS.items():
         if only and name not in only:
             continue
         out = os.path.join(DEV, f"libp1r_{name}.so")
-        subprocess.run(base + ["-shared", "-o", out, *flags, p1o, os.path.join(csrc, "sn_phase1r.hip")], check=True)
+        subprocess.run(base + ["-shared", "-o", out, *flags, os.path.join(csrc, "sn_phase1r.hip")], check=True)
         print("built", out, flush=True)
 
 
@@ -66,10 +64,10 @@ def time_all(names):
                     continue
                 lib = C.CDLL(path)
                 vp, ci = C.c_void_p, C.c_int
-                lib.sn_phase1_pool_blocks.argtypes = [ci, ci, ci, ci]
+                lib.sn_phase1_pool_blocks.argtypes = [ci, ci, ci]
                 lib.sn_gsts_cab2_phase1.argtypes = [C.POINTER(L.UnitSrc), vp, C.POINTER(L.Phase1Weights), vp, vp, C.POINTER(L.SeFold), C.POINTER(L.Phase1Opts), vp]
                 lib.sn_cab1_phase1.argtypes = [C.POINTER(L.UnitSrc), C.POINTER(L.Phase1Weights), vp, vp, C.POINTER(L.SeFold), C.POINTER(L.Phase1Opts), vp]
-                nb = lib.sn_phase1_pool_blocks(T, h, w, 1)
+                nb = lib.sn_phase1_pool_blocks(T, h, w)
                 pool = torch.zeros((T, nb, Cc), dtype=torch.float32, device=dev)
                 res = []
                 for mode, unit in ((0, "encoder_level1.1."), (1, "encoder_level1.0.")):
@@ -87,14 +85,6 @@ def time_all(names):
                     e1.record(); torch.cuda.synchronize()
                     res.append(e0.elapsed_time(e1) / 5 * 1e3)
                 print(f"VAR {model} {T}x{h}x{w} {name:16s} CAB1 {res[0]:8.1f} us   CAB2 {res[1]:8.1f} us", flush=True)
-                if name.startswith("timing"):        # per-wave (work, total) cycles of three workgroups of the last launch (CAB2)
-                    pc = pool.cpu()
-                    for (tt, bb) in ((0, 0), (T // 2, nb // 2), (T - 1, nb - 1)):
-                        r = pc[tt, bb]
-                        ns = r[40].item()
-                        nw = 2 * (Cc // 16) + 2
-                        print(f"   WG t={tt} blk={bb} steps {ns:.0f}: total {r[1].item() / ns:.0f} cyc/step; work cyc/step per wave:",
-                              " ".join(f"{r[2 * k].item() / ns:.0f}" for k in range(nw)), flush=True)
 
 
 if __name__ == "__main__":

@@ -40,11 +40,11 @@ def main():
         pool2 = torch.empty((T, nb, c), dtype=torch.float32, device=dev)
         ca2 = torch.ones((T, c + 16), dtype=torch.float32, device=dev)
         b_out = u["b_out"].data_ptr() if u["b_out"] is not None else None
-        fused = "p1" in u                 # Shift-Net-s deblur: phase 1 is one kernel (sn_gsts_cab2_phase1)
+        fused = "p1r" in u                 # Shift-Net-s deblur: phase 1 is one kernel (sn_gsts_cab2_phase1)
         pool1 = torch.empty((T, max(lib.sn_phase1_pool_blocks(T, h, w), 1), c), dtype=torch.float32, device=dev)
         calls = {
             "K0": lambda: lib.sn_gsts_shiftconv(C.byref(src), P.offs.data_ptr(), u["w1"].data_ptr(), hwb.data_ptr(), st),
-            "P1": lambda: L.cab_phase1(lib, src, hwb.data_ptr(), u["p1"]["desc"], g2.data_ptr(), pool1.data_ptr(), st),
+            "P1": lambda: L.cab_phase1(lib, src, hwb.data_ptr(), u["p1r"]["desc"], g2.data_ptr(), pool1.data_ptr(), st),
             "K12": lambda: lib.sn_ln_gemm_gate(C.byref(src), hwb.data_ptr(), u["w_ln"].data_ptr(), u["b_ln"].data_ptr(), u["w_dw3_h2"].data_ptr(),
                                                g1.data_ptr(), None, 2 if mst else 0, st),
             "K3": (lambda: lib.sn_dw5m_gemm_gate(g1.data_ptr(), None, u["w_toep5"].data_ptr(), u["w_gate"].data_ptr(), g2.data_ptr(), pool2.data_ptr(), T, h, w, c, st))
