@@ -188,7 +188,8 @@ int sn_dw5m_gemm_gate(const void* g1p, const float* ca_in, const void* ttab, con
  *             pair; k = kernel row, input column 0..5 relative to the pair, input channel);
  *     wfrag2  fp16 [C/8][KS2][64][8]: body[4], wave-paired rows, sigmoid rows times -log2 e.
  * g2: [T][h][w][C] NHWC bf16.  pool: NULL or [T][sn_phase1_pool_blocks(T,h,w)][C] f32 partial channel sums of g2 (CALayer2, finished by sn_ca_mlp or by
- * the sn_se_fold tail); EVERY row is written (rows no workgroup owns receive zeros), the layout does not depend on the frame range of the launch. */
+ * the sn_se_fold tail): one row per (column strip, block of 8 image rows) -- a property of the image, not of the launch, so the sums and every
+ * reduction over them are bit-identical whatever frame range (s->t0, s->nt), team size or device the launch runs with. */
 typedef struct sn_phase1_weights {
     const void* wfrag1;
     const uint32_t* w3;

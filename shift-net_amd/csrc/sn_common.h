@@ -138,9 +138,10 @@ __device__ __forceinline__ void sn_flag_nonfinite(unsigned* bad, float v) {
     if (bad && !(fabsf(v) <= 3.0e38f)) __hip_atomic_store(bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void sn_pool_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// pool_t: [nblk][cpad] partial sums of frame t (this workgroup's row already stored with sn_pool_store; rows nobody owns hold zeros);
-// narrive: how many calls are made for frame t by the whole launch (each after storing its row); lds: >= 16 + nthreads + 2 * 128
-// floats, no longer read by anybody in the workgroup once its first barrier is passed; cpad <= 128, cr <= 128.  Called by ALL threads.
+// pool_t: [nblk][cpad] partial sums of frame t (every row written by exactly one workgroup of the launch, with sn_pool_store);
+// narrive: how many calls are made for frame t by the whole launch (each after storing its rows); lds: >= 16 + (nthreads / (cpad / 4)) * cpad
+// + 2 * 128 floats, no longer read by anybody in the workgroup once its first barrier is passed; cpad % 4 == 0, cpad <= 128, cr <= 128.
+// Called by ALL threads.  The reduction order depends on (nblk, nthreads, cpad) only.
 __device__ __forceinline__ void sn_se_tail(const SeFold& S, const float* pool_t, int nblk, int narrive, int cpad, int t, float* lds, int tid, int nthreads) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's partial-sum stores are acknowledged by memory
     __syncthreads();
@@ -153,15 +154,23 @@ __device__ __forceinline__ void sn_se_tail(const SeFold& S, const float* pool_t,
         __hip_atomic_store(S.ticket + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch on this stream
     }
     __syncthreads();
-    float* acc = lds + 16; float* mean = acc + nthreads; float* hid = mean + 128;
-    // the nblk rows are split over nthreads / cpad thread groups, each walks its rows in order; the groups are then added in order
-    const int parts = nthreads / cpad, ch = tid % cpad, part = tid / cpad;
-    float sm = 0.f;
+    // thread = (row group `part`, channel quad): the nblk rows are split over nthreads / (cpad / 4) groups, each walks its rows in order with
+    // four channels per thread; the groups are then added in order
+    const int nq = cpad >> 2, parts = nthreads / nq, cq = tid % nq, part = tid / nq;
+    float* acc = lds + 16; float* mean = acc + parts * cpad; float* hid = mean + 128;
     if (part < parts) {
-#pragma unroll 8
-        for (int b = part; b < nblk; b += parts) sm += __hip_atomic_load(pool_t + (size_t)b * cpad + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
+        for (int b = part; b < nblk; b += parts) {
+            const float* r = pool_t + (size_t)b * cpad + 4 * cq;
+            s0 += __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s1 += __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s2 += __hip_atomic_load(r + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s3 += __hip_atomic_load(r + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        float* a = acc + part * cpad + 4 * cq;
+        a[0] = s0; a[1] = s1; a[2] = s2; a[3] = s3;
     }
-    acc[tid] = sm;
     __syncthreads();
     if (tid < cpad) {
         float m = 0.f;

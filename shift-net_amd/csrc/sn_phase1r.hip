@@ -44,19 +44,21 @@ namespace {
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
-// pool rows per (frame, column strip): a strip's rows of one frame are summed by at most P1R_KCAP workgroups (p1r_plan keeps the row chunks that long)
-#define P1R_KCAP 16
+// Pool rows (partial channel sums of g2 / g1) are per (frame, column strip, block of P1R_RB image rows) -- a property of the image, not of the
+// launch: whichever workgroups walk a frame, in whatever chunks, frame ranges and team sizes, every pool row is the same sum in the same order,
+// and so is the squeeze-excite tail's reduction over them.  A temporally split window or a frame-range launch is bit-identical to the whole one.
+#define P1R_RB 8
 
 // Work decomposition (p1r_plan, host).  The (strip, frame) walks of one launch form ONE list of rows, cut into equal chunks -- one chunk per
 // TEAM of F workgroups that walk F consecutive frames of the same strip rows in lock step (the half-channel roll of a CAB2 reads 64- / 80-byte
 // halves of 128-byte lines whose other half belongs to the neighbouring frame: team members sit on one XCD and touch such a line at the same
-// time).  A chunk that crosses the end of a strip simply continues with the next (strip, frame block) after a new warm-up.  Round 4 gave every
-// workgroup whole (strip, segment) items: 20 frames x 12 strips = 240 walks of 370 steps on 256 CUs, 16 of them idle and no way to use them;
-// the row list of 20 x 11 strips in 64 chunks of 310 rows takes ~330 steps.
+// time).  Chunks are whole row blocks (P1R_RB rows).  A chunk that crosses the end of a strip simply continues with the next (strip, frame
+// block) after a new warm-up.  Round 4 gave every workgroup whole (strip, segment) items: 20 frames x 12 strips = 240 walks of 370 steps on
+// 256 CUs, 16 of them idle and no way to use them; the row list of 20 x 11 strips in 64 chunks of 312 rows takes ~330 steps.
 struct P1RPlan {
     int nsx, sd, sr;      // column strips: count and how the slack of their capacity is spread (p1r_strip_begin)
     int F, nfb;           // frames walked in lock step by a team; frame blocks = ceil(nfr / F)
-    int q, nteam;         // rows of the row list per team; teams with work
+    int q, nteam;         // row BLOCKS of the list per team; teams with work
 };
 // first own column of strip s (s == nsx: w).  Strip 0 starts its 64-pixel region AT the image edge (no halo columns to the left of column 0)
 // and so does the last one on the right: capacities 61, 58, ..., 58, 61 own columns (one strip: 64); 1280 / 2 = 640 columns are 11 strips, not 12.
@@ -129,7 +131,7 @@ __device__ __forceinline__ uint32_t lane_next(uint32_t v) { return (uint32_t)__b
 #endif
 
 #ifndef P1R_NSW64        // stager waves at C = 64 (measurement builds: 2 = the round-4 split)
-#define P1R_NSW64 4
+#define P1R_NSW64 2
 #endif
 
 // compile-time geometry shared by the kernel and the launcher
@@ -156,7 +158,7 @@ template <int C, bool HW> struct P1RShape {
     static constexpr int WARM = 10;                           // steps per walk beyond its rows
     static_assert(GROW % 256 == 0, "the four lane groups of a RepConv B fragment read four ring rows: the pitch must keep their bank phase");
     static_assert(LDS <= 160 * 1024, "LDS");
-    static_assert((16 + NTHR + 256) * 4 <= 2 * OSLOT, "sn_se_tail scratch lives in the out ring");
+    static_assert((16 + (NTHR / (C / 4)) * C + 256) * 4 <= 2 * OSLOT, "sn_se_tail scratch lives in the out ring");
     static_assert(NSW == 2 || NSW == 4, "two or four lanes per region pixel");
 };
 
@@ -173,21 +175,23 @@ __device__ __forceinline__ int p1r_lane() { return (int)__builtin_amdgcn_mbcnt_h
 // one walk of a workgroup: rows [Y0, Y1) of strip s of frame t; all wave-uniform
 struct P1RItem {
     int s, t, Y0, Y1;
-    int k, cu;            // this walk is chunk k of the cu chunks that cover the strip's rows of this frame: pool row s * P1R_KCAP + k
     int xo, olo, ohi;     // image column of region column 0; own columns [olo, ohi) of the region
 };
 
 // ICA: the denoisers' inner CALayer2 on g1 (sn_phase1_opts).  0: none (deblur models); 1: sums pass (stagers + A waves only, channel sums of g1);
 // 2: g1 times A.g1_scale before the RepConv.  A template parameter: the deblur kernels sit at the 168-register limit of three waves per SIMD.
+// threads of a workgroup: the sums pass of the denoisers (ICA 1) has no B waves -- launching them idle cost the A waves a third of the register file
+template <int C, bool HW, int ICA> constexpr int p1r_threads() { return ICA == 1 ? 64 * (P1RShape<C, HW>::NGP + P1RShape<C, HW>::NSW) : P1RShape<C, HW>::NTHR; }
+
 template <int C, bool HW, int ICA>
-__global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(const P1RArgs A_) {
+__global__ __launch_bounds__((p1r_threads<C, HW, ICA>())) void cab_phase1r_kernel(const P1RArgs A_) {
     using SH = P1RShape<C, HW>;
     // The arguments are read from the kernarg segment where they are needed, through a pointer the compiler cannot see through (p1r_args): as SSA
     // values of the by-value parameter everything the end of a walk needs (plan, pool, squeeze-excite operands) stayed live across the step
     // loops -- 110 - 145 spilled SGPRs and, through their spill lanes, 7 - 30 spilled VGPRs in kernels that sit at the 168-register limit.
     P1RArgsP Ap = p1r_args();
 #define A (*Ap)
-    constexpr int NGP = SH::NGP, NTHR = SH::NTHR, CH = SH::CH, K = SH::K, KS1 = SH::KS1, KS2 = SH::KS2, NX = SH::NX;
+    constexpr int NGP = SH::NGP, NTHR = p1r_threads<C, HW, ICA>(), CH = SH::CH, K = SH::K, KS1 = SH::KS1, KS2 = SH::KS2, NX = SH::NX;
     constexpr int PSX = SH::PSX, XPL = SH::XPL, XSLOT = SH::XSLOT, GPL = SH::GPL, GROW = SH::GROW, PSR = SH::PSR, RSLOT = SH::RSLOT, PSO = SH::PSO, OSLOT = SH::OSLOT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const lds_x = smem + SH::OFF_X;
@@ -201,33 +205,31 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
     const int team = L / A.P.F, fm = L - team * A.P.F;
     if (team >= A.P.nteam) return;                                            // workgroup-uniform (padding of the last eighth)
     const int h = A.h, w = A.w, hw = h * w;
-    const int rows_all = A.P.nsx * A.P.nfb * h;
-    const int r0 = team * A.P.q, r1 = r0 + A.P.q < rows_all ? r0 + A.P.q : rows_all;
-    const int u0 = r0 / h, u1 = (r1 + h - 1) / h;                             // the (strip, frame block) walks this team's chunk touches
-    const int nrows = A.P.nsx * P1R_KCAP;                                     // pool rows per frame
-    auto chunks = [&](const int u) -> int { return ((u + 1) * h - 1) / A.P.q - (u * h) / A.P.q + 1; };
+    const int nbh = (h + P1R_RB - 1) / P1R_RB;                                // row blocks of a strip
+    const int blocks_all = A.P.nsx * A.P.nfb * nbh;
+    const int r0 = team * A.P.q, r1 = r0 + A.P.q < blocks_all ? r0 + A.P.q : blocks_all;
+    const int u0 = r0 / nbh, u1 = (r1 + nbh - 1) / nbh;                       // the (strip, frame block) walks this team's chunk touches
+    const int nrows = A.P.nsx * nbh;                                          // pool rows per frame: [strip][row block]
+    auto chunks = [&](const int u) -> int { return ((u + 1) * nbh - 1) / A.P.q - (u * nbh) / A.P.q + 1; };
     auto item = [&](const int u, P1RItem& I) -> bool {                        // false: this member's frame of the block does not exist (ragged last block)
         const int s = u / A.P.nfb, fb = u - s * A.P.nfb, f = fb * A.P.F + fm;
         if (f >= A.nfr) return false;
         I.s = s; I.t = A.t0 + f;
-        I.Y0 = r0 > u * h ? r0 - u * h : 0;
-        I.Y1 = r1 - u * h < h ? r1 - u * h : h;
-        I.k = team - (u * h) / A.P.q; I.cu = chunks(u);
+        const int b0_ = r0 > u * nbh ? r0 - u * nbh : 0, b1_ = r1 - u * nbh < nbh ? r1 - u * nbh : nbh;
+        I.Y0 = b0_ * P1R_RB;
+        I.Y1 = b1_ * P1R_RB < h ? b1_ * P1R_RB : h;
         const int b0 = p1r_strip_begin(A.P.nsx, A.P.sd, A.P.sr, s, w), b1 = p1r_strip_begin(A.P.nsx, A.P.sd, A.P.sr, s + 1, w);
         I.xo = s == 0 ? 0 : b0 - SH::HALO;
         I.olo = b0 - I.xo; I.ohi = b1 - I.xo;
         return true;
     };
-    // end of a walk, ALL threads: pool rows nobody writes are zeroed by the strip's first chunk, then the last workgroup of the frame finishes
-    // CALayer2 (the out ring is free: its last reader is behind the final barrier of the walk)
+    // end of a walk, ALL threads: the last workgroup of the frame finishes CALayer2 (the out ring is free: its last reader is behind the final
+    // barrier of the walk)
     auto finish = [&](const int u) {
         if (!A.pool) return;
         P1RItem I;
         item(u, I);
         const int tid = wv * 64 + p1r_lane();                                 // (not the kernel's `tid`: that one would stay live across the walk)
-        float* const prow = A.pool + ((size_t)I.t * nrows + I.s * P1R_KCAP) * C;
-        if (I.k == 0)
-            for (int e = I.cu * C + tid; e < P1R_KCAP * C; e += NTHR) sn_pool_store(prow + e, 0.f);
         if (A.se.ca) {
             const int fb = (I.t - A.t0) / A.P.F;
             int narr = 0;                                                     // walks that contribute to this frame
@@ -241,7 +243,8 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
     // role of this wave.  A workgroup's waves go to the four SIMDs round-robin, so waves wv, wv + 4, wv + 8 share a SIMD: the roles are laid
     // out so that every SIMD gets one A wave (VALU-heavy), one B wave (MFMA-heavy) and one of {A4, B4, S0, S1} (C = 80) / one stager (C = 64)
     int role, q;                                                              // 0: A, 1: B, 2: S
-    if (wv < 4) { role = 0; q = wv; }
+    if (ICA == 1) { role = wv < NGP ? 0 : 2; q = wv < NGP ? wv : wv - NGP; }
+    else if (wv < 4) { role = 0; q = wv; }
     else if (wv < 8) { role = 1; q = wv - 4; }
     else if (wv - 8 < 2 * (NGP - 4)) { role = (wv - 8) & 1; q = 4 + ((wv - 8) >> 1); }
     else { role = 2; q = wv - 8 - 2 * (NGP - 4); }
@@ -426,13 +429,12 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
                 cmul[0] = (h2_t){(_Float16)cs.x, (_Float16)cs.y}; cmul[1] = (h2_t){(_Float16)cs.z, (_Float16)cs.w};
             }
             float gsum[4] = {0.f, 0.f, 0.f, 0.f};
-            float ownc[NX];
-            if constexpr (ICA == 1) {
+            float* const psums = (ICA == 1 && A.pool) ? A.pool + ((size_t)t * nrows + (size_t)I.s * nbh) * C + 16 * q : nullptr;      // + row block * C
+            bool ownc[NX];                                                    // lane masks, not registers: this pass sits at the register limit
 #pragma unroll
-                for (int n = 0; n < NX; ++n) {
-                    const int rc = NX * p + n;
-                    ownc[n] = (rc >= I.olo && rc < I.ohi && colin[n]) ? 1.f : 0.f;
-                }
+            for (int n = 0; n < NX; ++n) {
+                const int rc = NX * p + n;
+                ownc[n] = ICA == 1 && rc >= I.olo && rc < I.ohi && colin[n];
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the weights have landed (no conservative waits inside the loop)
             __syncthreads();
@@ -469,13 +471,25 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
                         const uint32_t m = (rin && colin[n]) ? 0xffffffffu : 0u;
                         const h2_t g1a = F[n][0] * F[n][2], g1b = F[n][1] * F[n][3];
                         if constexpr (ICA == 1) {
-                            const float rown = (yg >= Y0 && yg < Y1) ? ownc[n] : 0.f;      // every pixel of the frame is counted by exactly one walk
-                            gsum[0] = fmaf((float)g1a[0], rown, gsum[0]); gsum[1] = fmaf((float)g1a[1], rown, gsum[1]);
-                            gsum[2] = fmaf((float)g1b[0], rown, gsum[2]); gsum[3] = fmaf((float)g1b[1], rown, gsum[3]);
+                            const bool cnt = yg >= Y0 && yg < Y1 && ownc[n];               // every pixel of the frame is counted by exactly one walk
+                            gsum[0] += cnt ? (float)g1a[0] : 0.f; gsum[1] += cnt ? (float)g1a[1] : 0.f;
+                            gsum[2] += cnt ? (float)g1b[0] : 0.f; gsum[3] += cnt ? (float)g1b[1] : 0.f;
                         } else if constexpr (ICA == 2) {
                             *(uint2*)(gs + n * GPL) = make_uint2(as_u(g1a * cmul[0]) & m, as_u(g1b * cmul[1]) & m);
                         } else {
                             *(uint2*)(gs + n * GPL) = make_uint2(as_u(g1a) & m, as_u(g1b) & m);
+                        }
+                    }
+                    if constexpr (ICA == 1) {
+                        if (psums && yg >= Y0 && yg < Y1 && (((yg + 1) & (P1R_RB - 1)) == 0 || yg == Y1 - 1)) {
+                            // the row block is complete: its channel sums of g1 (carried times 2^-4: undone here, exactly) -> its pool row
+                            const int ln = p1r_lane();
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float sm = row_sum16(gsum[r]) * 16.0f;
+                                if ((ln & 15) == 0) sn_pool_store(psums + (size_t)(yg / P1R_RB) * C + 4 * (ln >> 4) + r, sm);
+                                gsum[r] = 0.f;
+                            }
                         }
                     }
                     // ---- (2) first 1x1 on input row Y0 - 3 + j (x slot j & 1) -> packed fp16 `a` row for the next step.  Item i = (k-step i / NX,
@@ -485,7 +499,7 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
                     //  tools/ubench/mfma_chains.hip)
 #pragma unroll
                     for (int n0 = 0; n0 < NX; n0 += 2) {
-                        constexpr int NI = 2 * KS1, DA0 = ICA == 2 ? 2 : P1R_DA, DA = DA0 < NI ? DA0 : NI;      // (ICA 2 carries the scale registers: one fragment less in flight, no spill)
+                        constexpr int NI = 2 * KS1, DA0 = ICA != 0 ? 2 : P1R_DA, DA = DA0 < NI ? DA0 : NI;      // (ICA 1 / 2 carry the sums / the scale registers: one fragment less in flight, no spill)
                         auto rdx = [&](const int i) -> uint4 { return *(const uint4*)(xs + (n0 + (i & 1)) * XPL + 64 * (i >> 1)); };
                         uint4 bq[NI];
 #pragma unroll
@@ -512,32 +526,10 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
                 __syncthreads();
             }
             Ap = p1r_fresh(Ap);
-            if (ICA == 1 && A.pool) {                                         // channel sums of g1 (g1 is carried times 2^-4: undone here, exactly)
-                P1RItem J;
-                item(u, J);
-                const int ln = p1r_lane();
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float sm = row_sum16(gsum[r]) * 16.0f;
-                    if ((ln & 15) == 0) sn_pool_store(&A.pool[((size_t)J.t * nrows + J.s * P1R_KCAP + J.k) * C + 16 * q + 4 * (ln >> 4) + r], sm);
-                }
-            }
             finish(u);
         }
     } else if constexpr (ICA == 1) {
-        // B waves have no work in the sums pass: they only keep the barrier count
-#pragma unroll 1
-        for (int u = u0; u < u1; ++u) {
-            Ap = p1r_fresh(Ap);
-            P1RItem I;
-            if (!item(u, I)) continue;
-            const int NS = (I.Y1 - I.Y0 + 7 + 1) & ~1;
-            __syncthreads();
-#pragma unroll 1
-            for (int j = 0; j < NS; ++j) __syncthreads();
-            Ap = p1r_fresh(Ap);
-            finish(u);
-        }
+        // (the sums pass has no B waves)
     } else {
         // =================================================== B: RepConv, second 1x1, gate2 ===================================================
         __builtin_amdgcn_s_setprio(P1R_PRIO_B);
@@ -582,6 +574,8 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
                 own[n] = (rc >= I.olo && rc < I.ohi) ? 1.f : 0.f;
             }
             float psum[4] = {0.f, 0.f, 0.f, 0.f};
+            float* const psums = A.pool ? A.pool + ((size_t)I.t * nrows + (size_t)I.s * nbh) * C + 16 * q : nullptr;      // + row block * C
+            const int Y0 = I.Y0, Y1 = I.Y1;
             __builtin_amdgcn_s_waitcnt(0x0F70);
             __syncthreads();
             int jm = 1;                                                       // (j - 5) mod 6
@@ -662,21 +656,21 @@ __global__ __launch_bounds__((P1RShape<C, HW>::NTHR)) void cab_phase1r_kernel(co
                 if (do1 && do2) { gemm2(0); gemm2(2); repconv(std::integral_constant<int, P1R_BV>{}); }
                 else if (do1) { gemm2(0); gemm2(2); }
                 else if (do2) repconv(std::integral_constant<int, 0>{});
+                const int yo = Y0 - 9 + j;                                    // the g2 row gemm2 has just summed
+                if (do1 && psums && (((yo + 1) & (P1R_RB - 1)) == 0 || yo == Y1 - 1)) {
+                    // its row block is complete: the block's channel sums for CALayer2 (lane group g owns channels 16 q + 4 g + r) -> its pool row
+                    const int ln = p1r_lane();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sm = row_sum16(psum[r]);
+                        if ((ln & 15) == 0) sn_pool_store(psums + (size_t)(yo / P1R_RB) * C + 4 * (ln >> 4) + r, sm);
+                        psum[r] = 0.f;
+                    }
+                }
                 jm = jm == SH::GRING - 1 ? 0 : jm + 1;
                 __syncthreads();
             }
-            // channel sums of this walk for CALayer2: lane group g owns channels 16 q + 4 g + r
             Ap = p1r_fresh(Ap);
-            if (A.pool) {
-                P1RItem J;
-                item(u, J);
-                const int ln = p1r_lane();
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float sm = row_sum16(psum[r]);
-                    if ((ln & 15) == 0) sn_pool_store(&A.pool[((size_t)J.t * nrows + J.s * P1R_KCAP + J.k) * C + 16 * q + 4 * (ln >> 4) + r], sm);
-                }
-            }
             finish(u);
         }
     }
@@ -705,9 +699,8 @@ extern "C" int sn_p1r_plan(int nfr, int h, int w, int ncu, int team, int* out7) 
         P.nsx = n; P.sd = slack / n; P.sr = slack % n;
     }
     const int per_max = ncu / 8 > 0 ? ncu / 8 : 1;
-    int qmin = (h + P1R_KCAP - 2) / (P1R_KCAP - 1);                           // a strip's rows of one frame in <= P1R_KCAP chunks
-    const int q16 = h < 16 ? h : 16;                                          // and no chunk much shorter than its own warm-up
-    if (qmin < q16) qmin = q16;
+    const int nbh = (h + P1R_RB - 1) / P1R_RB;                                // chunks are whole row blocks (pool rows are per block)
+    const int qmin = nbh < 2 ? nbh : 2;                                       // no chunk much shorter than its own warm-up
     // team size: steps of the slowest workgroup ~ chunk rows + one warm-up per walk the chunk touches; among the sizes within 3 % of the best the
     // LARGEST wins (more frame pairs in lock step = fewer 128-byte lines fetched twice); a ragged last frame block idles its missing members
     long best = -1;
@@ -716,12 +709,12 @@ extern "C" int sn_p1r_plan(int nfr, int h, int w, int ncu, int team, int* out7) 
         const int F = 8 >> i;
         est[i] = -1;
         if ((team && F != team) || F > per_max || per_max % F) continue;
-        const long rows = (long)P.nsx * ((nfr + F - 1) / F) * h, tmax = 8L * per_max / F;
-        if (rows > 0x3fffffff) return SN_EINVAL;
-        long q = (rows + tmax - 1) / tmax;
+        const long blocks = (long)P.nsx * ((nfr + F - 1) / F) * nbh, tmax = 8L * per_max / F;
+        if (blocks > 0x3fffffff) return SN_EINVAL;
+        long q = (blocks + tmax - 1) / tmax;
         if (q < qmin) q = qmin;
         qs[i] = q;
-        est[i] = q + 10 * ((q + h - 1) / h + 1);
+        est[i] = q * P1R_RB + 10 * ((q + nbh - 1) / nbh + 1);
         if (best < 0 || est[i] < best) best = est[i];
     }
     if (best < 0) return SN_EINVAL;                                           // a fixed team size this device cannot place
@@ -729,8 +722,8 @@ extern "C" int sn_p1r_plan(int nfr, int h, int w, int ncu, int team, int* out7) 
     for (int i = 0; i < 4 && pick < 0; ++i)
         if (est[i] >= 0 && 100 * est[i] <= 103 * best) pick = i;
     P.F = 8 >> pick; P.nfb = (nfr + P.F - 1) / P.F;
-    const long rows_all = (long)P.nsx * P.nfb * h, q = qs[pick];
-    P.q = (int)q; P.nteam = (int)((rows_all + q - 1) / q);
+    const long blocks_all = (long)P.nsx * P.nfb * nbh, q = qs[pick];
+    P.q = (int)q; P.nteam = (int)((blocks_all + q - 1) / q);
     out7[0] = P.nsx; out7[1] = P.sd; out7[2] = P.sr; out7[3] = P.F; out7[4] = P.nfb; out7[5] = P.q; out7[6] = P.nteam;
     return SN_OK;
 }
@@ -757,7 +750,7 @@ int p1r_launch1(P1RArgs& A, hipStream_t st) {
     sn_clear_error();
     int per = (A.P.F * A.P.nteam + 7) / 8;
     per = (per + A.P.F - 1) / A.P.F * A.P.F;                                 // whole teams per XCD
-    hipLaunchKernelGGL((cab_phase1r_kernel<C, HW, ICA>), dim3((unsigned)(8 * per)), dim3(SH::NTHR), SH::LDS, st, A);
+    hipLaunchKernelGGL((cab_phase1r_kernel<C, HW, ICA>), dim3((unsigned)(8 * per)), dim3(p1r_threads<C, HW, ICA>()), SH::LDS, st, A);
     return sn_check_launch();
 }
 template <int C, bool HW>
@@ -787,7 +780,7 @@ int cab_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt
     }
     SN_FRAME_RANGE(s, t0, nt);
     A.t0 = t0; A.nfr = nt;
-    const int rc = p1r_plan(nt, s->h, s->w, ncu, opt ? opt->team : 0, A.P);      // the pool layout ([T][strips * P1R_KCAP][C]) does not depend on the frame range
+    const int rc = p1r_plan(nt, s->h, s->w, ncu, opt ? opt->team : 0, A.P);      // the pool layout ([T][strips][row blocks][C]) does not depend on the frame range
     if (rc != SN_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (s->C == 80) return s->mode ? p1r_launch<80, true>(A, st) : p1r_launch<80, false>(A, st);
@@ -802,7 +795,7 @@ int sn_phase1_pool_blocks(int T, int h, int w) {
     if (T < 1 || h < 1 || w < 1) return SN_EINVAL;
     int o[7];
     const int rc = sn_p1r_plan(1, h, w, 8, 1, o);                             // the strip count depends on w alone
-    return rc == SN_OK ? o[0] * P1R_KCAP : rc;
+    return rc == SN_OK ? o[0] * ((h + P1R_RB - 1) / P1R_RB) : rc;
 }
 
 int sn_gsts_cab2_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se,

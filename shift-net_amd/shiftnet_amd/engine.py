@@ -216,11 +216,13 @@ class Engine:
         self.fallbacks = 0                    # how often the guard moved this engine from the fused phase 1 to the bf16 chain (0 or 1)
         if self.phase1 not in ("auto", "r", "0"):
             raise ValueError(f"SN_PHASE1={self.phase1!r}: expected auto, r (fused kernel) or 0 (two-kernel bf16 chain)")
-        # hipGraph replay of the whole forward (~1400 launches per window), opt-in with SN_GRAPH=1: the first call with a given input
-        # signature runs eagerly, the second one is captured, later ones replay, so the Python / ctypes / allocator work per launch
-        # disappears.  Measured on MI355X: neutral at 1280x720 (126.4 vs 126.0 ms per window: the GPU is never starved there, kernels
-        # average 90 us), it pays on small clips where the ~10 us squeeze-excite kernels dominate the launch stream.
-        self.use_graph = os.environ.get("SN_GRAPH", "0") == "1"
+        # hipGraph replay of the whole forward (~1400 launches per window): the first call with a given input signature runs eagerly, the second
+        # one is captured, later ones replay, so the Python / ctypes / allocator work per launch disappears.  Measured on MI355X: neutral at
+        # 1280x720 (126.4 vs 126.0 ms per window: the GPU is never starved there, kernels average 90 us), 1.39x on a 64x96 clip where the ~10 us
+        # squeeze-excite kernels dominate the launch stream.  SN_GRAPH=1: always, 0: never, default: windows below GRAPH_AUTO_PXF pixel-frames.
+        g = os.environ.get("SN_GRAPH", "auto")
+        self.use_graph = g == "1"
+        self.graph_auto = g not in ("0", "1")
         self._graphs: "OrderedDict[Tuple, object]" = OrderedDict()   # LRU over input signatures, at most GRAPH_SLOTS captured graphs alive
 
     # ---- low level wrappers --------------------------------------------------------------------------------
@@ -623,7 +625,8 @@ class Engine:
         shortcut: optional [T,3,H,W] tensor added instead of x in "return output_features + shortcut[...]" (gshift_deblur1.py:791): the
         un-rounded float32 frames when x had to be rounded to a half-precision module dtype."""
         with torch.cuda.device(self.dev):      # launches, events and allocations all belong to the engine's device
-            eager = (not self.use_graph or self.split is not None or self.prof is not None or out_dtype is not None or shortcut is not None
+            graphed = self.use_graph or (self.graph_auto and x.shape[0] * x.shape[2] * x.shape[3] <= self.GRAPH_AUTO_PXF)
+            eager = (not graphed or self.split is not None or self.prof is not None or out_dtype is not None or shortcut is not None
                      or torch.cuda.is_current_stream_capturing())
             out = self._forward(x, noise_map, past, future, out_dtype, shortcut) if eager else self._forward_graphed(x, noise_map, past, future)
             if self._guard_tripped():
@@ -699,6 +702,7 @@ class Engine:
         return so.clone()                       # the graph owns `so`: hand out a copy, like the fresh tensor upstream returns
 
     MAX_TICKETS = 4096       # frames per tensor the squeeze-excite fold has counters for (longer windows fall back to sn_ca_mlp)
+    GRAPH_AUTO_PXF = 500_000   # T x H x W below which the launch stream, not the GPU, paces a forward (a 20 x 144 x 256 window: 0.74 M is GPU-bound)
     GRAPH_SLOTS = 2          # captured graphs kept per engine: each pins its whole activation pool (GBs at 720p), so a client that varies
     #                          the window shape must not accumulate them
 

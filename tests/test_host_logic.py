@@ -47,35 +47,39 @@ def test_library_exports_every_declared_symbol():
     assert lib.sn_conv_pool_blocks(ctypes.byref(d)) == 90 * 40            # 8x32 tiles
 
 
+P1R_RB = 8        # csrc/sn_phase1r.hip: rows per pool block
+
+
 def _p1r_walks(plan, nfr, h, w, lib):
     """The walks every workgroup of a phase-1 launch makes, re-derived from the plan exactly as cab_phase1r_kernel does (csrc/sn_phase1r.hip:
-    team chunk of the (strip, frame block) row list -> (frame, strip, rows, pool slot))."""
+    team chunk of the (strip, frame block) list of row BLOCKS -> (frame, strip, rows))."""
     nsx, sd, sr, F, nfb, q, nteam = plan
-    rows_all = nsx * nfb * h
+    nbh = -(-h // P1R_RB)
+    blocks_all = nsx * nfb * nbh
     plan7 = (ctypes.c_int * 7)(*plan)
     out = []
     for team in range(nteam):
-        r0, r1 = team * q, min(team * q + q, rows_all)
+        r0, r1 = team * q, min(team * q + q, blocks_all)
         for fm in range(F):
-            for u in range(r0 // h, (r1 + h - 1) // h):
+            for u in range(r0 // nbh, (r1 + nbh - 1) // nbh):
                 s, fb = divmod(u, nfb)
                 f = fb * F + fm
                 if f >= nfr:
                     continue
                 b0, b1 = lib.sn_p1r_strip_begin(plan7, s, w), lib.sn_p1r_strip_begin(plan7, s + 1, w)
                 xo = 0 if s == 0 else b0 - 3
-                k = team - (u * h) // q
-                cu = ((u + 1) * h - 1) // q - (u * h) // q + 1
-                out.append(dict(f=f, s=s, Y0=max(r0 - u * h, 0), Y1=min(r1 - u * h, h), k=k, cu=cu, xo=xo, olo=b0 - xo, ohi=b1 - xo))
+                cu = ((u + 1) * nbh - 1) // q - (u * nbh) // q + 1
+                B0, B1 = max(r0 - u * nbh, 0), min(r1 - u * nbh, nbh)
+                out.append(dict(f=f, s=s, Y0=B0 * P1R_RB, Y1=min(B1 * P1R_RB, h), cu=cu, xo=xo, olo=b0 - xo, ohi=b1 - xo))
     return out
 
 
 @pytest.mark.parametrize("ncu", [256, 304, 64, 8])
 def test_phase1_work_plan_covers_every_row_once(ncu):
     """sn_p1r_plan (the launch's own decomposition, csrc/sn_phase1r.hip): for the level sizes of every BASELINE config, ragged and tiny maps and
-    every team size, each row of each strip of each frame is walked exactly once; strips tile the width with own columns the 64-pixel region can
-    produce (3 halo columns towards every neighbour strip, none towards the image edge); pool slots stay below P1R_KCAP = 16 and the walks of
-    a (frame, strip) occupy slots 0 .. cu-1 exactly once (the squeeze-excite tail counts cu arrivals per strip)."""
+    every team size, each row of each strip of each frame is walked exactly once, in whole row blocks (a pool row = one (frame, strip, block)
+    has exactly one writer); strips tile the width with own columns the 64-pixel region can produce (3 halo columns towards every neighbour
+    strip, none towards the image edge); the number of walks per (frame, strip) is what the squeeze-excite tail counts as arrivals."""
     from shiftnet_amd import lib as L
     lib = L.load()
     sizes = [(20, 360, 640), (20, 180, 320), (52, 360, 640), (52, 180, 320), (52, 90, 160), (16, 540, 960), (16, 270, 480), (16, 135, 240),
@@ -91,14 +95,13 @@ def test_phase1_work_plan_covers_every_row_once(ncu):
             assert rc == 0, (nfr, h, w, ncu, team)
             plan = list(o)
             nsx, sd, sr, F, nfb, q, nteam = plan
-            assert lib.sn_phase1_pool_blocks(nfr, h, w) == nsx * 16
+            assert lib.sn_phase1_pool_blocks(nfr, h, w) == nsx * -(-h // P1R_RB)
             assert F in (1, 2, 4, 8) and (team == 0 or F == team) and nfb == -(-nfr // F) and F * nteam <= 8 * max(ncu // 8, 1)
             b = [lib.sn_p1r_strip_begin(o, s, w) for s in range(nsx + 1)]
             assert b[0] == 0 and b[-1] == w and all(b[i] < b[i + 1] for i in range(nsx))
-            seen = {}
-            slots = {}
+            seen, walks = {}, {}
             for wk in _p1r_walks(plan, nfr, h, w, lib):
-                assert 0 <= wk["Y0"] < wk["Y1"] <= h and 0 <= wk["k"] < wk["cu"] <= 16
+                assert 0 <= wk["Y0"] < wk["Y1"] <= h and wk["Y0"] % P1R_RB == 0 and (wk["Y1"] % P1R_RB == 0 or wk["Y1"] == h)
                 assert 0 <= wk["olo"] < wk["ohi"] <= 64 and wk["xo"] >= 0
                 assert wk["olo"] == (0 if wk["s"] == 0 else 3)                                          # halo towards the left neighbour
                 assert wk["ohi"] <= (64 if wk["s"] == nsx - 1 else 61)                                   # ... and towards the right one
@@ -106,13 +109,12 @@ def test_phase1_work_plan_covers_every_row_once(ncu):
                 rows = seen.setdefault(key, [0] * h)
                 for y in range(wk["Y0"], wk["Y1"]):
                     rows[y] += 1
-                sl = slots.setdefault(key, set())
-                assert wk["k"] not in sl
-                sl.add(wk["k"])
-                slots[key + ("cu",)] = wk["cu"]
+                walks[key] = walks.get(key, 0) + 1
+                assert wk["cu"] >= walks[key]
+                walks[key + ("cu",)] = wk["cu"]
             assert len(seen) == nfr * nsx, (nfr, h, w, ncu, team, len(seen))
             assert all(all(c == 1 for c in rows) for rows in seen.values()), (nfr, h, w, ncu, team)
-            assert all(slots[k] == set(range(slots[k + ("cu",)])) for k in seen)
+            assert all(walks[k] == walks[k + ("cu",)] for k in seen)                                      # arrivals the tail waits for == walks made
 
 
 def test_fp32_entry_points_refuse_what_their_kernels_do_not_implement():
