@@ -141,7 +141,7 @@ def kernel_alg_bytes(fn, meta):
         pin = T * ho * wo * stride * stride / (4 if in_mode == 1 else 1)
         return 4 * (pin * cin + T * ho * wo * (co // 4 if out_mode == 1 else co))
     if meta and meta[0] == "naf":
-        _, T, h, w, c, mode = meta
+        _, T, h, w, c, mode = meta[:6]
         px = T * h * w * 2
         p1 = px * (2.5 * c if mode else 2 * c)                                       # phase 1: read x (+ hw), write g2 (or g1)
         return {"sn_gsts_shiftconv": px * c, "sn_gsts_cab2_phase2": px * 3 * c, "sn_cab1_phase2": px * 3 * c, "sn_ln_gemm_gate": p1,
@@ -236,6 +236,8 @@ def main():
     ap.add_argument("--quadrants", action="store_true", help="denoise CLI tiling: 4 overlapping quadrants per step")
     ap.add_argument("--fp32_exact", action="store_true", help="--dtype fp32: exact fp32 products (v_mfma_f32_16x16x4_f32) instead of the default bf16 hi + lo "
                                                                "split products on the bf16 matrix cores (both within 1e-4 of the reference)")
+    ap.add_argument("--schedule", default=None, choices=["unit", "frame"], help="GSTS launch order: unit-major (default) or the frame-group wavefront (SURVEY 8 f2)")
+    ap.add_argument("--frame-group", type=int, default=None, help="--schedule frame: frames per group (default 4)")
     ap.add_argument("--lib", default=None, help="A/B measurements only: another build of libshiftnet_hip.so (the line then carries its path)")
     args = ap.parse_args()
     if args.lib:
@@ -313,6 +315,10 @@ def main():
     net.load_state_dict(synth_state_dict(args.variant), strict=True)
     net = net.to(dt).to(dev).eval()
     denoise = "denoise" in args.variant
+    if args.schedule or args.frame_group:
+        e_ = net.prepare()
+        e_.schedule = args.schedule or e_.schedule
+        e_.frame_group = args.frame_group or e_.frame_group
 
     # this rank's slice of one long synthetic clip: L owned frames (+ the clip edges on the first / last rank)
     blur, _ = synth.blurred_clip(L + 4, h, w, seed=100 + rank)
@@ -418,7 +424,7 @@ def main():
                 unit_ms += d
                 if meta[0] == "naf" and fn in ("sn_gsts_cab2_phase2", "sn_cab1_phase2"):      # one CAB finished: its fused-unit bytes = read x + write y
                     unit_bytes += 2 * meta[1] * meta[2] * meta[3] * meta[4] * 2
-                    n_cabs += 1
+                    n_cabs += meta[1] / meta[6]               # a frame-group launch of the wavefront schedule is that fraction of a CAB
                 elif "unit" in meta and label.endswith("weight]") and ".body." in label and meta[0] == "conv32" and meta[6] == 1 and meta[4] == meta[5]:
                     ui = meta.index("unit")                                                     # the fp32 CAB's last 1x1 (C -> C): same accounting, 4-byte elements
                     unit_bytes += 2 * meta[ui + 1] * meta[ui + 2] * meta[ui + 3] * meta[ui + 4] * 4
@@ -485,7 +491,7 @@ def main():
         dws = [window_gb(k) for k in G["members"]]
         dw = None if any(v is None for v in dws) else sum(dws)
         dom_traffic, dom_note = checked(None if dw is None else dw / G["n"], dom_alg, dom)
-        n_units = max(n_cabs // 2, 1)
+        n_units = max(int(round(n_cabs / 2)), 1)
         gw = [window_gb(k) for k, v in agg.items() if v["gsts"]]
         if pmc is not None and args.dtype == "fp32":      # fp32 engine: the unit's kernels are generic operators, told apart by launch order, not by symbol:
             gw = []                                         # the unit share of the window's traffic is not separable -> whole-net traffic only (below)
@@ -510,7 +516,8 @@ def main():
                                    + (f"module dtype {args.dtype}, " if args.dtype != "bf16" else "")
                                    + "one window per GPU, synthetic checkpoint", "parallelism": f"clip-parallel x{world}",
                        "baseline_config": args.config if args.config is not None else (2 if (args.variant, h, w, L) == (VARIANT, H, W, ONE_LEN) else None),
-                       **({"ab_library": args.lib} if args.lib else {})},
+                       **({"ab_library": args.lib} if args.lib else {}),
+                       **({"gsts_schedule": f"frame wavefront, groups of {net.prepare().frame_group}"} if net.prepare().schedule == "frame" else {})},
             # the roofline this path is graded on is the FUSED GSTS UNIT (channel_shift + CAB2 + CAB1: read x, write y per
             # CAB = 4 T C h w s bytes) over the time of every GSTS kernel; intermediates count zero bytes.
             "roofline": {"bound": "hbm", "scope": "fused GSTS unit (SURVEY.md 8d), all pyramid levels of one window", "achieved": round(ach_unit, 1),

@@ -131,14 +131,15 @@ __device__ __forceinline__ uint32_t lane_next(uint32_t v) { return (uint32_t)__b
 #endif
 
 #ifndef P1R_NSW64        // stager waves at C = 64 (measurement builds: 2 = the round-4 split)
-#define P1R_NSW64 2
+#define P1R_NSW64 4
 #endif
 
 // compile-time geometry shared by the kernel and the launcher
 template <int C, bool HW> struct P1RShape {
-    // Stager waves.  A workgroup's waves go to the four SIMDs round-robin and a SIMD's step costs the SUM of its waves' issue time.
-    // C = 80: 5 A + 5 B + 2 S = three waves on every SIMD.  C = 64 had 4 A + 4 B + 2 S: SIMDs 0 / 1 carried (A, B, S), SIMDs 2 / 3 only (A, B) and
-    // idled a third of every step -- four stagers with half the pixels' pieces each put (A, B, S/2) on every SIMD.
+    // Stager waves.  C = 80: 5 A + 5 B + 2 S = three waves on every SIMD (the 168-register limit).  C = 64 had 4 A + 4 B + 2 S; measured
+    // alone (tools/p1_ab.py, 20 x 360 x 640, CAB1) the roles take A 251, B 307, S 368 us of the launch's 555: ONE stager wave's instruction
+    // stream (two-pass LayerNorm of 4 - 6 sixteen-byte pieces per lane, then the g2 stores) is the longest dependency chain of a step.  Four
+    // stagers with half the pieces each: 525 / 580 us (CAB1 / CAB2) against 555 / 621 with two, interleaved A/B on one device.
     static constexpr int NGP = C / 16, NSW = NGP == 4 ? P1R_NSW64 : 2, NW = 2 * NGP + NSW, NTHR = 64 * NW;
     static constexpr int CH = C / 2, K = HW ? C + CH : C, KS1 = (K + 2 + 31) / 32, KS2 = (C + 31) / 32;
     static constexpr int NX = 4, RWD = 16 * NX, HALO = 3, VWMAX = RWD - HALO;      // a border strip has no halo on its image side

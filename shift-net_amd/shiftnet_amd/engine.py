@@ -426,7 +426,7 @@ class Engine:
         lib, V, P = self.lib, self.V, self.P
         u = P.units[pre]
         T, h, w, c = x.dims
-        self._meta = ("naf", T, h, w, c, mode)
+        self._meta = ("naf", frames[1] if frames is not None else T, h, w, c, mode, T)      # (frames of this launch group, ..., frames of the tensor)
         fused = self._fused_phase1(T)                    # phase 1 in ONE kernel: neither a, g1 nor r leave the CU
         mstencil = not V.grouped_rep                     # chain: depthwise RepConv (C = 64) as a Toeplitz-MFMA 5x5 on a channel-planar g1
         B = bufs if bufs is not None else self.naf_buffers(T, h, w, c, mode)
@@ -535,6 +535,35 @@ class Engine:
             x = self.gsts_unit(f"{pre}{UNIT_NAMES[i]}.", x, reverse=(i % 2 == 1))
         return x
 
+    # layer-frame wavefront.  "unit" (default): every unit runs over all T frames before the next one starts (the reference's
+    # order, gshift_deblur1.py:530-547).  "frame": the units of consecutive Encoder_shift_blocks of one pyramid level are issued per FRAME GROUP in
+    # dependency order -- unit k needs frames {t, t -/+ 1} of unit k - 1 (forward / reverse shift, :504-518), so a group of unit k can start as
+    # soon as its own and one neighbouring group of unit k - 1 are done and a frame's working set moves through many units while it is still in
+    # the Infinity Cache.  Results are bit-identical (every kernel honours frame ranges and the pool rows do not depend on them).  Measured:
+    # DESIGN.md section 3.3 -- no gain while phase 1 is not bandwidth-bound; SN_SCHEDULE=frame / bench.py --schedule frame keep it one flag away.
+    schedule = os.environ.get("SN_SCHEDULE", "unit")
+    frame_group = int(os.environ.get("SN_FRAME_GROUP", "4"))
+
+    def shift_chain(self, pres: Sequence[str], x: Act) -> Act:
+        """Consecutive Encoder_shift_blocks at one level (Encoder2.forward, gshift_deblur1.py:623-637 / gshift_deblur2.py:594-609)."""
+        T = x.dims[0]
+        if self.schedule != "frame" or self.split is not None or T <= self.frame_group:
+            for pre in pres:
+                x = self.shift_block(pre, x)
+            return x
+        _, h, w, c = x.dims
+        units = [(f"{pre}{UNIT_NAMES[i]}.", i % 2 == 1) for pre in pres for i in range(self.V.units)]
+        G = self.frame_group
+        groups = [(t0, min(G, T - t0)) for t0 in range(0, T, G)]
+        # every unit owns its tensors for the whole chain (no reuse games: 12 units x 3 GB at level 1 of config 2, out of 288 GB)
+        bufs = [(self.naf_buffers(T, h, w, c, 2 if rev else 1), self.naf_buffers(T, h, w, c, 0)) for _, rev in units]
+        ins = [x] + [Act(b1["y"], c) for _, b1 in bufs]           # ins[u]: input of unit u; ins[u + 1]: its output
+        for u, j in wavefront_order([rev for _, rev in units], T, G, self.V.wrap):
+            pre, rev = units[u]
+            y2 = self.naf(pre + "0.", ins[u], 2 if rev else 1, frames=groups[j], bufs=bufs[u][0])
+            self.naf(pre + "1.", y2, 0, frames=groups[j], bufs=bufs[u][1])
+        return ins[-1]
+
     def down(self, pre: str, x: Act) -> Act:
         """DownSample (gshift_deblur1.py:330-340 / gshift_denoise1.py:356-365)."""
         if self.V.denoise:
@@ -571,13 +600,10 @@ class Engine:
             x = self.shift_cab(p + "encoder_level0_1.", x, True)
         x = self.conv(p + "down01", [x], stride=2, pad=0, prelu=self.P.scalar(p + "down01.1.weight"))
         if V.topo == "small":
-            e = self.shift_block(p + "encoder_level1.", x)
-            e = self.shift_block(p + "encoder_level1_1.", e)
-            enc11 = self.shift_block(p + "encoder_level1_2.", e)
+            enc11 = self.shift_chain([p + "encoder_level1.", p + "encoder_level1_1.", p + "encoder_level1_2."], x)
             e = self.down(p + "down12.", enc11)
-            for n in ("encoder_level2", "encoder_level2_1", "encoder_level2_2",
-                      "decoder_level2", "decoder_level2_1", "decoder_level2_2"):
-                e = self.shift_block(f"{p}{n}.", e)
+            e = self.shift_chain([f"{p}{n}." for n in ("encoder_level2", "encoder_level2_1", "encoder_level2_2",
+                                                       "decoder_level2", "decoder_level2_1", "decoder_level2_2")], e)
             x = self.skip_up(p + "up21", e, self.cab(p + "skip_attn1.", enc11))
         else:
             if V.shift_cab:
@@ -589,13 +615,11 @@ class Engine:
             enc22 = self.cab(p + "encoder_level2_1.", self.cab(p + "encoder_level2.", e))
             e = self.down(p + "down23.", enc22)
             enc33 = self.cab(p + "encoder_level3_1.", self.cab(p + "encoder_level3.", e))
-            d = self.shift_block(p + "decoder_level3_1.", self.shift_block(p + "decoder_level3.", enc33))
+            d = self.shift_chain([p + "decoder_level3.", p + "decoder_level3_1."], enc33)
             x = self.skip_up(p + "up32", d, self.cab(p + "skip_attn2.", enc22))
-            d = self.shift_block(p + "decoder_level2_1.", self.shift_block(p + "decoder_level2.", x))
+            d = self.shift_chain([p + "decoder_level2.", p + "decoder_level2_1."], x)
             x = self.skip_up(p + "up21", d, self.cab(p + "skip_attn1.", enc11))
-        d = self.shift_block(p + "decoder_level1.", x)
-        d = self.shift_block(p + "decoder_level1_1.", d)
-        dec11 = self.shift_block(p + "decoder_level1_2.", d)
+        dec11 = self.shift_chain([p + "decoder_level1.", p + "decoder_level1_1.", p + "decoder_level1_2."], x)
         skip = self.cab(p + "skip_conv.", shortcut)
         if V.hr_cat:
             up = self.conv(p + "upsample0", [dec11], out_mode=1)
@@ -754,6 +778,41 @@ class Engine:
         assert sc.shape[0] == T and tuple(sc.shape[2:]) == (H, W) and sc.shape[1] >= 3 and sc.device == x.device
         self.conv("conv_last", [y], out_mode=2, nchw_out=out, nchw_sc=sc[lo:hi, :3].contiguous() if sc.shape[1] > 3 else sc[lo:hi].contiguous())
         return out
+
+
+def wavefront_order(revs: Sequence[bool], T: int, G: int, circular: bool) -> List[Tuple[int, int]]:
+    """Launch order (unit, frame group) of the frame wavefront: sweeps over the units, every unit advancing by at most one group per sweep --
+    the lowest-numbered group whose inputs exist.  Unit u needs, of unit u - 1, the group itself and the group of the ONE frame its boundary
+    frame borrows from: frame t0 - 1 for a forward unit, t0 + nt for a reverse one (gshift_deblur1.py:504-518); outside [0, T) that frame wraps
+    (deblur2, gshift_deblur2.py:504-505) or does not exist (kept boundary frame).  On the ring the first group of a forward unit therefore comes
+    last.  Pure host logic: tests/test_host_logic.py checks every order against the dependency rule."""
+    ng = -(-T // G)
+    groups = [(t0, min(G, T - t0)) for t0 in range(0, T, G)]
+    done = [[False] * ng for _ in revs]
+
+    def ready(u: int, j: int) -> bool:
+        if u == 0:
+            return True
+        t0, nt = groups[j]
+        tb = t0 + nt if revs[u] else t0 - 1
+        if tb < 0 or tb >= T:
+            tb = (tb % T) if circular else None
+        need = {j} | ({tb // G} if tb is not None else set())
+        return all(done[u - 1][g] for g in need)
+    order: List[Tuple[int, int]] = []
+    left = len(revs) * ng
+    while left:
+        progressed = False
+        for u in range(len(revs)):
+            j = next((j for j in range(ng) if not done[u][j] and ready(u, j)), None)
+            if j is None:
+                continue
+            order.append((u, j))
+            done[u][j] = True
+            left -= 1
+            progressed = True
+        assert progressed, "frame wavefront: dependency cycle"
+    return order
 
 
 def make_engine(V: Variant, sd: Dict[str, torch.Tensor], device: torch.device, dtype: torch.dtype):

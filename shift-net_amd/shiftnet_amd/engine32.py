@@ -106,6 +106,7 @@ class Engine32(Engine):
     def __init__(self, plan: Plan32) -> None:
         super().__init__(plan, torch.float32)
         self.graph_auto = False            # hipGraph replay stays opt-in (SN_GRAPH=1) for the fp32 engine: measured on the bf16 engine only
+        self.schedule = "unit"             # the frame wavefront (Engine.shift_chain) is built on the bf16 engine's frame-range launches
         self.range_guard = False           # no half-precision intermediates: nothing to guard (and no sn_se_fold / sn_ca_mlp flag operand is passed)
 
     act_dtype = torch.float32

@@ -117,6 +117,33 @@ def test_phase1_work_plan_covers_every_row_once(ncu):
             assert all(walks[k] == walks[k + ("cu",)] for k in seen)                                      # arrivals the tail waits for == walks made
 
 
+@pytest.mark.parametrize("circular", [False, True])
+def test_frame_wavefront_order_respects_the_shift_dependencies(circular):
+    """engine.wavefront_order: every (unit, frame group) exactly once, and never before the groups of the previous unit that
+    hold its own frames and the one frame its boundary frame borrows from (t - 1 forward, t + 1 reverse, wrapped on deblur2's ring)."""
+    from shiftnet_amd.engine import wavefront_order
+    for n_units in (1, 2, 4, 12, 24):
+        revs = [i % 2 == 1 for i in range(n_units)]
+        for T, G in ((20, 4), (20, 1), (7, 2), (7, 3), (52, 4), (5, 8), (16, 5)):
+            order = wavefront_order(revs, T, G, circular)
+            ng = -(-T // G)
+            assert sorted(order) == [(u, j) for u in range(n_units) for j in range(ng)]
+            pos = {k: i for i, k in enumerate(order)}
+            for (u, j), i in pos.items():
+                if u == 0:
+                    continue
+                frames = set(range(j * G, min(j * G + G, T)))
+                for t in list(frames):
+                    nb = t + 1 if revs[u] else t - 1
+                    if 0 <= nb < T:
+                        frames.add(nb)
+                    elif circular:
+                        frames.add(nb % T)
+                assert all(pos[(u - 1, t // G)] < i for t in frames), (n_units, T, G, u, j)
+            if n_units > 1 and ng > 2:                      # it IS a wavefront: the second unit starts before the first one is through
+                assert pos[(1, order[[k[0] for k in order].index(1)][1])] < max(pos[(0, j)] for j in range(ng))
+
+
 def test_fp32_entry_points_refuse_what_their_kernels_do_not_implement():
     """The optional operands of sn32_conv_desc exist in specific kernels only; any other shape must come back SN_EINVAL (-22) from the host-side
     checks (no GPU needed) instead of being silently ignored -- a LayerNorm / residual scale / channel sum that is not applied is a wrong result."""
