@@ -27,8 +27,10 @@ import torch.distributed as dist  # noqa: E402
 
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS command line with --no-parity --no-cpu-baseline (tools/make_profiles_r04.sh), one file
 # per preset; every file records the hash of the kernel sources it was measured on and is ignored when they have changed since.
-# (Config 4 = 4 quadrants x ~2900 launches per window: a --pmc pass of it did not finish within 10 minutes on the GPU box; no file.)
-PMC_FILES = {(2, "bf16"): "r04_pmc_hbm_traffic_cfg2.json", (3, "bf16"): "r04_pmc_hbm_traffic_cfg3.json"}
+PMC_FILES = {(2, "bf16"): "r05_pmc_hbm_traffic_cfg2.json", (3, "bf16"): "r05_pmc_hbm_traffic_cfg3.json",
+             # config 4: ONE of the CLI's four quadrants traced (bench.py --config 4 --one-quadrant: a quarter of the ~2900 launches, the four differ
+             # only in their crop); tools/pmc_summary.py scales the per-window totals by 4 (PMC_WINDOW_FRACTION=0.25, recorded in the file)
+             (4, "bf16"): "r05_pmc_hbm_traffic_cfg4_bf16.json"}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 VARIANT = "gshift_deblur2"
 H, W, ONE_LEN = 720, 1280, 16
@@ -234,6 +236,8 @@ def main():
     ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS), help="BASELINE.json config preset (default: 2)")
     ap.add_argument("--dtype", default=None, choices=list(DTYPES), help="module dtype (fp32 runs the fp32 engine)")
     ap.add_argument("--quadrants", action="store_true", help="denoise CLI tiling: 4 overlapping quadrants per step")
+    ap.add_argument("--one-quadrant", action="store_true", help="profiling only: run the FIRST of the four quadrants per step (a quarter of a config-4 window; "
+                                                                 "the line is marked and is not a throughput figure)")
     ap.add_argument("--fp32_exact", action="store_true", help="--dtype fp32: exact fp32 products (v_mfma_f32_16x16x4_f32) instead of the default bf16 hi + lo "
                                                                "split products on the bf16 matrix cores (both within 1e-4 of the reference)")
     ap.add_argument("--schedule", default=None, choices=["unit", "frame"], help="GSTS launch order: unit-major (default) or the frame-group wavefront (SURVEY 8 f2)")
@@ -331,6 +335,8 @@ def main():
         assert all(b - a == hh and d - c == ww for a, b, c, d in quads), (h, w, hh, ww)
     else:
         hh, ww, quads = h, w, [(0, h, 0, w)]
+    if args.one_quadrant:
+        quads = quads[:1]
     sigma_map = torch.full((1, L + 4, 1, hh, ww), 30.0 / 255.0, dtype=dt, device=dev) if denoise else None
 
     gather_ms = []          # per step: time of the halo exchange (N > 1), measured with events on the stream it is issued on
@@ -517,6 +523,7 @@ def main():
                                    + "one window per GPU, synthetic checkpoint", "parallelism": f"clip-parallel x{world}",
                        "baseline_config": args.config if args.config is not None else (2 if (args.variant, h, w, L) == (VARIANT, H, W, ONE_LEN) else None),
                        **({"ab_library": args.lib} if args.lib else {}),
+                       **({"one_quadrant_only": "profiling run: a quarter of the window's work per step"} if args.one_quadrant else {}),
                        **({"gsts_schedule": f"frame wavefront, groups of {net.prepare().frame_group}"} if net.prepare().schedule == "frame" else {})},
             # the roofline this path is graded on is the FUSED GSTS UNIT (channel_shift + CAB2 + CAB1: read x, write y per
             # CAB = 4 T C h w s bytes) over the time of every GSTS kernel; intermediates count zero bytes.

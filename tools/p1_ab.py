@@ -38,6 +38,14 @@ def main():
             libs["r04"] = (C.CDLL(os.path.join(DEV, f)), True)
         elif f.startswith("libp1r_") and f.endswith(".so"):
             libs[f[7:-3]] = (C.CDLL(os.path.join(DEV, f)), False)
+    k0libs = {"r04": libs["r04"][0]} if "r04" in libs else {}
+    k0libs["cur"] = C.CDLL(L.LIB_PATH)
+    for lib in k0libs.values():
+        lib.sn_gsts_shiftconv.argtypes = [C.POINTER(L.UnitSrc), vp, vp, vp, vp]
+        lib.sn_gsts_cab2_phase2.argtypes = [C.POINTER(L.UnitSrc), vp, vp, vp, vp, vp, vp]
+        lib.sn_cab1_phase2.argtypes = [C.POINTER(L.UnitSrc), vp, vp, vp, vp, vp, vp]
+    if "--k0-only" in sys.argv:
+        libs = {}
     for name, (lib, old) in libs.items():
         W = OldWeights if old else L.Phase1Weights
         lib.sn_gsts_cab2_phase1.argtypes = [C.POINTER(L.UnitSrc), vp, C.POINTER(W), vp, vp, vp, vp, vp]
@@ -72,6 +80,26 @@ def main():
                         f = (lambda lib=lib, src=src, wt=wt, op=op: lib.sn_cab1_phase1(C.byref(src), C.byref(wt), g2.data_ptr(), pool.data_ptr(), None, op, st))
                     f.keep = (src, wt, opt)
                     calls[(name + (f"_team{team}" if team else ""), "CAB2" if mode else "CAB1")] = f
+        # K0 (sn_gsts_shiftconv): round-4 library against the current one, forward and reverse units
+        for name, lib in k0libs.items():
+            for mode, unit in ((1, "encoder_level1.0."), (2, "encoder_level1_1.0.")):
+                u = P.units["stage1.decoder_level1." + unit]
+                src = L.UnitSrc(xd.data_ptr(), T, h, w, Cc, mode, 1 if V.wrap else 0)
+                f = (lambda lib=lib, src=src, u=u: lib.sn_gsts_shiftconv(C.byref(src), P.offs.data_ptr(), u["w1"].data_ptr(), hwb.data_ptr(), st))
+                f.keep = (src,)
+                calls[("K0_" + name, "CAB2" if mode == 2 else "CAB1")] = f          # (columns: forward unit / reverse unit)
+        # K4 (sn_cab1_phase2 / sn_gsts_cab2_phase2): columns CAB1 / CAB2
+        cav = torch.rand(T, Cc, device=dev)
+        yv = torch.empty_like(g2)
+        for name, lib in k0libs.items():
+            for mode, unit in ((0, "encoder_level1.1."), (1, "encoder_level1.0.")):
+                u = P.units["stage1.decoder_level1." + unit]
+                src = L.UnitSrc(xd.data_ptr(), T, h, w, Cc, mode, 1 if (mode and V.wrap) else 0)
+                bo = u["b_out"].data_ptr() if u["b_out"] is not None else None
+                fn = lib.sn_gsts_cab2_phase2 if mode else lib.sn_cab1_phase2
+                f = (lambda fn=fn, src=src, u=u, bo=bo: fn(C.byref(src), g2.data_ptr(), cav.data_ptr(), u["w_out"].data_ptr(), bo, yv.data_ptr(), st))
+                f.keep = (src,)
+                calls[("K4_" + name, "CAB2" if mode else "CAB1")] = f
         res = {k: [] for k in calls}
         keys = list(calls)
         for r in range(rounds):

@@ -28,6 +28,7 @@ def short(name):
 
 def main(out, windows, note, dirs):
     windows = int(windows)
+    frac = float(os.environ.get("PMC_WINDOW_FRACTION", "1"))      # the traced steps ran this fraction of a window (config 4: one quadrant of four)
     tot, grid = {}, {}
     for d in dirs:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -43,8 +44,8 @@ def main(out, windows, note, dirs):
     for k, cs in tot.items():
         e = {}
         for cn, (s, n) in cs.items():
-            e[cn + unit(cn)] = round(s / windows, 1)
-            e["launches_per_window"] = round(n / windows, 3)
+            e[cn + unit(cn)] = round(s / windows / frac, 1)
+            e["launches_per_window"] = round(n / windows / frac, 3)
         per_win[k] = e
     for k, cs in grid.items():
         e = {}
@@ -54,7 +55,7 @@ def main(out, windows, note, dirs):
         by_grid[k] = e
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import csrc_files, csrc_hash   # the sources these kernels were compiled from: bench.py ignores the file once one of them changes
-    doc = {"note": note, "csrc_hash": csrc_hash(), "csrc_files": csrc_files(per_win.keys()), "windows_in_trace": windows,
+    doc = {"note": note, "window_fraction_traced": frac, "csrc_hash": csrc_hash(), "csrc_files": csrc_files(per_win.keys()), "windows_in_trace": windows,
            "kernels_per_window": per_win, "by_grid_per_launch": by_grid}
     if any("FETCH_SIZE_KB" in e and "WRITE_SIZE_KB" in e for e in per_win.values()):
         gb = lambda e: (2 * e.get("FETCH_SIZE_KB", 0.0) + e.get("WRITE_SIZE_KB", 0.0)) * 1024 / 1e9
