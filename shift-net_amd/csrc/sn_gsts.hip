@@ -51,6 +51,11 @@ __global__ void gather_kernel(const UnitK U, const int8_t* offs, bf16_t* u, cons
 // config 3 (C = 80: one workgroup per CU) -- the fourth register-prefetch pipeline on this path that lost to plain occupancy.  So was a
 // ROW-WALKING build (strip of 32 columns, ring of 20 input rows in LDS: 1.56 instead of 4.5 window bytes per output byte): 11.3 vs
 // 10.05 ms -- the kernel is not bound by the bytes it loads either.
+// Round 5: channel pairs that share a displacement (8 of the 24 offsets of C = 64, 16 of C = 80 carry two channels) read as ONE 4-byte LDS word
+// per tap with two v_dot2c (weight words with one non-zero half) -- 25 % / 40 % fewer LDS reads, bit-identical -- measured SLOWER, interleaved
+// against the round-4 library on one device (tools/p1_ab.py): 374.8 vs 323.2 us (C = 64, 20 x 360 x 640), 1761.6 vs 1592.7 us (C = 80, 52 x 360 x
+// 640): the wave-uniform pair test splits the unrolled tap loop into two bodies and the scheduler loses its order of LDS reads and dot
+// products.  The sixth rebuild of this kernel that lost.
 template <int CH, int PP>
 __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const XcdTiles G, const int8_t* __restrict__ offs,
                                                       const uint32_t* __restrict__ w1d, bf16_t* hw) {
@@ -105,36 +110,17 @@ __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const Xcd
             for (int kc = pc0; kc < pc0 + np; ++kc) {
                 float o[8];
 #pragma unroll
-                for (int j = 0; j < 8; j += 2) {
+                for (int j = 0; j < 8; ++j) {
                     const int k = kc * 8 + j;
                     const int dy = offs[2 * k], dx = offs[2 * k + 1];
                     const char* base = smem + (py + 8 + dy) * ROWP + (px + 8 + dx) * PSB + (k - pc0 * 8) * 2;
-                    float acc = 0.f, acc1 = 0.f;
-                    // Channels 2i, 2i + 1 that share their displacement (the 8 inner offsets of C = 64 carry two channels each, the 16 outer
-                    // ones of C = 80 too: spatial_shift2's n1 / n2, gshift_deblur1.py:470-503) are ONE 4-byte LDS word per tap: one ds_read_b32
-                    // and two v_dot2c, each with a weight word that has one non-zero half (bf16 weight low / high), instead of two
-                    // ds_read_u16 -- the kernel is bound by its LDS instruction count (288 / 360 two-byte reads per output pixel).  Wave-uniform.
-                    if (offs[2 * k + 2] == dy && offs[2 * k + 3] == dx) {
+                    float acc = 0.f;
 #pragma unroll
-                        for (int ty = 0; ty < 3; ++ty)
+                    for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
-                            for (int tx = 0; tx < 3; ++tx) {
-                                const uint32_t v2 = *(const uint32_t*)(base + ty * ROWP + tx * PSB);
-                                acc = dot2bf(v2, w1d[k * 9 + ty * 3 + tx], acc);                        // (x_k, x_k+1) . (w_k, 0)
-                                acc1 = dot2bf(v2, w1d[(k + 1) * 9 + ty * 3 + tx] << 16, acc1);          // (x_k, x_k+1) . (0, w_k+1)
-                            }
-                    } else {
-                        const int dy1 = offs[2 * k + 2], dx1 = offs[2 * k + 3];
-                        const char* base1 = smem + (py + 8 + dy1) * ROWP + (px + 8 + dx1) * PSB + (k + 1 - pc0 * 8) * 2;
-#pragma unroll
-                        for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-                            for (int tx = 0; tx < 3; ++tx) {
-                                acc = dot2bf((uint32_t)(*(const bf16_t*)(base + ty * ROWP + tx * PSB)), w1d[k * 9 + ty * 3 + tx], acc);
-                                acc1 = dot2bf((uint32_t)(*(const bf16_t*)(base1 + ty * ROWP + tx * PSB)), w1d[(k + 1) * 9 + ty * 3 + tx], acc1);
-                            }
-                    }
-                    o[j] = acc; o[j + 1] = acc1;
+                        for (int tx = 0; tx < 3; ++tx)
+                            acc = dot2bf((uint32_t)(*(const bf16_t*)(base + ty * ROWP + tx * PSB)), w1d[k * 9 + ty * 3 + tx], acc);
+                    o[j] = acc;
                 }
                 *(uint4*)(hw + (((size_t)t * U.h + oy) * U.w + ox) * CH + kc * 8) = pack8(o);
             }
@@ -176,23 +162,16 @@ __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const Xcd
 // waves-per-SIMD target: see the register-budget note in sn_conv.hip (91 VGPRs + 80 AGPRs = 2 waves without it; 148 / 152 = 3 waves)
 // NT = N-tiles (16 pixels) per wave = 4: 148 / 152 registers, 3 waves per SIMD, the shortcut is loaded after the MFMAs.  (NT = 2 with the
 // shortcut prefetched, 6 / 4 waves per SIMD, measured 22.6 vs 20.5 ms per window for C = 64 and 69.0 vs 71.2 ms for C = 80 in round 2.)
+// Round 5: the shortcut operand by LDS-DMA (global_load_lds_dwordx4, no VGPRs) issued BEFORE the g2 loads, so that a wave waits for memory once per
+// chunk instead of twice (32 KB of LDS per workgroup, still three workgroups per CU, 150 VGPRs): 353.3 / 370.3 us against 354.2 / 368.5 us for
+// this kernel (CAB1 / CAB2, C = 64, 20 x 360 x 640, interleaved on one device) -- no difference: the kernel streams at its rate of 5.0 - 5.2 TB/s
+// whether the second latency is exposed or not.  Not kept.
 #define SN_K4_NT 4
-#ifndef SN_K4_GLDS       // measurement builds: 0 = the shortcut through registers after the MFMAs (round 4)
-#define SN_K4_GLDS 1
-#endif
-// Round 5: the shortcut operand travels global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs), issued BEFORE the g2 loads, so both
-// streams of a wave are in flight together and the wave waits for memory once per chunk instead of twice (g2 loads -> MFMAs -> shortcut loads ->
-// stores); the register-prefetch form of the same idea cost the third wave per SIMD (NT = 2 experiment above).  The DMA's LDS image is
-// lane-linear (wave-uniform base + lane x 16 bytes), exactly what the lane reads back after the MFMAs.  C = 64 (an even number of M-tiles: the
-// lane's 8 MT bytes are whole 16-byte pieces); C = 80 keeps the register path.  32 KB of LDS per workgroup, three workgroups per CU as before.
-template <int C> constexpr bool sn_k4_glds() { return SN_K4_GLDS && ((C / 16) % 2 == 0); }
 template <int C, int NT>
 __global__ __launch_bounds__(256, 3)
 void scale_gemm_res_kernel(const UnitK U, const bf16_t* __restrict__ g2, const float* __restrict__ ca,
                            const uint4* __restrict__ wfrag, const float* __restrict__ bias, bf16_t* y, const int nchunk, const int nfr) {
     constexpr int CH = C / 2, KS = (C + 31) / 32, MT = C / 16;
-    constexpr bool GLDS = sn_k4_glds<C>();
-    extern __shared__ __attribute__((aligned(16))) char k4_lds[];
     const int lane = threadIdx.x & 63, wv = wave_id(), g = lane >> 4, p = lane & 15;
     // Workgroup -> (pixel chunk, frame) with the FRAMES of one chunk back to back on ONE XCD (workgroup b runs on XCD b % 8): the rolled shortcut
     // of a CAB2 is the upper half-channels of frame t-1 and the lower ones of frame t, i.e. 64 / 80-byte halves of 128-byte lines whose other half
@@ -207,18 +186,6 @@ void scale_gemm_res_kernel(const UnitK U, const bf16_t* __restrict__ g2, const f
     const int c0 = g * 4 * MT;                   // lane (g,p) owns channels [c0, c0 + 4 MT): one contiguous 8*MT-byte run of the shortcut and of y
     const bf16_t* const sbase = c0 < CH ? sl.p0 + c0 : sl.p1 + c0 - CH;
     const int sstr = c0 < CH ? sl.s0 : sl.s1;                                  // pixel stride of this lane's half (C, or C/2 for a halo half-frame)
-    char* const my_lds = k4_lds + wv * (NT * (MT / 2) * 1024);                 // this wave's shortcut image: [n][m pair][lane] x 16 bytes
-    if constexpr (GLDS) {
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int i = ibase + n * 16 + p, ii = i < hw ? i : hw - 1;        // (clamped: the row of a pixel beyond the frame is never stored)
-            const bf16_t* sp = sbase + (size_t)ii * sstr;
-#pragma unroll
-            for (int m = 0; m + 1 < MT; m += 2)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sp + m * 4),
-                                                 (__attribute__((address_space(3))) void*)(my_lds + (n * (MT / 2) + (m >> 1)) * 1024), 16, 0, 0);
-        }
-    }
     bf16x8_t B[NT][KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -254,23 +221,14 @@ void scale_gemm_res_kernel(const UnitK U, const bf16_t* __restrict__ g2, const f
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[m][n] = mfma16(a, B[n][s], acc[m][n]);
         }
-    if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the DMA writes have landed (they were issued before the g2 loads)
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int i = ibase + n * 16 + p;
         if (i >= hw) continue;
         uint32_t sc[2 * MT], o[2 * MT];
         const bf16_t* sp = sbase + (size_t)i * sstr;
-        if constexpr (GLDS) {
 #pragma unroll
-            for (int m = 0; m + 1 < MT; m += 2) {
-                const uint4 q = *(const uint4*)(my_lds + (n * (MT / 2) + (m >> 1)) * 1024 + lane * 16);
-                sc[2 * m] = q.x; sc[2 * m + 1] = q.y; sc[2 * m + 2] = q.z; sc[2 * m + 3] = q.w;
-            }
-        } else {
-#pragma unroll
-            for (int m = 0; m + 1 < MT; m += 2) { const uint4 q = *(const uint4*)(sp + m * 4); sc[2 * m] = q.x; sc[2 * m + 1] = q.y; sc[2 * m + 2] = q.z; sc[2 * m + 3] = q.w; }
-        }
+        for (int m = 0; m + 1 < MT; m += 2) { const uint4 q = *(const uint4*)(sp + m * 4); sc[2 * m] = q.x; sc[2 * m + 1] = q.y; sc[2 * m + 2] = q.z; sc[2 * m + 3] = q.w; }
         if (MT & 1) { const uint2 q = *(const uint2*)(sp + (MT - 1) * 4); sc[2 * MT - 2] = q.x; sc[2 * MT - 1] = q.y; }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -346,7 +304,7 @@ int cab_phase2(const sn_unit_src* s, const void* g2, const float* ca, const void
     SN_FRAME_RANGE(s, t0, nt);
     const int nchunk = (npx + PXWG - 1) / PXWG;
     dim3 grid((unsigned)(8 * ((nchunk * nt + 7) / 8)));
-    if (s->C == 64) hipLaunchKernelGGL((scale_gemm_res_kernel<64, SN_K4_NT>), grid, dim3(256), sn_k4_glds<64>() ? 4 * SN_K4_NT * 2 * 1024 : 0, (hipStream_t)stream, to_k(s), (const bf16_t*)g2, ca, (const uint4*)wfrag, bias, (bf16_t*)y, nchunk, nt);
+    if (s->C == 64) hipLaunchKernelGGL((scale_gemm_res_kernel<64, SN_K4_NT>), grid, dim3(256), 0, (hipStream_t)stream, to_k(s), (const bf16_t*)g2, ca, (const uint4*)wfrag, bias, (bf16_t*)y, nchunk, nt);
     else hipLaunchKernelGGL((scale_gemm_res_kernel<80, SN_K4_NT>), grid, dim3(256), 0, (hipStream_t)stream, to_k(s), (const bf16_t*)g2, ca, (const uint4*)wfrag, bias, (bf16_t*)y, nchunk, nt);
     return sn_check_launch();
 }
