@@ -361,9 +361,9 @@ def main():
                 gather_ms.append((e0, e1))
         outs = []
         for a, b, c, d in quads:
-            xq = win if len(quads) == 1 else win[:, :, a:b, c:d].contiguous()
+            xq = win[:, :, a:b, c:d].contiguous() if args.quadrants else win
             outs.append(net(xq.unsqueeze(0), sigma_map) if denoise else net(xq.unsqueeze(0)))
-        return outs[0] if len(quads) == 1 else outs
+        return outs if args.quadrants else outs[0]
 
     def barrier():
         if world > 1:
