@@ -118,7 +118,7 @@ def symbol_key(sym):
     if m:
         return "sn_ln_gemm_gate<cab2>" if m.group(1) == "true" else "sn_ln_gemm_gate<cab1>"
     for pat, key in (("scale_gemm_res_kernel", "sn_cab_phase2"), ("shiftconv_kernel", "sn_gsts_shiftconv"), ("grp5p_gemm_gate_kernel", "sn_grp5_gemm_gate"),
-                     ("dw5m_gemm_gate_kernel", "sn_dw5m_gemm_gate"), ("ca_mlp_kernel", "sn_ca_mlp"), ("cab_ca", "sn_cab_ca"), ("temporal_roll", "sn_temporal_roll"),
+                     ("dw5m_gemm_gate_kernel", "sn_dw5m_gemm_gate"), ("ca_mlp_kernel", "sn_ca_mlp"), ("cab_ca", "sn_cab_ca"), ("gather_kernel", "sn_temporal_roll"),
                      ("ingest_kernel", "sn_ingest")):
         if pat in s:
             return key
@@ -148,6 +148,8 @@ def kernel_alg_bytes(fn, meta):
         p1 = px * (2.5 * c if mode else 2 * c)                                       # phase 1: read x (+ hw), write g2 (or g1)
         return {"sn_gsts_shiftconv": px * c, "sn_gsts_cab2_phase2": px * 3 * c, "sn_cab1_phase2": px * 3 * c, "sn_ln_gemm_gate": p1,
                 "sn_dw5m_gemm_gate": px * 2 * c, "sn_grp5_gemm_gate": px * 2 * c, "sn_gsts_cab2_phase1": p1, "sn_cab1_phase1": p1}.get(fn, 0)
+    if meta and meta[0] == "roll":             # Shift_CAB's temporal roll: one read, one write
+        return 2 * meta[1] * meta[2] * meta[3] * meta[4] * 2
     if meta and meta[0] == "conv":
         _, T, ho, wo, cin, cs_out, k, stride, in_mode, out_mode = meta
         pin = T * ho * wo * stride * stride / (4 if in_mode == 1 else 1)

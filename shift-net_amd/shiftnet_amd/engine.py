@@ -390,6 +390,7 @@ class Engine:
         assert cs == x.c, "Shift_CAB widths (24, 80) are stored unpadded"
         y = self._new(T, h, w, cs)
         mode = 2 if reverse else 1
+        self._meta = ("roll", T, h, w, cs)              # (not a kernel of a GSTS unit: bench.py's unit figure must not inherit the previous launch's record)
         for wrap, halo, t0, nt in self._split_pieces(x, mode, False):
             s = self._unit_src(x, mode, wrap=wrap, halo=halo, t0=t0, nt=nt)
             self._call("sn_temporal_roll", "sn_temporal_roll", C.byref(s), y.data_ptr(), self._stream())

@@ -314,6 +314,48 @@ def C_byref(s):
     return ctypes.byref(s)
 
 
+@pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_deblur1", "gshift_denoise1"])
+def test_phase1_results_do_not_depend_on_launch_geometry(name, engines):
+    """csrc/sn_phase1r.hip: pool rows are per (frame, strip, block of 8 image rows) and every walk computes a row from the same operands in the
+    same order, so g2, the partial channel sums and the squeeze-excite scale are BIT-IDENTICAL whatever the launch looks like: the library's
+    own team size, teams of 1 / 2 / 8 workgroups (other chunk boundaries, other walks per workgroup), and the frames launched in three
+    separate frame ranges -- what a temporally split window, the halo-overlap pieces and the frame wavefront rely on."""
+    from shiftnet_amd import lib as L
+    eng, sd = engines(name)
+    V = O.VARIANTS[name]
+    C_, T, h, w = V.c1, 5, 45, 150                                  # 3 strips, 6 row blocks (the last one short), a ragged last frame block for teams of 2 / 8
+    x = torch.from_numpy(synth.unit_noise((T, h, w, C_), seed=17)).to(torch.bfloat16).to(DEV)
+    hwb = torch.from_numpy(synth.unit_noise((T, h, w, C_ // 2), seed=18)).to(torch.bfloat16).to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    nblk = eng.lib.sn_phase1_pool_blocks(T, h, w)
+    for mode, unit in ((0, "encoder_level1.1."), (2, "encoder_level1_1.0.")):
+        pre = "stage1.decoder_level1." + unit
+        p1, q = eng.P.units[pre]["p1r"], eng.P.cas[pre + "ca2"]
+        ca1 = None
+        if V.denoise:                                               # the inner scale of the denoisers' second pass: any fixed values do
+            ca1 = (0.5 + torch.rand(T, C_, device=DEV)).float()
+
+        def run(team, ranges):
+            g2 = torch.full((T, h, w, C_), float("nan"), dtype=torch.bfloat16, device=DEV)
+            pool = torch.full((T, nblk, C_), float("nan"), dtype=torch.float32, device=DEV)
+            ca = torch.full((T, C_), float("nan"), dtype=torch.float32, device=DEV)
+            tickets = torch.zeros((T,), dtype=torch.int32, device=DEV)
+            for t0, nt in ranges:
+                src = L.UnitSrc(x.data_ptr(), T, h, w, C_, mode, 1 if (mode and V.wrap) else 0, None, t0, nt)
+                se = L.SeFold(q["wa"].data_ptr(), q["wb"].data_ptr(), q["c"], q["cr"], tickets.data_ptr(), ca.data_ptr(), None)
+                opt = L.Phase1Opts(ca1.data_ptr() if ca1 is not None else None, 0, team)
+                L.check(L.cab_phase1(eng.lib, src, hwb.data_ptr() if mode else None, p1["desc"], g2.data_ptr(), pool.data_ptr(), st, se, opt), "phase 1")
+            torch.cuda.synchronize()
+            assert int(tickets.abs().sum()) == 0
+            return g2, pool, ca
+        ref = run(0, [(0, 0)])
+        assert torch.isfinite(ref[0].float()).all() and torch.isfinite(ref[1]).all() and torch.isfinite(ref[2]).all()
+        for team, ranges in ((1, [(0, 0)]), (2, [(0, 0)]), (8, [(0, 0)]), (0, [(1, 3), (0, 1), (4, 1)]), (1, [(3, 2), (0, 3)])):
+            got = run(team, ranges)
+            for a, b, what in zip(ref, got, ("g2", "pool", "ca")):
+                assert torch.equal(a, b), (name, mode, team, ranges, what)
+
+
 @pytest.mark.parametrize("name,T,h,w", [("gshift_deblur2", 3, 184, 328), ("gshift_deblur2", 3, 40, 200), ("gshift_deblur1", 3, 184, 328),
                                         ("gshift_deblur1", 3, 40, 200), ("gshift_denoise1", 3, 136, 224)])
 def test_unit_parity_at_production_tile_counts(name, T, h, w, engines):
