@@ -56,6 +56,10 @@ __global__ void gather_kernel(const UnitK U, const int8_t* offs, bf16_t* u, cons
 // against the round-4 library on one device (tools/p1_ab.py): 374.8 vs 323.2 us (C = 64, 20 x 360 x 640), 1761.6 vs 1592.7 us (C = 80, 52 x 360 x
 // 640): the wave-uniform pair test splits the unrolled tap loop into two bodies and the scheduler loses its order of LDS reads and dot
 // products.  The sixth rebuild of this kernel that lost.
+// And the seventh: the channel chunks of a tile split over TWO neighbouring workgroups (C = 64: 2 + 2 chunks, 46 KB of LDS, 76 VGPRs, three workgroups per
+// CU instead of two; C = 80: 3 + 2 chunks, 63 KB, two instead of one), both halves adjacent in the XCD-aware walk so that the second finds the window in
+// L2: 491.7 vs 317.6 us (C = 64), 2636.6 vs 1586.1 us (C = 80, 52 x 360 x 640), 1823.9 vs 1077.8 us (1080p): the loader then takes 32 / 48 bytes of every
+// 64- / 80-byte pixel record -- half-used sectors and twice the staging index work per output byte cost far more than the extra residency buys.
 template <int CH, int PP>
 __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const XcdTiles G, const int8_t* __restrict__ offs,
                                                       const uint32_t* __restrict__ w1d, bf16_t* hw) {
@@ -165,10 +169,13 @@ __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const Xcd
 // Round 5: the shortcut operand by LDS-DMA (global_load_lds_dwordx4, no VGPRs) issued BEFORE the g2 loads, so that a wave waits for memory once per
 // chunk instead of twice (32 KB of LDS per workgroup, still three workgroups per CU, 150 VGPRs): 353.3 / 370.3 us against 354.2 / 368.5 us for
 // this kernel (CAB1 / CAB2, C = 64, 20 x 360 x 640, interleaved on one device) -- no difference: the kernel streams at its rate of 5.0 - 5.2 TB/s
-// whether the second latency is exposed or not.  Not kept.
+// whether the second latency is exposed or not.  Not kept.  NT = 2 WITHOUT the prefetch (88 VGPRs, five waves per SIMD instead of three, twice the
+// weight-fragment fetches per pixel): 363.2 / 389.5 us against 352.4 / 369.1 us (C = 64), 1279.8 / 1368.7 against 1206.6 / 1280.7 (C = 80): slower.
+#ifndef SN_K4_NT         // (measurement builds: -DSN_K4_NT=2)
 #define SN_K4_NT 4
+#endif
 template <int C, int NT>
-__global__ __launch_bounds__(256, 3)
+__global__ __launch_bounds__(256, NT == 4 ? 3 : 5)
 void scale_gemm_res_kernel(const UnitK U, const bf16_t* __restrict__ g2, const float* __restrict__ ca,
                            const uint4* __restrict__ wfrag, const float* __restrict__ bias, bf16_t* y, const int nchunk, const int nfr) {
     constexpr int CH = C / 2, KS = (C + 31) / 32, MT = C / 16;

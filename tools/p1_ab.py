@@ -40,6 +40,9 @@ def main():
             libs[f[7:-3]] = (C.CDLL(os.path.join(DEV, f)), False)
     k0libs = {"r04": libs["r04"][0]} if "r04" in libs else {}
     k0libs["cur"] = C.CDLL(L.LIB_PATH)
+    for f in sorted(os.listdir(DEV)):          # whole-library variants (build.py build(out=..., flags=[...])): K0 / K4 rows
+        if f.startswith("libshiftnet_") and f.endswith(".so") and f != "libshiftnet_r04.so":
+            k0libs[f[12:-3]] = C.CDLL(os.path.join(DEV, f))
     for lib in k0libs.values():
         lib.sn_gsts_shiftconv.argtypes = [C.POINTER(L.UnitSrc), vp, vp, vp, vp]
         lib.sn_gsts_cab2_phase2.argtypes = [C.POINTER(L.UnitSrc), vp, vp, vp, vp, vp, vp]
