@@ -316,6 +316,18 @@ def test_cli_refuses_clip_parallel_modes_it_cannot_run():
         assert e.value.code == 2
 
 
+def test_cli_spawn_stops_all_ranks_when_one_fails():
+    """cli._spawn_ranks (the `--gpus N` launcher of the drop-in CLIs): ranks are started as `python -m shiftnet_amd.cli <variant> ...` whatever
+    program called it (pytest here), and a rank that exits non-zero ends the launch at once -- its siblings are terminated instead of waiting in
+    a collective until the process-group timeout.  An unknown variant makes every rank fail at start-up: no GPU needed."""
+    import time
+    from shiftnet_amd import cli
+    t0 = time.time()
+    with pytest.raises(SystemExit) as e:
+        cli._spawn_ranks("no_such_variant", 2, ["--synthetic", "32", "32", "12", "--one_len", "4"])
+    assert "exited with codes" in str(e.value) and time.time() - t0 < 120
+
+
 def test_bench_refuses_fewer_gpus_than_asked():
     """`bench.py --gpus N` must never print an N-GPU line from fewer devices (this container has none)."""
     import subprocess
