@@ -97,7 +97,7 @@ __device__ __forceinline__ uint32_t lane_next(uint32_t v) { return (uint32_t)__b
 // how many LDS fragment reads the MFMA loops keep in flight ahead of their consumers (A: first 1x1, B: RepConv, B2: second 1x1)
 // measurement builds only (tools/p1r_variants.py): switch off parts of the roles (results are wrong) to see which one paces the step
 //   1: stagers skip the LayerNorm / LDS staging   2: stagers skip the global loads   4: stagers skip the g2 stores
-//   8: A waves idle   16: B waves skip the second 1x1   32: B waves skip the RepConv
+//   8: A waves idle   16: B waves skip the second 1x1   32: B waves skip the RepConv   64: SimpleGate2 without exp / rcp
 #ifndef P1R_SKIP
 #define P1R_SKIP 0
 #endif
@@ -613,7 +613,8 @@ __global__ __launch_bounds__((p1r_threads<C, HW, ICA>())) void cab_phase1r_kerne
                         float v[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {                         // b1 * sigmoid(b2); the gate rows carry -log2(e) (prep.pack_phase1r)
-                            v[r] = c[n][0][r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(c[n][1][r]));
+                            if (P1R_SKIP & 64) v[r] = c[n][0][r] * c[n][1][r];               // (measurement: the step without its 32 transcendentals)
+                            else v[r] = c[n][0][r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(c[n][1][r]));
                             psum[r] = fmaf(v[r], own[n0 + n], psum[r]);
                         }
                         *(uint2*)(os + (n0 + n) * 16 * PSO) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));

@@ -19,7 +19,7 @@ VARIANTS = {
     "barriers_only": ["-DP1R_SKIP=63"],
     "noAV": ["-DP1R_AV=0"], "noBV": ["-DP1R_BV=0"], "noAVBV": ["-DP1R_AV=0", "-DP1R_BV=0"], "d86": ["-DP1R_DB=8", "-DP1R_DA=6"], "d22": ["-DP1R_DB=2", "-DP1R_DA=2"],
     "AV6": ["-DP1R_AV=6"], "BV2": ["-DP1R_BV=2"],
-    "da2": ["-DP1R_DA=2"], "nsw4": ["-DP1R_NSW64=4"], "no_mem": ["-DP1R_SKIP=6"],
+    "da2": ["-DP1R_DA=2"], "nsw4": ["-DP1R_NSW64=4"], "no_mem": ["-DP1R_SKIP=6"], "no_sigmoid": ["-DP1R_SKIP=64"], "nsw2": ["-DP1R_NSW64=2"],
     "prio000": ["-DP1R_PRIO_S=0", "-DP1R_PRIO_B=0", "-DP1R_PRIO_A=0"], "prio300": ["-DP1R_PRIO_S=3", "-DP1R_PRIO_B=0", "-DP1R_PRIO_A=0"],
     "prio311": ["-DP1R_PRIO_S=3", "-DP1R_PRIO_B=1", "-DP1R_PRIO_A=1"], "prio312": ["-DP1R_PRIO_S=3", "-DP1R_PRIO_B=1", "-DP1R_PRIO_A=2"],
     "prio210": ["-DP1R_PRIO_S=2", "-DP1R_PRIO_B=1", "-DP1R_PRIO_A=0"], "prio231": ["-DP1R_PRIO_S=2", "-DP1R_PRIO_B=3", "-DP1R_PRIO_A=1"],
