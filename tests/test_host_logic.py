@@ -32,13 +32,13 @@ def test_library_exports_every_declared_symbol():
     import subprocess, tempfile
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "sz.c")
-        open(src, "w").write('#include <stdio.h>\n#include "shiftnet_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(sn_conv_desc), '
-                             'sizeof(sn32_conv_desc), sizeof(sn_unit_src), sizeof(sn_phase1_weights), sizeof(sn_se_fold));return 0;}\n')
+        open(src, "w").write('#include <stdio.h>\n#include "shiftnet_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(sn_conv_desc), '
+                             'sizeof(sn32_conv_desc), sizeof(sn_unit_src), sizeof(sn_phase1_weights), sizeof(sn_se_fold), sizeof(sn_phase1_opts));return 0;}\n')
         exe = os.path.join(td, "sz")
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
         sizes = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     assert sizes == [ctypes.sizeof(L.ConvDesc), ctypes.sizeof(L.Conv32Desc), ctypes.sizeof(L.UnitSrc), ctypes.sizeof(L.Phase1Weights),
-                     ctypes.sizeof(L.SeFold)], sizes
+                     ctypes.sizeof(L.SeFold), ctypes.sizeof(L.Phase1Opts)], sizes
     # argument validation is host side and must not need a GPU
     assert lib.sn_conv2d(None, None) == -22
     d = L.ConvDesc(); d.stride, d.mt, d.n_in, d.cs_in, d.h_out, d.w_out = 1, 1, 1, 16, 720, 1280
