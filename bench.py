@@ -552,6 +552,9 @@ def main():
                                    "traffic": (round(sum((2 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) for v in pmc.values()) * 1024 / 1e9, 1) if pmc else None),
                                    "traffic_note": "GB per window, all of this library's kernels: " + pmc_note},
             "kernels": kernels,
+            # high-water mark of this rank's device allocations over warm-up, timed steps and the profiling step (PyTorch caching allocator: every
+            # activation of a window is a torch tensor): how much of the 288 GB a window of this configuration occupies
+            "peak_device_memory_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
         }
         if per_rank is not None:
             result["per_rank"] = per_rank
