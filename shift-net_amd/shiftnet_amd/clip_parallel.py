@@ -38,7 +38,7 @@ def assemble_window(own: torch.Tensor, first_edge: Optional[torch.Tensor], last_
     if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return torch.cat((first_edge, own, last_edge), 0)
     active = world if active is None else active
-    if own.shape[0] < 2:
+    if world > 1 and own.shape[0] < 2:
         raise ValueError("clip-parallel windows need one_len >= 2: the two halo frames of a side come from ONE neighbour rank")
     if all_gather or world == 1:
         send = torch.cat((own[:2], own[-2:]), 0).contiguous()

@@ -548,6 +548,8 @@ class Engine:
     def shift_chain(self, pres: Sequence[str], x: Act) -> Act:
         """Consecutive Encoder_shift_blocks at one level (Encoder2.forward, gshift_deblur1.py:623-637 / gshift_deblur2.py:594-609)."""
         T = x.dims[0]
+        if self.schedule not in ("unit", "frame") or self.frame_group < 1:
+            raise ValueError(f"SN_SCHEDULE={self.schedule!r} / SN_FRAME_GROUP={self.frame_group}: expected unit or frame, and a group of >= 1 frames")
         if self.schedule != "frame" or self.split is not None or T <= self.frame_group:
             for pre in pres:
                 x = self.shift_block(pre, x)
