@@ -325,7 +325,7 @@ def test_cli_spawn_stops_all_ranks_when_one_fails():
     t0 = time.time()
     with pytest.raises(SystemExit) as e:
         cli._spawn_ranks("no_such_variant", 2, ["--synthetic", "32", "32", "12", "--one_len", "4"])
-    assert "exited with codes" in str(e.value) and time.time() - t0 < 120
+    assert "exited with codes" in str(e.value) and time.time() - t0 < 600
 
 
 def test_bench_refuses_fewer_gpus_than_asked():
