@@ -25,6 +25,7 @@ struct ConvK {
     const bf16_t* res; bf16_t* out; int cs_out, out_mode, c_out, nchw_dtype, sc_dtype;
     const void* sc; float* pool; const float* oscale; int oscale_stride; const bf16_t* res2;
     int rh, rw, ps;
+    int lines_len;                   // conv3_fast_kernel<.., STATS>: `out` is the border-line buffer [T][4][lines_len][cs_out] (sn_cab_stats)
     XcdTiles xg;                     // tile walk of conv_mfma_kernel / conv3_fast_kernel (sn_common.h)
     unsigned m_nblk8, m_rw, m_csb, m_cv, m_k;   // ceil(2^24/d) multipliers: integer division by runtime constants without v_div
 };
@@ -296,7 +297,10 @@ __global__ __launch_bounds__(256, sn_conv_waves(MT, TH)) void conv_mfma_kernel(c
 // round-1 attempt on the generic kernel) measured slower -- 16-channel convs 16.5 -> 20.4 ms, 24-channel 15.7 -> 18.2 ms per window of
 // config 2: the prefetch and the loop-carried state take the kernel from 32-48 to 107-155 VGPRs, and at 3.8-5.1 TB/s this kernel
 // hides its load latency through occupancy (6-8 resident workgroups per CU), not through software pipelining.
-template <int MT, int CS, int TH>
+// STATS (sn_cab_stats, pass 1 of the fused CAB of csrc/sn_cabf.hip): same tile, same arithmetic, same per-workgroup channel sums, but the
+// output is NOT stored -- only its first / last rows and columns, bf16-rounded exactly like the stored tensor, into the small line buffer
+// `out` = [T][4][lines_len][cs_out] (row 0, row h-1, column 0, column w-1): everything sn_cab_ca's closed form reads of `mid`.
+template <int MT, int CS, int TH, bool STATS = false>
 __global__ __launch_bounds__(256, sn_conv3_waves(MT, CS)) void conv3_fast_kernel(const ConvK P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TW = 32, RH = TH + 2, RW = TW + 2, NPB = CS / 8;
@@ -485,6 +489,26 @@ __global__ __launch_bounds__(256, sn_conv3_waves(MT, CS)) void conv3_fast_kernel
 #pragma unroll
                     for (int r = 0; r < 4; ++r) psum[m][r] += v[m][r];
             }
+            if constexpr (STATS) {
+                const int nn = wv * NTW + n, row = nn / XB, xb = nn - row * XB;
+                const int oy = oy0 + row, ox = ox0 + xb * 16 + p;
+                bf16_t* const lb = P.out + (size_t)t * 4 * P.lines_len * P.cs_out + c0;
+                bf16_t* tgt[4] = {oy == 0 ? lb + (size_t)ox * P.cs_out : nullptr,
+                                  oy == P.hout - 1 ? lb + ((size_t)P.lines_len + ox) * P.cs_out : nullptr,
+                                  ox == 0 ? lb + ((size_t)2 * P.lines_len + oy) * P.cs_out : nullptr,
+                                  ox == P.wout - 1 ? lb + ((size_t)3 * P.lines_len + oy) * P.cs_out : nullptr};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (!tgt[q]) continue;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        if (c0 + m * 4 < P.cs_out) {
+                            uint2 o; o.x = pack_bf2(v[m][0], v[m][1]); o.y = pack_bf2(v[m][2], v[m][3]);
+                            *(uint2*)(tgt[q] + m * 4) = o;
+                        }
+                }
+                continue;
+            }
             if constexpr (MT == 2 || MT == 4) {
 #pragma unroll
                 for (int m = 0; m < MT; m += 2)
@@ -520,17 +544,17 @@ __global__ __launch_bounds__(256, sn_conv3_waves(MT, CS)) void conv3_fast_kernel
 }
 
 
-template <int MT, int CS>
+template <int MT, int CS, bool STATS = false>
 int launch_conv3_fast(const ConvK& K, int T, hipStream_t st) {
     constexpr int TH = 8, TW = 32, NPB = CS / 8, PS = 16 * sn_lds_slots(NPB);
     ConvK P = K; P.xg = sn_xcd_tiles((K.wout + TW - 1) / TW, (K.hout + TH - 1) / TH, T);
     const dim3 grid = sn_xcd_grid(P.xg);
     const size_t lds = (size_t)(TH + 2) * (TW + 2) * PS + 4 * 16 * MT * sizeof(float);
     if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)conv3_fast_kernel<MT, CS, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv3_fast_kernel<MT, CS, TH, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return SN_ELAUNCH;
     }
-    hipLaunchKernelGGL((conv3_fast_kernel<MT, CS, TH>), grid, dim3(256), lds, st, P);
+    hipLaunchKernelGGL((conv3_fast_kernel<MT, CS, TH, STATS>), grid, dim3(256), lds, st, P);
     return sn_check_launch();
 }
 

@@ -542,14 +542,38 @@ class Engine:
     # soon as its own and one neighbouring group of unit k - 1 are done and a frame's working set moves through many units while it is still in
     # the Infinity Cache.  Results are bit-identical (every kernel honours frame ranges and the pool rows do not depend on them).  Measured:
     # DESIGN.md section 3.3 -- no gain while phase 1 is not bandwidth-bound; SN_SCHEDULE=frame / bench.py --schedule frame keep it one flag away.
+    # "streams" (round 6): the window's frames are cut into stream_groups contiguous frame groups and every group runs ITS chain of launches
+    # (K0 -> phase 1 -> K4 -> phase 1 -> K4, unit after unit) on its own HIP stream; the only cross-stream edges are the one boundary frame a
+    # shifted unit borrows from the neighbouring group (events).  The groups drift out of phase by themselves -- two phase-1 launches cannot
+    # share a CU (131 / 149 KB of LDS each), so the second one waits and from then on its memory-bound K4 runs UNDER the other group's
+    # issue-bound phase 1 (K4 has no LDS and 76 VGPRs: it fits beside phase 1's 12 waves).  Bit-identical to unit-major by construction.
     schedule = os.environ.get("SN_SCHEDULE", "unit")
     frame_group = int(os.environ.get("SN_FRAME_GROUP", "4"))
+    stream_groups = int(os.environ.get("SN_STREAM_GROUPS", "2"))
+    STREAMS_MIN_PXF = 400_000     # frames x pixels of a GROUP below which the streams schedule is not used (launches too small to overlap usefully)
 
     def shift_chain(self, pres: Sequence[str], x: Act) -> Act:
         """Consecutive Encoder_shift_blocks at one level (Encoder2.forward, gshift_deblur1.py:623-637 / gshift_deblur2.py:594-609)."""
         T = x.dims[0]
-        if self.schedule not in ("unit", "frame") or self.frame_group < 1:
-            raise ValueError(f"SN_SCHEDULE={self.schedule!r} / SN_FRAME_GROUP={self.frame_group}: expected unit or frame, and a group of >= 1 frames")
+        if self.schedule not in ("unit", "frame", "streams") or self.frame_group < 1 or self.stream_groups < 1:
+            raise ValueError(f"SN_SCHEDULE={self.schedule!r} / SN_FRAME_GROUP={self.frame_group} / SN_STREAM_GROUPS={self.stream_groups}: "
+                             "expected unit, frame or streams, and groups of >= 1 frames")
+        ev = None
+        if self.prof is not None:             # wall time of the whole chain on the launching stream (bench.py: GSTS time of the window under any schedule)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        y = self._shift_chain(pres, x)
+        if ev is not None:
+            ev[1].record()
+            self.prof.append(("gsts_chain", "gsts_chain", ("chain",) + tuple(x.dims) + (len(pres) * self.V.units,), ev[0], ev[1]))
+        return y
+
+    def _shift_chain(self, pres: Sequence[str], x: Act) -> Act:
+        T = x.dims[0]
+        if self.schedule == "streams" and self.split is None and not torch.cuda.is_current_stream_capturing():
+            ng = min(self.stream_groups, T // 2)
+            if ng >= 2 and (T // ng) * x.dims[1] * x.dims[2] >= self.STREAMS_MIN_PXF:
+                return self._shift_chain_streams(pres, x, ng)
         if self.schedule != "frame" or self.split is not None or T <= self.frame_group:
             for pre in pres:
                 x = self.shift_block(pre, x)
@@ -566,6 +590,51 @@ class Engine:
             y2 = self.naf(pre + "0.", ins[u], 2 if rev else 1, frames=groups[j], bufs=bufs[u][0])
             self.naf(pre + "1.", y2, 0, frames=groups[j], bufs=bufs[u][1])
         return ins[-1]
+
+    STREAM_RING = 3            # buffer sets of the streams schedule: unit u writes set u % STREAM_RING
+
+    def _shift_chain_streams(self, pres: Sequence[str], x: Act, ng: int) -> Act:
+        """The chain with one HIP stream per frame group (see `schedule`).  Group g's stream runs, unit after unit, CAB2 then CAB1 on ITS frames
+        (frame-range launches: every GSTS kernel honours sn_unit_src.t0 / nt and their results do not depend on the range).  stream_plan gives
+        the cross-stream edges: before CAB2 of unit u a group waits for the group that owns the ONE frame its boundary frame borrows from to
+        have finished unit u - 1 (gshift_deblur1.py:504-518), and before it overwrites the ring slot of unit u - STREAM_RING for the groups
+        that borrowed from it there."""
+        T, h, w, c = x.dims
+        units = [(f"{pre}{UNIT_NAMES[i]}.", i % 2 == 1) for pre in pres for i in range(self.V.units)]
+        R = min(self.STREAM_RING, max(len(units), 2))
+        groups, plan = stream_plan([rev for _, rev in units], T, ng, self.V.wrap, R)
+        if getattr(self, "_gstreams", None) is None or len(self._gstreams) < ng:
+            self._gstreams = [torch.cuda.Stream(self.dev) for _ in range(ng)]
+        streams = self._gstreams[:ng]
+        main = torch.cuda.current_stream(self.dev)
+        sets = [(self.naf_buffers(T, h, w, c, 1), self.naf_buffers(T, h, w, c, 0)) for _ in range(R)]
+        if self._tickets is None and self._fused_phase1(T) and self.fold_se:      # allocated on the launching stream, not on a group's
+            self._tickets = torch.zeros((self.MAX_TICKETS,), dtype=torch.int32, device=self.dev)
+        self._guard_ptr()
+        ready = main.record_event()
+        done: List[List[Optional[torch.cuda.Event]]] = [[None] * ng for _ in units]      # unit u's output frames of group g are written
+        cab2: List[List[Optional[torch.cuda.Event]]] = [[None] * ng for _ in units]      # group g no longer reads unit u's input
+        cur = x
+        for u, (pre, rev) in enumerate(units):
+            b2, b1 = sets[u % R]
+            for g, fr in enumerate(groups):
+                raw, war = plan[u][g]
+                with torch.cuda.stream(streams[g]):
+                    s = streams[g]
+                    if u == 0:
+                        s.wait_event(ready)
+                    for uu, gg in raw:
+                        s.wait_event(done[uu][gg])
+                    for uu, gg in war:
+                        s.wait_event(cab2[uu][gg])
+                    y2 = self.naf(pre + "0.", cur, 2 if rev else 1, frames=fr, bufs=b2)
+                    cab2[u][g] = s.record_event()
+                    self.naf(pre + "1.", y2, 0, frames=fr, bufs=b1)
+                    done[u][g] = s.record_event()
+            cur = Act(b1["y"], c)
+        for g in range(ng):
+            main.wait_event(done[-1][g])
+        return cur
 
     def down(self, pre: str, x: Act) -> Act:
         """DownSample (gshift_deblur1.py:330-340 / gshift_denoise1.py:356-365)."""
@@ -816,6 +885,40 @@ def wavefront_order(revs: Sequence[bool], T: int, G: int, circular: bool) -> Lis
             progressed = True
         assert progressed, "frame wavefront: dependency cycle"
     return order
+
+
+def stream_plan(revs: Sequence[bool], T: int, ng: int, circular: bool, ring: int):
+    """Frame groups and cross-stream edges of the streams schedule (Engine._shift_chain_streams).  Returns (groups, plan): groups[g] = (t0, nt),
+    ng contiguous ranges as equal as possible; plan[u][g] = (raw, war), lists of (unit, group) whose events group g's stream waits for before it
+    launches unit u.  raw: the group that owns the ONE frame g's boundary frame borrows from -- frame t0 - 1 for a forward unit, t0 + nt for a
+    reverse one (gshift_deblur1.py:504-518), wrapped on the ring (gshift_deblur2.py:504-505), nobody when that frame does not exist (kept
+    boundary) -- must have WRITTEN unit u - 1's output.  war: unit u overwrites ring slot u % ring, last used by unit u - ring, whose output the
+    groups that borrow from g were still READING in CAB2 of unit u - ring + 1.  Same-group edges are stream order.  Pure host logic
+    (tests/test_host_logic.py replays every plan against the dependency rule)."""
+    assert ng >= 1 and T >= ng and ring >= 2
+    bounds = [T * j // ng for j in range(ng + 1)]
+    groups = [(bounds[j], bounds[j + 1] - bounds[j]) for j in range(ng)]
+
+    def lender(u: int, g: int) -> Optional[int]:
+        t0, nt = groups[g]
+        tb = t0 + nt if revs[u] else t0 - 1
+        if tb < 0 or tb >= T:
+            if not circular:
+                return None
+            tb %= T
+        o = max(j for j in range(ng) if bounds[j] <= tb)
+        return None if o == g else o
+    plan = []
+    for u in range(len(revs)):
+        row = []
+        for g in range(ng):
+            ln = lender(u, g)
+            raw = [(u - 1, ln)] if (u > 0 and ln is not None) else []
+            uu = u - ring + 1
+            war = [(uu, gg) for gg in range(ng) if gg != g and lender(uu, gg) == g] if uu >= 1 else []
+            row.append((raw, war))
+        plan.append(row)
+    return groups, plan
 
 
 def make_engine(V: Variant, sd: Dict[str, torch.Tensor], device: torch.device, dtype: torch.dtype):

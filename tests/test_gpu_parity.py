@@ -387,6 +387,8 @@ def test_frame_wavefront_schedule_is_bit_identical(name, G, engines):
     b = wave.stage1(act(to_dev(x0), V.c0)).t
     torch.cuda.synchronize()
     assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+    with torch.no_grad():                                       # ... and against the CPU oracle, at stage 1's own tolerance (test_unet_and_stage1)
+        check(f"stage1_frame_wavefront_{name}_G{G}", to_cpu(b, V.c0), O.stage1(sd, x0, V), 4e-2)
     # ... and the launch order really was a wavefront: the second unit started before the first one had finished
     order = []
     orig = wave.naf
@@ -395,6 +397,37 @@ def test_frame_wavefront_schedule_is_bit_identical(name, G, engines):
     first = [i for i, (pre, fr) in enumerate(order) if pre == "stage1.decoder_level1.encoder_level1_1.0."][0]      # second unit's first launch
     last0 = [i for i, (pre, fr) in enumerate(order) if pre == "stage1.decoder_level1.encoder_level1.1."][-1]       # first unit's last launch
     assert first < last0 and all(fr is not None for _, fr in order)
+
+
+@pytest.mark.parametrize("name,ng", [("gshift_deblur2", 2), ("gshift_deblur2", 3), ("gshift_deblur1", 2), ("gshift_denoise1", 3), ("gshift_denoise2", 2)])
+def test_streams_schedule_is_bit_identical_and_matches_the_oracle(name, ng, engines):
+    """Engine._shift_chain_streams (SN_SCHEDULE=streams): every frame group runs its chain of GSTS launches on its own HIP stream, ordered against
+    the neighbouring group only by the events of engine.stream_plan (one borrowed boundary frame per shifted unit; a ring of three buffer sets).
+    The whole stage 1 must be bit-identical to the unit-major order on one stream AND within stage 1's tolerance of the CPU oracle; repeated, with
+    uneven groups of T = 7, for the ring (deblur2), the kept boundary and the denoisers' two passes."""
+    eng, sd = engines(name)
+    V = O.VARIANTS[name]
+    par = _sibling_engine(eng, schedule="streams", stream_groups=ng, STREAMS_MIN_PXF=0)
+    x0 = bf(torch.from_numpy(synth.unit_noise((7, V.c0, 24, 40), seed=95)))
+    a = eng.stage1(act(to_dev(x0), V.c0)).t
+    launches = []
+    orig = par._shift_chain_streams
+    par._shift_chain_streams = lambda pres, x, n: (launches.append(n), orig(pres, x, n))[1]
+    for rep in range(3):
+        b = par.stage1(act(to_dev(x0), V.c0)).t
+        torch.cuda.synchronize()
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b), (name, ng, rep)
+    assert launches and all(n == ng for n in launches)          # the chains really took the streams path
+    with torch.no_grad():
+        check(f"stage1_streams_{name}_ng{ng}", to_cpu(b, V.c0), O.stage1(sd, x0, V), 4e-2)
+    # a larger level-1 chain where the launches are long enough to really run concurrently (12 units, 3 x 4 or 8)
+    xs = act(to_dev(bf(torch.from_numpy(synth.unit_noise((6, V.c1, 96, 160), seed=96)))), V.c1)
+    pres = ["stage1.decoder_level1.", "stage1.decoder_level1_1."]
+    ya = eng.shift_chain(pres, xs).t
+    for rep in range(3):
+        yb = par.shift_chain(pres, xs).t
+        torch.cuda.synchronize()
+        assert torch.equal(ya, yb), (name, ng, rep)
 
 
 def _sibling_engine(eng, **attrs):

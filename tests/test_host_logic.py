@@ -144,6 +144,61 @@ def test_frame_wavefront_order_respects_the_shift_dependencies(circular):
                 assert pos[(1, order[[k[0] for k in order].index(1)][1])] < max(pos[(0, j)] for j in range(ng))
 
 
+@pytest.mark.parametrize("circular", [False, True])
+def test_streams_schedule_orders_every_cross_stream_access(circular):
+    """engine.stream_plan (one HIP stream per frame group): with nothing but stream order and the plan's event waits, (a) every frame a group's
+    CAB2 of unit u reads -- its own and the one its boundary frame borrows, t - 1 forward / t + 1 reverse, wrapped on deblur2's ring -- was written
+    by unit u - 1 before, and (b) nobody still reads the ring slot a unit overwrites.  Happens-before is the transitive closure of
+    'same stream, earlier' and the waited events; events: done(u, g) after unit u's CAB1 on g, cab2(u, g) after its CAB2."""
+    from shiftnet_amd.engine import stream_plan
+    for n_units in (1, 2, 3, 5, 12, 24):
+        revs = [i % 2 == 1 for i in range(n_units)]
+        for T, ng, ring in ((20, 2, 3), (20, 3, 3), (20, 4, 2), (7, 2, 3), (7, 3, 2), (52, 2, 3), (52, 3, 3), (5, 2, 2), (16, 5, 4)):
+            groups, plan = stream_plan(revs, T, ng, circular, ring)
+            assert [t for t0, nt in groups for t in range(t0, t0 + nt)] == list(range(T)) and all(nt >= 1 for _, nt in groups)
+            owner = {t: g for g, (t0, nt) in enumerate(groups) for t in range(t0, t0 + nt)}
+            # node (u, g, k): k = 0 CAB2 of unit u on group g, k = 1 its CAB1.  hb[n] = set of nodes that happened before n STARTS.
+            hb = {}
+            for u in range(n_units):
+                for g in range(ng):
+                    raw, war = plan[u][g]
+                    before = set()
+                    if u > 0:
+                        before |= hb[(u - 1, g, 1)] | {(u - 1, g, 1)}
+                    for uu, gg in raw:
+                        assert uu < u
+                        before |= hb[(uu, gg, 1)] | {(uu, gg, 1)}
+                    for uu, gg in war:
+                        assert uu < u
+                        before |= hb[(uu, gg, 0)] | {(uu, gg, 0)}
+                    hb[(u, g, 0)] = before
+                    hb[(u, g, 1)] = before | {(u, g, 0)}
+            for u in range(n_units):
+                for g, (t0, nt) in enumerate(groups):
+                    reads = set(range(t0, t0 + nt))
+                    for t in range(t0, t0 + nt):
+                        nb = t + 1 if revs[u] else t - 1
+                        if 0 <= nb < T:
+                            reads.add(nb)
+                        elif circular:
+                            reads.add(nb % T)
+                    if u > 0:                                   # (a) read after write: unit u - 1's CAB1 of every owner of a frame CAB2 reads
+                        assert all((u - 1, owner[t], 1) in hb[(u, g, 0)] for t in reads), (n_units, T, ng, ring, u, g)
+                    # (b) write after read: unit u's CAB1 writes slot u % ring over unit u - ring's output, read by CAB2 of unit u - ring + 1
+                    uo = u - ring
+                    if uo >= 0:
+                        for g2, (s0, sn) in enumerate(groups):
+                            rd = set(range(s0, s0 + sn))
+                            for t in range(s0, s0 + sn):
+                                nb = t + 1 if revs[uo + 1] else t - 1
+                                if 0 <= nb < T:
+                                    rd.add(nb)
+                                elif circular:
+                                    rd.add(nb % T)
+                            if rd & set(range(t0, t0 + nt)):
+                                assert (uo + 1, g2, 0) in hb[(u, g, 0)] | {(u, g, 0)}, (n_units, T, ng, ring, u, g, g2)
+
+
 def test_fp32_entry_points_refuse_what_their_kernels_do_not_implement():
     """The optional operands of sn32_conv_desc exist in specific kernels only; any other shape must come back SN_EINVAL (-22) from the host-side
     checks (no GPU needed) instead of being silently ignored -- a LayerNorm / residual scale / channel sum that is not applied is a wrong result."""
