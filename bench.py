@@ -22,6 +22,7 @@ for p in (ROOT, os.path.join(ROOT, "shift-net_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it); must be set before the HIP runtime starts
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -122,6 +123,12 @@ def symbol_key(sym):
                      ("ingest_kernel", "sn_ingest")):
         if pat in s:
             return key
+    m = re.search(r"cab_fused_kernel<(\d+), ", s)
+    if m:
+        return f"sn_cab_fused<mt{m.group(1)}>"
+    m = re.search(r"conv3_fast_kernel<(\d+), \d+, \d+, true>", s)
+    if m:
+        return f"sn_cab_stats<mt{m.group(1)}>"
     m = re.search(r"conv3_fast_kernel<(\d+), ", s)
     if m:
         return f"sn_conv2d<mt{m.group(1)},8x32>"
@@ -150,6 +157,8 @@ def kernel_alg_bytes(fn, meta):
                 "sn_dw5m_gemm_gate": px * 2 * c, "sn_grp5_gemm_gate": px * 2 * c, "sn_gsts_cab2_phase1": p1, "sn_cab1_phase1": p1}.get(fn, 0)
     if meta and meta[0] == "roll":             # Shift_CAB's temporal roll: one read, one write
         return 2 * meta[1] * meta[2] * meta[3] * meta[4] * 2
+    if meta and meta[0] == "cabf":             # fused dense CAB: statistics pass reads x; fused pass reads x (+ the second residual) and writes out
+        return meta[5] * meta[1] * meta[2] * meta[3] * meta[4] * 2
     if meta and meta[0] == "conv":
         _, T, ho, wo, cin, cs_out, k, stride, in_mode, out_mode = meta
         pin = T * ho * wo * stride * stride / (4 if in_mode == 1 else 1)
@@ -247,6 +256,9 @@ def main():
                          "(K4 of one group under phase 1 of another); default: the engine's")
     ap.add_argument("--frame-group", type=int, default=None, help="--schedule frame: frames per group (default 4)")
     ap.add_argument("--stream-groups", type=int, default=None, help="--schedule streams: frame groups = HIP streams (default 2)")
+    ap.add_argument("--halo", default="auto", choices=["auto", "p2p", "allgather"],
+                    help="N > 1: form of the halo exchange -- point to point to the two neighbour ranks, the all-gather of every rank's edge frames, or "
+                         "(default) point to point with an automatic, logged fall-back to the all-gather form if the first exchange fails")
     ap.add_argument("--lib", default=None, help="A/B measurements only: another build of libshiftnet_hip.so (the line then carries its path)")
     args = ap.parse_args()
     if args.lib:
@@ -312,7 +324,7 @@ def main():
     import importlib
     GShiftNet = importlib.import_module(f"basicsr.models.archs.{args.variant}").GShiftNet
     from shiftnet_amd import synth
-    from shiftnet_amd.clip_parallel import assemble_window
+    from shiftnet_amd.clip_parallel import Halo
     from shiftnet_amd.weights import synth_state_dict
 
     h, w, L = args.height, args.width, args.one_len
@@ -349,6 +361,8 @@ def main():
     # The exchange of a window's raw edge frames depends on nothing the previous window computes: it is issued on a side stream, where it
     # overlaps the tail of the previous window's kernels, and the compute stream waits for it only before the window's first launch.
     side = torch.cuda.Stream(dev) if world > 1 else None
+    halo = Halo(args.halo, log=lambda m: log(f"rank {rank}: {m}"))
+    assemble_window = halo.assemble
 
     def step(local_only=False, timed=False):
         # local_only: rank 0's extra per-kernel profiling step must not enter a collective the other ranks are not in
@@ -400,7 +414,10 @@ def main():
         mine = torch.tensor([own_elapsed / args.steps * 1e3, g_ms], device=dev, dtype=torch.float64)
         allv = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
-        per_rank = {"ms_per_step": [round(v[0].item(), 3) for v in allv], "halo_exchange_ms": [round(v[1].item(), 3) for v in allv]}
+        per_rank = {"ms_per_step": [round(v[0].item(), 3) for v in allv], "halo_exchange_ms": [round(v[1].item(), 3) for v in allv],
+                    "halo_form": halo.form, "halo_fell_back_from_p2p": halo.fell_back,
+                    "halo_note": "the exchange is issued on a side stream and overlaps the previous window's tail here; the CLI (cli.infer_clip_parallel) issues it "
+                                 "on the compute stream after decoding: its rate per window is this ms_per_step + halo_exchange_ms"}
 
     result = None
     if rank == 0:
@@ -423,6 +440,10 @@ def main():
             if fn == "sn_conv2d":                       # one GPU kernel per (M-tiles, tile shape): key by template instance
                 mt = -(-max(meta[5], 1) // 16) if meta[9] != 1 else -(-meta[5] * 4 // 16)
                 key = f"sn_conv2d<mt{mt},{'8x32' if meta[7] == 1 else '4x16'}>"
+            elif fn in ("sn_cab_stats", "sn_cab_fused"):
+                key = f"{fn}<mt{-(-meta[4] // 16)}>"
+            elif fn == "sn_cab_ca_lines":
+                key = "sn_cab_ca"
             elif fn == "sn_ln_gemm_gate":
                 key = f"{fn}<{'cab2' if meta[5] else 'cab1'}>"
             elif fn in ("sn_gsts_cab2_phase2", "sn_cab1_phase2"):
@@ -454,8 +475,8 @@ def main():
         def template_of(k):
             if k in ("sn_gsts_cab2_phase1", "sn_cab1_phase1"):
                 return "cab_phase1r_kernel (sn_gsts_cab2_phase1 + sn_cab1_phase1)"
-            if k.startswith("sn_conv2d<"):
-                return "sn_conv2d (conv3_fast_kernel + conv_mfma_kernel, every instance)"
+            if k.startswith("sn_conv2d<") or k.startswith("sn_cab_stats<") or k.startswith("sn_cab_fused<"):
+                return "dense convs (conv3_fast_kernel + conv_mfma_kernel + cab_fused_kernel, every instance)"
             return k
         groups = {}
         for k, v in agg.items():

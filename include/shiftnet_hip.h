@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 14     /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
+#define SN_ABI_VERSION 15     /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
 
 /* element types of NCHW tensors exchanged with the PyTorch side */
 #define SN_F32 0
@@ -76,7 +76,12 @@ typedef struct sn_conv_desc {
     int oscale_stride;
     const void* res2;    /* NULL or a second NHWC residual of the same shape as `res`, added after it: the "+ shortcut" that
                             follows the last TFR_UNet of a stage (gshift_deblur1.py:769,779) rides on that UNet's last conv */
+    int flags;           /* SN_CONV_TILE_KERNEL: run single-input 3x3 stride-1 convs on the one-workgroup-per-tile kernel instead of the
+                            persistent streaming kernel (csrc/sn_conv3p.hip) -- A/B measurements; results are bit-identical.
+                            Bits 4..7: persistent workgroups per CU of the streaming kernel, 0 = the library's choice; bit 8: the streaming kernel also
+                            where the library prefers the tile kernel (measurements) */
 } sn_conv_desc;
+#define SN_CONV_TILE_KERNEL 1
 int sn_conv2d(const sn_conv_desc* d, void* stream);   /* d is a HOST pointer, read during the call */
 /* number of workgroups per frame sn_conv2d launches for this descriptor (= rows of `pool` per frame); host only */
 int sn_conv_pool_blocks(const sn_conv_desc* d);
@@ -98,6 +103,24 @@ int sn_ca_mlp(const float* partial, int nblk, int cpad, int c, int cr, float inv
 int sn_cab_ca_scratch_floats(int T);
 int sn_cab_ca(const float* partial, int nblk, int cpad, const void* mid, int cs, int c, int cr, int h, int w,
               const float* w2, const float* wa, const float* wb, float* scratch, float* ca, int T, void* stream);
+/* ---- fused dense CAB (csrc/sn_cabf.hip): CAB.forward, gshift_deblur1.py:141-156, in three tensor passes instead of five ----
+ *   res = body(x) = conv3x3(PReLU(conv3x3(x)));  res = CA(res);  res += x
+ * The two-launch form (sn_conv2d with `pool`, sn_cab_ca, sn_conv2d with oscale / res) writes `mid` = PReLU(conv1(x)) to memory and reads it
+ * back.  The fused form never stores it:
+ *   1. sn_cab_stats(conv1, lines_len): conv1 exactly as sn_conv2d would run it -- same tiles, same per-workgroup channel sums into conv1->pool --
+ *      but conv1->out is the LINE buffer [T][4][lines_len][cs] bf16 (lines_len >= max(h, w)): row 0, row h-1, column 0, column w-1 of mid;
+ *   2. sn_cab_ca_lines: sn_cab_ca reading those lines instead of the tensor;
+ *   3. sn_cab_fused(conv1, conv2, tile_rows): per (tile_rows x 32)-pixel tile conv1 + PReLU on the tile's 1-pixel ring into LDS, conv2 from there,
+ *      * conv2->oscale, + x (conv2->res must be conv1->in[0]), + conv2->res2, stored to conv2->out.  tile_rows: 8 or 16.
+ * Both descriptors are those of the two-launch form (3x3, stride 1, pad 1, one input, cs_in == cs_out, NHWC); conv1->pool / conv1->out are only
+ * read by sn_cab_stats.  Results are bit-identical to the two-launch form.  sn_cab_fused_supported: 1 when an instance for the pair exists
+ * (16- and 24-channel storage), else 0 -- the caller then uses the two-launch form. */
+int sn_cab_fused_supported(const sn_conv_desc* conv1, const sn_conv_desc* conv2);
+int sn_cab_stats(const sn_conv_desc* conv1, int lines_len, void* stream);
+int sn_cab_ca_lines(const float* partial, int nblk, int cpad, const void* lines, int lines_len, int cs, int c, int cr, int h, int w,
+                    const float* w2, const float* wa, const float* wb, float* scratch, float* ca, int T, void* stream);
+int sn_cab_fused(const sn_conv_desc* conv1, const sn_conv_desc* conv2, int tile_rows, void* stream);
+
 /* the same for the fp32 engine: mid [T][h][w][c] float32 (pixel stride c), partial = sn32_chan_sum(mid), w2 [c][9][cpad] f32: the CAB's scale and
  * residual then ride on the second sn32_conv2d (oscale / res) instead of a pass of their own (sn32_scale_residual). */
 int sn32_cab_ca(const float* partial, int nblk, int cpad, const float* mid, int c, int cr, int h, int w,

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libshiftnet_hip.so")
-SOURCES = ["sn_conv.hip", "sn_gsts.hip", "sn_gsts2.hip", "sn_gsts3.hip", "sn_phase1r.hip", "sn_f32.hip", "sn_io.hip"]
+SOURCES = ["sn_conv.hip", "sn_conv3p.hip", "sn_cabf.hip", "sn_gsts.hip", "sn_gsts2.hip", "sn_gsts3.hip", "sn_phase1r.hip", "sn_f32.hip", "sn_io.hip"]
 
 
 def needs_build(out: str = OUT) -> bool:

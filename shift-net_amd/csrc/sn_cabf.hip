@@ -326,7 +326,7 @@ int sn_cab_fused(const sn_conv_desc* a, const sn_conv_desc* b, int tile_rows, vo
     const int key = cabf_key(a, b);
     if (!key) return SN_EINVAL;
     // conv1: x -> PReLU(conv + bias), nothing else; conv2: mid -> conv (+ bias) * oscale + res (= x) + res2
-    if (!a->in[0] || a->res || a->res2 || a->oscale || a->pool || b->pool || b->act != 0 || !b->out || b->res != a->in[0]) return SN_EINVAL;
+    if (!a->in[0] || a->res || a->res2 || a->oscale || b->pool || b->act != 0 || !b->out || b->res != a->in[0]) return SN_EINVAL;   // (a->pool / a->out: sn_cab_stats')
     if (b->oscale && b->oscale_stride < 16 * b->mt) return SN_EINVAL;
     if (a->h_in < 2 || a->w_in < 2) return SN_EINVAL;
     CabK K;

@@ -14,6 +14,11 @@
 #include "sn_common.h"
 #include "../../include/shiftnet_hip.h"
 
+// the streaming form of the single-input 3x3 convs (sn_conv3p.hip); sn_conv2d routes to it unless the descriptor asks for the tile kernel
+int sn_conv3p_key(const sn_conv_desc* d, bool want_pool);   // want_pool: the caller is about to attach a pool buffer (sn_conv_pool_blocks)
+int sn_conv3p_pool_rows(const sn_conv_desc* d);
+int sn_conv3p_launch(const sn_conv_desc* d, void* stream);
+
 namespace {
 
 struct ConvK {
@@ -641,12 +646,18 @@ __global__ __launch_bounds__(1024) void ca_mlp_kernel(const float* partial, int 
 __device__ __forceinline__ float cab_ldf(const bf16_t* p) { return bf_to_f(*p); }
 __device__ __forceinline__ float cab_ldf(const float* p) { return *p; }
 // E = bf16_t (bf16 engine: cs = padded channel count = pixel stride) or float (fp32 engine: cs = channel count = pixel stride)
+// L = 0: mid is the whole tensor [T][h][w][cs]; L > 0: mid is the border-line buffer of sn_cab_stats, [T][4][L][cs] = row 0, row h-1, column 0,
+// column w-1 (the only pixels of mid these kernels read)
+template <typename E>
+__device__ __forceinline__ const E* cab_px(const E* mt, int L, int w, int cs, int line, int y, int x) {
+    return L > 0 ? mt + ((size_t)line * L + (line < 2 ? x : y)) * cs : mt + ((size_t)y * w + x) * cs;
+}
 template <typename E>
 __global__ __launch_bounds__(256) void cab_ca_part_kernel(const float* partial, int nblk, int cpad, const E* mid, int cs,
-                                                        int h, int w, float* scratch) {
+                                                        int h, int w, float* scratch, int L) {
     __shared__ float acc[256];
     const int t = blockIdx.y, sidx = blockIdx.x, tid = threadIdx.x;
-    const E* mt = mid + (size_t)t * h * w * cs;
+    const E* mt = mid + (L > 0 ? (size_t)t * 4 * L * cs : (size_t)t * h * w * cs);
     float* out = scratch + ((size_t)t * SN_CABCA_NS + sidx) * 5 * 128;
     {
         const int nsplit = 256 / cpad, ch = tid % cpad, part = tid / cpad;
@@ -671,7 +682,7 @@ __global__ __launch_bounds__(256) void cab_ca_part_kernel(const float* partial, 
         if (seg < nseg)
             for (int i = sidx * nseg + seg; i < len; i += SN_CABCA_NS * nseg) {
                 const int y = line == 0 ? 0 : (line == 1 ? h - 1 : i), x = line == 2 ? 0 : (line == 3 ? w - 1 : i);
-                sm += cab_ldf(mt + ((size_t)y * w + x) * cs + ch);
+                sm += cab_ldf(cab_px(mt, L, w, cs, line, y, x) + ch);
             }
         acc[tid] = sm;
         __syncthreads();
@@ -686,13 +697,13 @@ __global__ __launch_bounds__(256) void cab_ca_part_kernel(const float* partial, 
 
 template <typename E>
 __global__ __launch_bounds__(1024) void cab_ca_kernel(const float* scratch, int cpad, const E* mid, int cs, int c, int cr,
-                                                     int h, int w, const float* w2, const float* wa, const float* wb, float* ca) {
+                                                     int h, int w, const float* w2, const float* wa, const float* wb, float* ca, int L) {
     __shared__ float acc[1024];
     __shared__ float S[9][128];      // 0 total, 1 row0, 2 row h-1, 3 col0, 4 col w-1, 5..8 corners (0,0) (0,w-1) (h-1,0) (h-1,w-1)
     __shared__ float mean[128];
     __shared__ float hid[128];
     const int t = blockIdx.x, tid = threadIdx.x;
-    const E* mt = mid + (size_t)t * h * w * cs;
+    const E* mt = mid + (L > 0 ? (size_t)t * 4 * L * cs : (size_t)t * h * w * cs);
     if (tid < 5 * 128) {
         const int k = tid >> 7, ch = tid & 127;
         float m = 0.f;
@@ -703,10 +714,10 @@ __global__ __launch_bounds__(1024) void cab_ca_kernel(const float* scratch, int 
         S[k][ch] = m;
     }
     if (tid < cs) {
-        S[5][tid] = cab_ldf(mt + tid);
-        S[6][tid] = cab_ldf(mt + ((size_t)(w - 1)) * cs + tid);
-        S[7][tid] = cab_ldf(mt + ((size_t)(h - 1) * w) * cs + tid);
-        S[8][tid] = cab_ldf(mt + ((size_t)(h - 1) * w + w - 1) * cs + tid);
+        S[5][tid] = cab_ldf(cab_px(mt, L, w, cs, 0, 0, 0) + tid);
+        S[6][tid] = cab_ldf(cab_px(mt, L, w, cs, 0, 0, w - 1) + tid);
+        S[7][tid] = cab_ldf(cab_px(mt, L, w, cs, 1, h - 1, 0) + tid);
+        S[8][tid] = cab_ldf(cab_px(mt, L, w, cs, 1, h - 1, w - 1) + tid);
     }
     __syncthreads();
     {   // pooled res[co] = (1/hw) sum_ci sum_tap w2[ci][tap][co] * S_tap[ci]; thread = (slice of ci, co), then a tree over slices
@@ -797,6 +808,10 @@ static void conv_tile(const sn_conv_desc* d, int* th, int* tw) {
 
 int sn_conv_pool_blocks(const sn_conv_desc* d) {
     if (!d) return SN_EINVAL;
+    if (!(d->flags & SN_CONV_TILE_KERNEL)) {                 // the streaming kernel writes one row per (chunk of the tile list, wave) and frame
+        const int rows = sn_conv3p_pool_rows(d);
+        if (rows > 0) return rows;
+    }
     int th, tw; conv_tile(d, &th, &tw);
     return ((d->h_out + th - 1) / th) * ((d->w_out + tw - 1) / tw);
 }
@@ -821,7 +836,11 @@ int sn_conv2d(const sn_conv_desc* d, void* stream) {
     K.c_out = d->c_out; K.nchw_dtype = d->nchw_dtype; K.sc_dtype = d->sc_dtype; K.sc = d->sc; K.pool = d->pool; K.oscale = d->oscale; K.oscale_stride = d->oscale_stride; K.res2 = (const bf16_t*)d->res2;
     const int blocks = K.cv >> 3;
     K.ps = d->stride == 1 ? 16 * sn_lds_slots(blocks) : ((blocks & 1) ? K.cv * 2 : K.cv * 2 + 16);     // stride 2: odd slot count (pixels 2 apart)
-    K.rh = K.rw = 0;
+    K.rh = K.rw = 0; K.lines_len = 0;
+    if (!(d->flags & SN_CONV_TILE_KERNEL) && sn_conv3p_key(d, false)) {
+        const int rc = sn_conv3p_launch(d, stream);
+        if (rc != SN_EINVAL) return rc;                      // (SN_EINVAL: no device to plan for -- fall through to the tile kernel's own checks)
+    }
     int th, tw; conv_tile(d, &th, &tw);
     {   // the specialised single-input 3x3 path; key = M-tiles, channels
         hipStream_t st = (hipStream_t)stream;
@@ -851,16 +870,46 @@ int sn_ca_mlp(const float* partial, int nblk, int cpad, int c, int cr, float inv
 
 int sn_cab_ca_scratch_floats(int T) { return T * SN_CABCA_NS * 5 * 128; }
 
-int sn_cab_ca(const float* partial, int nblk, int cpad, const void* mid, int cs, int c, int cr, int h, int w,
-              const float* w2, const float* wa, const float* wb, float* scratch, float* ca, int T, void* stream) {
+static int cab_ca_launch(const float* partial, int nblk, int cpad, const void* mid, int lines_len, int cs, int c, int cr, int h, int w,
+                         const float* w2, const float* wa, const float* wb, float* scratch, float* ca, int T, void* stream) {
     sn_clear_error();
     if (!partial || !mid || !w2 || !wa || !wb || !ca || !scratch || cpad < 16 || cpad > 128 || cs > 128 || (cs & 7) || c > cs ||
-        c > cpad || cr < 1 || cr > 128 || nblk < 1 || h < 2 || w < 2) return SN_EINVAL;
+        c > cpad || cr < 1 || cr > 128 || nblk < 1 || h < 2 || w < 2 || (lines_len != 0 && lines_len < (h > w ? h : w))) return SN_EINVAL;
     hipLaunchKernelGGL(cab_ca_part_kernel<bf16_t>, dim3(SN_CABCA_NS, T), dim3(256), 0, (hipStream_t)stream, partial, nblk, cpad,
-                       (const bf16_t*)mid, cs, h, w, scratch);
+                       (const bf16_t*)mid, cs, h, w, scratch, lines_len);
     hipLaunchKernelGGL(cab_ca_kernel<bf16_t>, dim3(T), dim3(1024), 0, (hipStream_t)stream, (const float*)scratch, cpad, (const bf16_t*)mid, cs,
-                       c, cr, h, w, w2, wa, wb, ca);
+                       c, cr, h, w, w2, wa, wb, ca, lines_len);
     return sn_check_launch();
+}
+
+int sn_cab_ca(const float* partial, int nblk, int cpad, const void* mid, int cs, int c, int cr, int h, int w,
+              const float* w2, const float* wa, const float* wb, float* scratch, float* ca, int T, void* stream) {
+    return cab_ca_launch(partial, nblk, cpad, mid, 0, cs, c, cr, h, w, w2, wa, wb, scratch, ca, T, stream);
+}
+
+int sn_cab_ca_lines(const float* partial, int nblk, int cpad, const void* lines, int lines_len, int cs, int c, int cr, int h, int w,
+                    const float* w2, const float* wa, const float* wb, float* scratch, float* ca, int T, void* stream) {
+    if (lines_len < 1) return SN_EINVAL;
+    return cab_ca_launch(partial, nblk, cpad, lines, lines_len, cs, c, cr, h, w, w2, wa, wb, scratch, ca, T, stream);
+}
+
+// pass 1 of the fused CAB (csrc/sn_cabf.hip): d = the CAB's FIRST conv as sn_conv2d would run it with `pool`, except that d->out is the line buffer
+int sn_cab_stats(const sn_conv_desc* d, int lines_len, void* stream) {
+    sn_clear_error();
+    if (!d || !d->out || !d->pool || !d->wfrag || !d->in[0] || d->res || d->res2 || d->oscale || d->cs_in != d->cs_out) return SN_EINVAL;
+    if (lines_len < (d->h_out > d->w_out ? d->h_out : d->w_out) || d->h_out < 2 || d->w_out < 2) return SN_EINVAL;
+    const int key = conv3_key(d);
+    if (key != 1016 && key != 2024) return SN_EINVAL;
+    ConvK K;
+    K.in0 = (const bf16_t*)d->in[0]; K.in1 = K.in2 = nullptr;
+    K.n_in = 1; K.cs = d->cs_in; K.cv = d->cs_in;
+    K.hin = d->h_in; K.win = d->w_in; K.in_mode = 0; K.k = 3; K.stride = 1; K.pad = 1; K.hout = d->h_out; K.wout = d->w_out;
+    K.wfrag = (const uint4*)d->wfrag; K.ks = d->ks; K.bias = d->bias; K.act = d->act; K.prelu = d->prelu;
+    K.res = nullptr; K.out = (bf16_t*)d->out; K.cs_out = d->cs_out; K.out_mode = 0; K.c_out = d->c_out; K.nchw_dtype = 0; K.sc_dtype = 0; K.sc = nullptr;
+    K.pool = d->pool; K.oscale = nullptr; K.oscale_stride = 0; K.res2 = nullptr;
+    K.ps = 16 * sn_lds_slots(K.cv >> 3); K.rh = K.rw = 0; K.lines_len = lines_len;
+    hipStream_t st = (hipStream_t)stream;
+    return key == 1016 ? launch_conv3_fast<1, 16, true>(K, d->T, st) : launch_conv3_fast<2, 24, true>(K, d->T, st);
 }
 
 int sn32_cab_ca(const float* partial, int nblk, int cpad, const float* mid, int c, int cr, int h, int w,
@@ -868,8 +917,8 @@ int sn32_cab_ca(const float* partial, int nblk, int cpad, const float* mid, int 
     sn_clear_error();
     if (!partial || !mid || !w2 || !wa || !wb || !ca || !scratch || cpad < 16 || cpad > 128 || c < 1 || c > cpad || cr < 1 || cr > 128 ||
         nblk < 1 || h < 2 || w < 2) return SN_EINVAL;
-    hipLaunchKernelGGL(cab_ca_part_kernel<float>, dim3(SN_CABCA_NS, T), dim3(256), 0, (hipStream_t)stream, partial, nblk, cpad, mid, c, h, w, scratch);
-    hipLaunchKernelGGL(cab_ca_kernel<float>, dim3(T), dim3(1024), 0, (hipStream_t)stream, (const float*)scratch, cpad, mid, c, c, cr, h, w, w2, wa, wb, ca);
+    hipLaunchKernelGGL(cab_ca_part_kernel<float>, dim3(SN_CABCA_NS, T), dim3(256), 0, (hipStream_t)stream, partial, nblk, cpad, mid, c, h, w, scratch, 0);
+    hipLaunchKernelGGL(cab_ca_kernel<float>, dim3(T), dim3(1024), 0, (hipStream_t)stream, (const float*)scratch, cpad, mid, c, c, cr, h, w, w2, wa, wb, ca, 0);
     return sn_check_launch();
 }
 

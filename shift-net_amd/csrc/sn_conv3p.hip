@@ -1,0 +1,474 @@
+// Streaming form of the workhorse 3x3 convolution (stride 1, pad 1, ONE NHWC input, NHWC output: both convs of every CAB, conv_trans).
+// gfx950 only.
+//
+// conv3_fast_kernel (sn_conv.hip) launches one workgroup per 8 x 32 tile: load -> barrier -> MFMA -> store, latency hidden by 6-8 resident
+// workgroups only, and ~700 executed instructions per wave for its 20-56 MFMAs (address arithmetic, bounds masks, tap-offset selects: counted
+// on the ISA).  Round 6 measured that a pass of it that stores NOTHING (the statistics pass of the fused CAB) takes 270 us where the full conv
+// takes 295: the kernel is bound by its own instruction stream and by the exposed latency chain of each tile, not by HBM.
+//
+// Here the workgroups are PERSISTENT (one chunk of the tile list each, the list ordered frame > tile column > tile row, so a workgroup walks
+// DOWN a column and the two halo rows it shares with its previous tile are L2 hits) and ROLE-SPLIT:
+//   * wave 4, the LOADER, moves the (TH+2) x 34 pixel region of tile i+2 HBM -> LDS with LDS-DMA
+//     (buffer_load_dwordx4 ... lds: no VGPRs, no ds_write pass) while tiles i and i+1 are being computed / are in flight; zero padding is
+//     the buffer descriptor's range check (rows above / below the frame are out of range and read as 0) plus one select per piece on the
+//     left / right tile columns; it never stores, so its counted vmcnt sees loads only (in-order);
+//   * waves 0-3 COMPUTE: weights stay in registers for the whole chunk, B fragments are ds_read_b128 at precomputed per-lane addresses
+//     (one VGPR per k-step, immediates per N-tile), stores go out through a scalar base + per-lane offset.  The residual operand of tile
+//     i + 1 is fetched into registers during tile i (range-checked buffer loads: 8-16 bytes per lane and N-tile); those are the only loads of
+//     a compute wave, older than the stores behind them, so hipcc's counted vmcnt waits for them without draining the stores.
+//   One s_barrier per tile: loader "tile i landed", compute waves "tile i-1 consumed" (its buffer is the one tile i+2 goes into).
+// Operand layouts, k-slot order, accumulation order and every rounding are conv3_fast_kernel's: results are bit-identical to it.
+#include "sn_common.h"
+#include "../../include/shiftnet_hip.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+struct C3P {
+    const bf16_t* in; const bf16_t* res; bf16_t* out;
+    const uint4* wfrag; const float* bias; const float* oscale; int oscale_stride;
+    float* pool; int pool_rows;
+    int act; float prelu;
+    int T, h, w, ntx, nty;
+    int S, nseg, nsg, qs;        // a tile column is cut into nseg segments of S tiles (the last one shorter); nsg segments in all; qs per chunk (workgroup)
+};
+
+// v_max_f32 without the canonicalising v_max per operand that fmaxf adds (device-only helper: inline asm inside a __global__ body poisons
+// the host-side stub of the kernel)
+__device__ __forceinline__ float max_bare(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// round(a * b) + c with BOTH roundings (hipcc contracts the source form -- and __fmul_rn / __fadd_rn -- to one fma)
+__device__ __forceinline__ float mul_then_add(float a, float b, float c) {
+    float r;
+    asm("v_mul_f32 %0, %1, %2\n\tv_add_f32 %0, %0, %3" : "=&v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t frame_rsrc(const bf16_t* base, int frame_bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, frame_bytes, 0x00020000);      // raw buffer: offsets >= num_records read as 0
+}
+
+constexpr int c3p_waves(int mt) { return mt == 1 ? 4 : mt == 2 ? 3 : 2; }      // waves per SIMD (5-wave workgroups: k per CU need ceil(5 k / 4))
+
+// D: tiles in flight ahead of the one being computed (D + 1 LDS buffers).  MODE: the epilogue, fixed at compile time (no wave-uniform branches
+// per N-tile): 0 bias only (conv_trans); 1 PReLU with a slope in [0, 1] + per-wave channel sums (first conv of a CAB); 2 CALayer scale +
+// residual (its second conv).  Any other combination stays on the tile kernel.
+template <int MT, int CS, int TH, int D, int MODE>
+__global__ __launch_bounds__(320, c3p_waves(MT)) void conv3p_kernel(const C3P P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TW = 32, RH = TH + 2, RW = TW + 2, NPB = CS / 8, PSB = CS * 2;
+    constexpr int KTOT = 9 * CS, KS = (KTOT + 31) / 32;
+    constexpr int ROWP = RW * NPB, NITEM = RH * ROWP, NDMA = (NITEM + 63) / 64, XBUF = NDMA * 1024;
+    constexpr int NBUF = D + 1, BUFSZ = XBUF, NL = NDMA;
+    constexpr bool WLDS = MT * KS > 16;                            // weights: registers up to 64 per lane, else staged once into LDS (1 KB per fragment)
+    constexpr int WBYTES = WLDS ? MT * KS * 1024 : 0;
+    constexpr int RPW = TH / 4, NTW = RPW * 2;                     // rows / N-tiles (16 pixels) per compute wave
+    constexpr int NH = MT == 1 ? (NTW < 4 ? NTW : 4) : 2;          // N-tiles per accumulation pass
+    static_assert(NTW % NH == 0 && NTW <= 4 * NH, "passes");
+    static_assert(TH % 4 == 0 && NL * (D - 1) <= 63 && D >= 1, "tile / prefetch shape");
+    const int lane = threadIdx.x & 63, wv = wave_id();
+    // chunk of the tile list; XCD k (= blockIdx.x & 7 as dispatched) takes the k-th contiguous eighth of the chunks
+    const int G = (int)gridDim.x, c = ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);
+    // The work list is (frame, tile column, segment of the column) in that order; a chunk is qs consecutive segments, so its tiles are consecutive
+    // in the (frame > column > row) order and every segment -- the unit the channel sums are flushed in -- belongs to exactly one workgroup.
+    const int fseg = c * P.qs, nsegs = min(P.qs, P.nsg - fseg);
+    if (nsegs <= 0) return;                                         // workgroup-uniform
+    int t = fseg / (P.ntx * P.nseg), tx, ty, n = 0;
+    {
+        const int rem = fseg - t * (P.ntx * P.nseg);
+        tx = rem / P.nseg;
+        const int sg = rem - tx * P.nseg;
+        ty = sg * P.S;
+        const int tail = P.nty - (P.nseg - 1) * P.S;                // tiles of a column's last segment
+        for (int k = 0, g2 = sg; k < nsegs; ++k) { n += g2 == P.nseg - 1 ? tail : P.S; if (++g2 == P.nseg) g2 = 0; }
+    }
+    n = __builtin_amdgcn_readfirstlane(n);
+    t = __builtin_amdgcn_readfirstlane(t); tx = __builtin_amdgcn_readfirstlane(tx); ty = __builtin_amdgcn_readfirstlane(ty);
+    const int rowpitch = P.w * PSB, frame_bytes = P.h * rowpitch;
+    const size_t frame_elems = (size_t)P.h * P.w * CS;
+    char* const xbufs = smem + WBYTES;
+    if constexpr (WLDS) {                                           // all five waves, before the roles split: no DMA is in flight yet
+        for (int i = (int)threadIdx.x; i < MT * KS * 64; i += 320) *(uint4*)(smem + i * 16) = P.wfrag[i];
+        __syncthreads();
+    }
+
+    if (wv == 4) {
+        // =================================================== LOADER ===================================================
+        int voff[NDMA], pxk[NDMA];
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) {
+            const int i = k * 64 + lane, ic = i < NITEM ? i : NITEM - 1;
+            const int r = ic / ROWP, j = ic - r * ROWP;
+            voff[k] = r * rowpitch + j * 16;
+            pxk[k] = j / NPB;
+        }
+        auto issue = [&](int ft, int ftx, int fty, int buf) {
+            const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P.in + (size_t)ft * frame_elems, frame_bytes);
+            const int ix0 = ftx * TW - 1;
+            const int o = ((fty * TH - 1) * P.w + ix0) * PSB;                       // may be negative: 32-bit wrap -> out of range -> 0
+            const bool edge = ftx == 0 || ix0 + RW > P.w;                           // wave-uniform
+            char* const dst = xbufs + buf * BUFSZ;
+            // (one loop with the wave-uniform test inside: written as two loops, hipcc 7.2 silently drops the kernel's HOST stub)
+#pragma unroll
+            for (int k = 0; k < NDMA; ++k) {
+                int vo = voff[k] + o;
+                if (edge) { const int gx = ix0 + pxk[k]; vo = (gx < 0 || gx >= P.w) ? (int)0x80000000 : vo; }      // left / right of the image: reads 0
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(dst + k * 1024), 16, vo, 0, 0, 0);
+            }
+        };
+        int ft = t, ftx = tx, fty = ty;                             // the tile the next issue() fetches
+        auto advance = [&]() { if (++fty == P.nty) { fty = 0; if (++ftx == P.ntx) { ftx = 0; ++ft; } } };
+        int issued = 0;
+        for (; issued < D && issued < n; ++issued) { issue(ft, ftx, fty, issued); advance(); }
+        for (int i = 0; i < n; ++i) {
+            if (n - 1 - i >= D - 1) wait_vmcnt<NL * (D - 1)>(); else wait_vmcnt<0>();      // tile i has landed (the newer ones may be in flight)
+            __builtin_amdgcn_s_barrier();
+            if (issued < n) { issue(ft, ftx, fty, issued % NBUF); advance(); ++issued; }      // into the buffer tile i - 1 was computed from
+        }
+        return;
+    }
+
+    // ====================================================== COMPUTE ======================================================
+    const int g = lane >> 4, p = lane & 15;
+    const int c0 = g * 4 * MT;
+    // per-lane LDS address of the B operand of k-step s for the wave's first N-tile (row wv*RPW, pixels 0..15): lane group g reads
+    // k-slots [(4s+g)*8, +8) = 8 channels starting at cc0 of tap (dy,dx)
+    int addr_s[KS];
+    const int lane_base = ((wv * RPW) * RW + p) * PSB;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        int toff = 0;
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            const int kk0 = (s * 4 + gg) * 8;
+            const int tap = kk0 / CS, cc0 = kk0 - tap * CS, dy = tap / 3, dx = tap - dy * 3;
+            const int o = kk0 < KTOT ? (dy * RW + dx) * PSB + cc0 * 2 : 0;
+            toff = g == gg ? o : toff;
+        }
+        addr_s[s] = lane_base + toff;
+    }
+    bf16x8_t A[WLDS ? 1 : MT][WLDS ? 1 : KS];
+    if constexpr (!WLDS) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) A[m][s] = as_frag(P.wfrag[(m * KS + s) * 64 + lane]);
+    }
+    const char* const wl = smem + lane * 16;                         // WLDS: fragment (m, s) at wl + (m * KS + s) * 1024
+    f32x4_t biasv[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const float4 b4 = P.bias ? *(const float4*)(P.bias + c0 + m * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        biasv[m] = (f32x4_t){b4.x, b4.y, b4.z, b4.w};
+    }
+    const float slope = P.prelu;
+    float4 osc[MT];
+    auto load_osc = [&](int ft) {
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) osc[m] = *(const float4*)(P.oscale + (size_t)ft * P.oscale_stride + c0 + m * 4);
+        }
+    };
+    load_osc(t);
+    // Byte offset of (wave row rr, pixel p, channel c0) from the tile's first output pixel.  Stores and residual loads go through a
+    // range-checked buffer descriptor of the frame: an offset beyond it is dropped / reads 0, so rows below the frame need no mask, and a
+    // lane whose channels are all padding (24 channels in 32 rows: lane group 3) carries an out-of-range offset for good.
+    constexpr int OOR = (int)0x80000000;
+    constexpr int PIECE = (MT == 2 || MT == 4) ? 16 : 8;             // bytes per store / residual piece; NP pieces per lane and N-tile
+    constexpr int NP = (MT * 8) / PIECE;
+    typedef unsigned rword_t __attribute__((ext_vector_type(PIECE / 4)));
+    int ooff[RPW][NP];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+            ooff[rr][q] = (c0 + q * (PIECE / 2) < CS) ? ((wv * RPW + rr) * P.w + p) * PSB + c0 * 2 + q * PIECE : OOR;
+    // The residual of tile i + 1 is requested BEFORE tile i's MFMAs and stores: the loads are then older than the stores issued behind them, and
+    // hipcc's counted vmcnt waits for them without draining those stores.
+    // (two named sets used alternately by a tile loop unrolled twice: with one set plus a copy per tile hipcc hoists the copy -- and with it the
+    // wait for loads issued a moment ago -- into the MFMA phase)
+    typedef rword_t rset_t[MODE == 2 ? NTW : 1][MODE == 2 ? NP : 1];
+    rset_t rA, rB;
+    auto load_res = [&](rset_t& rnxt, int ft, int ftx, int fty) __attribute__((always_inline)) {
+        if constexpr (MODE == 2) {
+            const __amdgpu_buffer_rsrc_t rr = frame_rsrc(P.res + (size_t)ft * frame_elems, frame_bytes);
+            const int o2 = ((fty * TH) * P.w + ftx * TW) * PSB;
+#pragma unroll
+            for (int nn = 0; nn < NTW; ++nn)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const int vo = o2 + ooff[nn >> 1][q] + (nn & 1) * 16 * PSB;
+                    if constexpr (PIECE == 16) rnxt[nn][q] = __builtin_amdgcn_raw_buffer_load_b128(rr, vo, 0, 0);
+                    else rnxt[nn][q] = __builtin_amdgcn_raw_buffer_load_b64(rr, vo, 0, 0);
+                }
+        }
+    };
+    load_res(rA, t, tx, ty);
+    float psum[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) psum[m][r] = 0.f;
+    // this wave's channel sums over ONE segment -> pool row (column, segment, wave) of the frame: the rows are a property of the image (not of
+    // the frame's position in the window, the chunking or the device), so equal frames give bit-equal sums wherever they sit
+    auto flush_pool = [&](int ft, int ftx, int fsg) {
+        if constexpr (MODE == 1) {
+            const int row = (ftx * P.nseg + fsg) * 4 + wv;
+            float* dst = P.pool + ((size_t)ft * P.pool_rows + row) * (16 * MT);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sm = row_sum16(psum[m][r]);
+                    if (p == 0) dst[c0 + m * 4 + r] = sm;
+                    psum[m][r] = 0.f;
+                }
+        }
+    };
+
+    // one N-tile of the epilogue; MASKED: the tile crosses the right / bottom image border (pixels beyond it must reach neither a store nor the sums)
+    // (plain lambdas called with literal arguments and force-inlined: generic lambdas in a __global__ template lose the host-side stub)
+    auto finish = [&](const f32x4_t (&acc)[MT][NH], const rset_t& rres, const int N0, const __amdgpu_buffer_rsrc_t ro, int o2, const bool MASKED, int ylim,
+                      int xlim) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nh = 0; nh < NH; ++nh) {
+            const int nn = N0 + nh, rr = nn >> 1, xb = nn & 1;
+            float v[MT][4];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                v[m][0] = acc[m][nh][0]; v[m][1] = acc[m][nh][1]; v[m][2] = acc[m][nh][2]; v[m][3] = acc[m][nh][3];
+                if constexpr (MODE == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {                    // max(x, a x), a in [0, 1]; the bare instruction: fmaxf adds a canonicalising v_max per operand
+                        v[m][r] = max_bare(v[m][r], slope * v[m][r]);
+                    }
+                }
+            }
+            if constexpr (MODE == 2) {      // round(conv * scale) + x: the tile kernel's two steps sit in different blocks and are NOT contracted to an fma
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const rword_t qv = rres[nn][(m * 8) / PIECE];
+                    const unsigned lo = qv[((m * 8) % PIECE) / 4], hi = qv[((m * 8) % PIECE) / 4 + 1];
+                    v[m][0] = mul_then_add(v[m][0], osc[m].x, bf_lo(lo)); v[m][1] = mul_then_add(v[m][1], osc[m].y, bf_hi(lo));
+                    v[m][2] = mul_then_add(v[m][2], osc[m].z, bf_lo(hi)); v[m][3] = mul_then_add(v[m][3], osc[m].w, bf_hi(hi));
+                }
+            }
+            bool ok = true;
+            if (MASKED) ok = (rr < ylim) && (xb * 16 < xlim);
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) psum[m][r] += (MASKED && !ok) ? 0.f : v[m][r];
+            }
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                int vo = o2 + ooff[rr][q] + xb * 16 * PSB;
+                if (MASKED) vo = ok ? vo : OOR;
+                if constexpr (PIECE == 16) {
+                    const int m = q * 2;
+                    const rword_t d = {pack_bf2(v[m][0], v[m][1]), pack_bf2(v[m][2], v[m][3]), pack_bf2(v[m + 1][0], v[m + 1][1]), pack_bf2(v[m + 1][2], v[m + 1][3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(d, ro, vo, 0, 0);
+                } else {
+                    const rword_t d = {pack_bf2(v[q][0], v[q][1]), pack_bf2(v[q][2], v[q][3])};
+                    __builtin_amdgcn_raw_buffer_store_b64(d, ro, vo, 0, 0);
+                }
+            }
+        }
+    };
+
+    int sgi = ty / P.S, sleft = min(P.S, P.nty - ty);                // current segment of the column and the tiles left in it (a chunk starts at a segment)
+    int t2 = t, tx2 = tx, ty2 = ty;                                  // the tile after the current one
+    auto advance2 = [&]() { if (++ty2 == P.nty) { ty2 = 0; if (++tx2 == P.ntx) { tx2 = 0; ++t2; } } };
+    advance2();
+    auto tile = [&](const int i, const rset_t& rres, rset_t& rnxt) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_barrier();                                // tile i is in LDS (the loader waited for its DMA before arriving here)
+        const char* const xs = xbufs + (i % NBUF) * BUFSZ;
+        if (i + 1 < n) load_res(rnxt, t2, tx2, ty2);                 // residual of tile i + 1: older than this tile's stores
+        // B fragments one k-step ahead of the MFMAs that consume them (two register sets): the scheduler on its own keeps two fragments in
+        // flight and waits for each before its MFMA -- an LDS round trip per pair, ten per tile.  NH N-tiles per pass (registers).
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        const __amdgpu_buffer_rsrc_t ro = frame_rsrc(P.out + (size_t)t * frame_elems, frame_bytes);
+        const int o2 = (oy0 * P.w + ox0) * PSB;
+        const bool full = (oy0 + TH <= P.h) && (ox0 + TW <= P.w);    // wave-uniform
+#pragma unroll
+        for (int ps = 0; ps < NTW / NH; ++ps) {
+            const int N0 = ps * NH;                                  // a constant after unrolling
+            f32x4_t acc[MT][NH];
+            bf16x8_t bq[2][NH], aq[2][WLDS ? MT : 1];
+#pragma unroll
+            for (int nh = 0; nh < NH; ++nh)
+                bq[0][nh] = as_frag(*(const uint4*)(xs + addr_s[0] + (((N0 + nh) >> 1) * RW + ((N0 + nh) & 1) * 16) * PSB));
+            if constexpr (WLDS) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) aq[0][m] = as_frag(*(const uint4*)(wl + (m * KS) * 1024));
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (s + 1 < KS) {
+#pragma unroll
+                    for (int nh = 0; nh < NH; ++nh)
+                        bq[(s + 1) & 1][nh] = as_frag(*(const uint4*)(xs + addr_s[s + 1] + (((N0 + nh) >> 1) * RW + ((N0 + nh) & 1) * 16) * PSB));
+                    if constexpr (WLDS) {
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) aq[(s + 1) & 1][m] = as_frag(*(const uint4*)(wl + (m * KS + s + 1) * 1024));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int nh = 0; nh < NH; ++nh)
+                        acc[m][nh] = mfma16(WLDS ? aq[s & 1][m] : A[WLDS ? 0 : m][WLDS ? 0 : s], bq[s & 1][nh], s == 0 ? biasv[m] : acc[m][nh]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- epilogue (arithmetic of conv3_fast_kernel): PReLU + channel sums | CALayer scale + residual; store ----
+            if (full) finish(acc, rres, N0, ro, o2, false, 0, 0);
+            else finish(acc, rres, N0, ro, o2, true, P.h - oy0 - wv * RPW, P.w - ox0 - p);
+        }
+        // next tile of the chunk (down the column, then the next column, then the next frame)
+        if (--sleft == 0) {                                          // the segment ends with this tile (after S tiles or with the column)
+            flush_pool(t, tx, sgi);
+            ++sgi;
+            sleft = min(P.S, P.nty - ty - 1);
+        }
+        if (++ty == P.nty) {
+            ty = 0; sgi = 0; sleft = min(P.S, P.nty);
+            if (++tx == P.ntx) {
+                tx = 0;
+                ++t;
+                if (i + 1 < n) load_osc(t);
+            }
+        }
+        advance2();
+    };
+    for (int i = 0; i < n; i += 2) {
+        tile(i, rA, rB);
+        if (i + 1 < n) tile(i + 1, rB, rA);
+    }
+}
+
+struct C3PPlan { int ntx, nty, S, nseg, nsg, qs, grid, pool_rows; };
+
+// `wgs` persistent workgroups per CU.  Segment length S: the longest of 8, 6, 4, 3, 2, 1 tiles whose chunks (whole segments) keep the busiest
+// workgroup within 6 % of the mean -- a flush of the channel sums costs ~64 VALU instructions per wave, so segments should not be shorter than needed.
+C3PPlan c3p_plan(int T, int h, int w, int th, int ncu, int wgs) {
+    C3PPlan p;
+    p.ntx = (w + 31) / 32; p.nty = (h + th - 1) / th;
+    const long ntiles = (long)p.ntx * p.nty * T;
+    long g = (long)ncu * wgs;
+    if (g > (ntiles + 7) / 8) g = (ntiles + 7) / 8;                  // every workgroup at least 8 tiles to amortise its prologue
+    if (g < 1) g = 1;
+    const int cand[6] = {8, 6, 4, 3, 2, 1};
+    double best = -1.0;
+    for (int k = 0; k < 6; ++k) {
+        const int S = cand[k] < p.nty ? cand[k] : p.nty;
+        const int nseg = (p.nty + S - 1) / S;
+        const long nsg = (long)nseg * p.ntx * T;
+        const long qs = (nsg + g - 1) / g;
+        const double eff = (double)ntiles / (double)g / (double)(qs * S);      // mean tiles per workgroup / the busiest one's (upper bound)
+        if (eff > best + 1e-9) { best = eff; p.S = S; p.nseg = nseg; p.nsg = (int)nsg; p.qs = (int)qs; }
+        if (eff >= 0.94) break;
+    }
+    const int chunks = (p.nsg + p.qs - 1) / p.qs;
+    p.grid = (chunks + 7) / 8 * 8;
+    p.pool_rows = 4 * p.ntx * p.nseg;
+    return p;
+}
+
+template <int MT, int CS, int TH, int D, int MODE>
+int launch_conv3p_mode(const C3P& P, const C3PPlan& pl, hipStream_t st) {
+    constexpr int NPB = CS / 8, NDMA = ((TH + 2) * 34 * NPB + 63) / 64, KS = (9 * CS + 31) / 32;
+    const size_t lds = (size_t)(D + 1) * NDMA * 1024 + (MT * KS > 16 ? MT * KS * 1024 : 0);
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv3p_kernel<MT, CS, TH, D, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return SN_ELAUNCH;
+    hipLaunchKernelGGL((conv3p_kernel<MT, CS, TH, D, MODE>), dim3(pl.grid), dim3(320), lds, st, P);
+    return sn_check_launch();
+}
+
+template <int MT, int CS, int TH, int D>
+int launch_conv3p(const C3P& K, const C3PPlan& pl, int mode, hipStream_t st) {
+    C3P P = K;
+    P.ntx = pl.ntx; P.nty = pl.nty; P.S = pl.S; P.nseg = pl.nseg; P.nsg = pl.nsg; P.qs = pl.qs; P.pool_rows = pl.pool_rows;
+    switch (mode) {
+        case 0: return launch_conv3p_mode<MT, CS, TH, D, 0>(P, pl, st);
+        case 1: return launch_conv3p_mode<MT, CS, TH, D, 1>(P, pl, st);
+        case 2: return launch_conv3p_mode<MT, CS, TH, D, 2>(P, pl, st);
+        default: return SN_EINVAL;
+    }
+}
+
+// epilogue mode of a descriptor (conv3p_kernel), -1: a combination the streaming kernel does not implement
+// (want_pool: sn_conv_pool_blocks is asked BEFORE the caller has a pool buffer to put into the descriptor)
+int c3p_mode(const sn_conv_desc* d, bool want_pool = false) {
+    if (d->res2) return -1;
+    const bool pool = d->pool != nullptr || want_pool;
+    if (d->act == 0 && !pool && !d->oscale && !d->res) return 0;
+    if (d->act == 1 && d->prelu >= 0.f && d->prelu <= 1.f && pool && !d->oscale && !d->res) return 1;
+    if (d->act == 0 && !pool && d->oscale && d->res) return 2;
+    return -1;
+}
+
+}  // namespace
+
+// ---- entry points used by sn_conv.hip (sn_conv2d / sn_conv_pool_blocks) -------------------------------------------------------------
+// key = M-tiles * 1000 + storage channels of a conv the streaming kernel has an instance for, else 0
+int sn_conv3p_key(const sn_conv_desc* d, bool want_pool) {
+    if (!(d->k == 3 && d->stride == 1 && d->pad == 1 && d->in_mode == 0 && d->out_mode == 0 && d->n_in == 1 && d->cs_in == d->cs_out &&
+          d->ks == (9 * d->cs_in + 31) / 32 && d->h_in == d->h_out && d->w_in == d->w_out) || c3p_mode(d, want_pool) < 0) return 0;
+    if ((size_t)d->h_out * d->w_out * d->cs_out * 2 >= 0x7fffffffull) return 0;       // a frame is addressed with 32-bit byte offsets
+    const int key = d->mt * 1000 + d->cs_in;
+    // (the 16-channel conv with scale + residual is the one case the tile kernel still wins: 348 vs 395 us at 20 x 720 x 1280; bit 8 of flags forces it here)
+    if (key == 1016 && c3p_mode(d, want_pool) == 2 && !(d->flags & 256)) return 0;
+    return (key == 1016 || key == 2024 || key == 3040 || key == 3048 || key == 4064) ? key : 0;
+}
+
+static int c3p_ncu() {
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return ncu;
+}
+// persistent workgroups per CU (LDS: 3 buffers of 11 / 16 KB; registers: 5-wave workgroups); bits 4..7 of sn_conv_desc.flags override it (measurements)
+static int c3p_wgs(const sn_conv_desc* d, int key) {
+    const int o = (d->flags >> 4) & 15;
+    // 16 channels: 3 (measured best of 1-4); 24 channels: 2 (one: +6 % time); >= 40 channels: weights (36-72 KB) + buffers fill the LDS of a CU
+    return o ? o : (key == 1016 ? 3 : key == 2024 ? 2 : 1);
+}
+
+// rows of `pool` per frame when sn_conv2d runs this descriptor on the streaming kernel; 0: it will not (no instance, or no device to plan for)
+int sn_conv3p_pool_rows(const sn_conv_desc* d) {
+    const int key = sn_conv3p_key(d, true), ncu = key ? c3p_ncu() : 0;
+    if (!key || !ncu) return 0;
+    return c3p_plan(d->T, d->h_out, d->w_out, 8, ncu, c3p_wgs(d, key)).pool_rows;
+}
+
+int sn_conv3p_launch(const sn_conv_desc* d, void* stream) {
+    const int key = sn_conv3p_key(d, false), ncu = key ? c3p_ncu() : 0;
+    if (!key || !ncu) return SN_EINVAL;
+    C3P K;
+    K.in = (const bf16_t*)d->in[0]; K.res = (const bf16_t*)d->res; K.out = (bf16_t*)d->out;
+    K.wfrag = (const uint4*)d->wfrag; K.bias = d->bias; K.oscale = d->oscale; K.oscale_stride = d->oscale_stride;
+    K.pool = d->pool; K.pool_rows = 0; K.act = d->act; K.prelu = d->prelu;
+    K.T = d->T; K.h = d->h_out; K.w = d->w_out;
+    const C3PPlan pl = c3p_plan(d->T, d->h_out, d->w_out, 8, ncu, c3p_wgs(d, key));
+    hipStream_t st = (hipStream_t)stream;
+    const int mode = c3p_mode(d);
+    switch (key) {
+        case 1016: return launch_conv3p<1, 16, 8, 2>(K, pl, mode, st);
+        case 2024: return launch_conv3p<2, 24, 8, 2>(K, pl, mode, st);
+        case 3040: return launch_conv3p<3, 40, 8, 2>(K, pl, mode, st);
+        case 3048: return launch_conv3p<3, 48, 8, 2>(K, pl, mode, st);
+        case 4064: return launch_conv3p<4, 64, 8, 1>(K, pl, mode, st);      // 72 KB of weights: two buffers of 43 KB
+        default: return SN_EINVAL;
+    }
+}

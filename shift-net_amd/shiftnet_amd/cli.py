@@ -34,7 +34,7 @@ import torch
 
 from . import synth
 from .arch import CLASSES
-from .clip_parallel import assemble_window, rounds, window_ranges
+from .clip_parallel import Halo, assemble_window, rounds, window_ranges
 from .io_edges import egress_u8, ingest_u8, ssim_u8
 from .weights import synth_state_dict
 
@@ -185,11 +185,14 @@ class Inference:
     def infer_clip_parallel(self) -> Tuple[float, float]:
         """The deblur main loop (test_deblur.py:91-177) with the windows of a clip taken `world` at a time, one per rank: a rank
         decodes the one_len frames it restores (+ the clip-side edge frames on the first / last active rank of a round), the 2 + 2 halo frames
-        arrive in one all-gather of raw uint8 frames, every rank restores and scores its window on its device, and rank 0 logs the gathered
-        lines in window order -- the same lines (times aside) as the single-process run with the same one_len."""
+        arrive from the two neighbour ranks as raw uint8 frames (clip_parallel.Halo: point to point, or -- `--halo allgather` / automatic fall-back --
+        one all-gather), every rank restores and scores its window on its device, and rank 0 logs the gathered lines in window order -- the same
+        lines (times aside) as the single-process run with the same one_len.  Idle ranks of a partial last round decode nothing and, once the
+        exchange form is settled, take no part in a point-to-point exchange."""
         import torch.distributed as dist
         a, rank, world = self.args, self.rank, self.world
         on_host = dist.get_backend() == "gloo"                 # several ranks on one device (tests): the collective moves host tensors
+        halo = Halo(getattr(a, "halo", "auto"), log=lambda m: print(f"[rank {rank}] {m}", file=sys.stderr, flush=True))
         total_psnr, total_ssim = {}, {}
         for v, ins, gts in self.videos():
             vp, vs = [], []
@@ -197,17 +200,22 @@ class Inference:
             for rnd in rounds(len(wins), world):
                 t0 = time.time()
                 act = len(rnd)
-                mine = rnd[rank] if rank < act else rnd[0]         # idle ranks of a partial last round decode window 0's frames as filler
+                idle = rank >= act                                 # a partial last round: this rank holds no window
+                mine = rnd[rank] if not idle else rnd[0]
                 r_in, r_out = wins[mine]
-                own_np = self._load(ins[r_out.start:r_out.stop])
-                h, w, _ = own_np[0].shape
-                nh, nw = h - h % 4, w - w % 4
-                crop = lambda ims: torch.from_numpy(np.stack([im[:nh, :nw] for im in ims])).permute(0, 3, 1, 2).contiguous()      # noqa: E731
                 to = (lambda t: t) if on_host else (lambda t: t.to(self.device))
-                own = to(crop(own_np))
-                first = to(crop(self._load(ins[r_in.start:r_in.start + 2]))) if rank == 0 else None
-                last = to(crop(self._load(ins[r_in.stop - 2:r_in.stop]))) if rank == act - 1 else None
-                win = assemble_window(own, first, last, rank, world, active=act)      # uint8 [L+4,3,H,W]
+                if idle and halo.form == "p2p":                    # nothing to decode, nobody to talk to
+                    win = None
+                else:
+                    # (an idle rank of the collective form contributes filler frames of the right shape: the first frame of the round, repeated)
+                    own_np = self._load(ins[r_out.start:r_out.stop] if not idle else [ins[r_out.start]] * len(r_out))
+                    h, w, _ = own_np[0].shape
+                    nh, nw = h - h % 4, w - w % 4
+                    crop = lambda ims: torch.from_numpy(np.stack([im[:nh, :nw] for im in ims])).permute(0, 3, 1, 2).contiguous()      # noqa: E731
+                    own = to(crop(own_np))
+                    first = to(crop(self._load(ins[r_in.start:r_in.start + 2]))) if rank == 0 else None
+                    last = to(crop(self._load(ins[r_in.stop - 2:r_in.stop]))) if rank == act - 1 else None
+                    win = halo.assemble(own, first, last, rank, world, active=act)      # uint8 [L+4,3,H,W]
                 rec = None
                 if win is not None:
                     u8 = win.to(self.device).permute(0, 2, 3, 1).contiguous()        # HWC frames, what ingest_u8 takes
@@ -350,11 +358,12 @@ def main(variant: str, argv: Optional[Sequence[str]] = None) -> Tuple[float, flo
                          "products (~2^-16 per product; both within 1e-4 of the reference, the exact mode is about half as fast)")
     if not denoise:
         ap.add_argument("--gpus", type=int, default=1, help="clip-parallel: one process per GPU, the windows of a clip N at a time")
+        ap.add_argument("--halo", choices=["auto", "p2p", "allgather"], default="auto",
+                        help="clip-parallel halo exchange: point to point, all-gather, or point to point with an automatic fall-back (default)")
     a = ap.parse_args(argv)
     if a.fp32_exact:
         os.environ["SN_FP32_EXACT"] = "1"
     a.rank, a.world = 0, 1
-    a.local_device = torch.cuda.current_device() if torch.cuda.is_available() else 0      # an embedding process may have chosen another device
     ngpus = getattr(a, "gpus", 1)
     if (ngpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1) and not denoise:
         # clip-parallel takes its halo from ONE neighbour window and keeps the frames on the device
@@ -363,8 +372,11 @@ def main(variant: str, argv: Optional[Sequence[str]] = None) -> Tuple[float, flo
         if a.host_io:
             ap.error("--host_io is a single-process mode (upstream's host path); it cannot be combined with --gpus / a multi-rank launch")
     if ngpus > 1 and "RANK" not in os.environ:
-        return _spawn_ranks(variant, ngpus, sys.argv[1:] if argv is None else argv)      # this process only launches and waits; rank 0 prints the log
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not denoise:
+        return _spawn_ranks(variant, ngpus, sys.argv[1:] if argv is None else argv)      # this process only launches and waits (it never touches a GPU); rank 0 prints the log
+    # single process: the device an embedding process may have chosen; ranks: LOCAL_RANK, set below before anything touches a device
+    multi = int(os.environ.get("WORLD_SIZE", "1")) > 1 and not denoise
+    a.local_device = 0 if multi else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    if multi:
         import torch.distributed as dist
         a.rank, a.world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
         ndev = torch.cuda.device_count()
@@ -397,11 +409,12 @@ def main(variant: str, argv: Optional[Sequence[str]] = None) -> Tuple[float, flo
     except BaseException:
         # This rank failed while the others may sit in a collective: no barrier here (it would never complete and hide the error behind the
         # process-group timeout).  Leaving the group un-synchronised makes the launcher / _spawn_ranks see a non-zero exit at once.
+        # Nor destroy_process_group(): on an RCCL group whose peers sit in a collective it can block itself.  Log and leave at once.
         if a.world > 1 and dist.is_initialized():
-            try:
-                dist.destroy_process_group()
-            except Exception:                                   # noqa: BLE001
-                pass
+            import traceback
+            traceback.print_exc()
+            sys.stderr.flush()
+            os._exit(1)
         raise
     if a.world > 1 and dist.is_initialized():
         dist.barrier()

@@ -33,7 +33,8 @@ def assemble_window(own: torch.Tensor, first_edge: Optional[torch.Tensor], last_
     tests -- needs host tensors: pass them as such).  L >= 2: a window's halo is two frames of ONE neighbour (a shorter window would need
     the neighbour's neighbour; the CLI refuses one_len < 2 under --gpus).
     all_gather=True keeps round 4's collective form (every rank's 4 edge frames to every rank); a one-rank group uses it so that the RCCL
-    path is exercised on a single-GPU box (tests/test_gpu_multirank.py), where point-to-point has nobody to talk to.
+    path is exercised on a single-GPU box (tests/test_gpu_multirank.py), where point-to-point has nobody to talk to.  `Halo` (below) picks
+    the form per process group and falls back from point to point to the collective on its own.
     """
     if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return torch.cat((first_edge, own, last_edge), 0)
@@ -55,18 +56,79 @@ def assemble_window(own: torch.Tensor, first_edge: Optional[torch.Tensor], last_
     edge = lambda t: (t.cpu() if staged else t.contiguous())         # noqa: E731
     recv = lambda: torch.empty((2,) + tuple(own.shape[1:]), dtype=own.dtype, device="cpu" if staged else own.device)      # noqa: E731
     ops, head, tail = [], first_edge, last_edge
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)      # P2POp addresses GLOBAL ranks
     if rank > 0:                                    # my first two frames are the left neighbour's tail; its last two are my head
         head = recv()
-        ops.append(dist.P2POp(dist.isend, edge(own[:2]), rank - 1, group))
-        ops.append(dist.P2POp(dist.irecv, head, rank - 1, group))
+        ops.append(dist.P2POp(dist.isend, edge(own[:2]), peer(rank - 1), group))
+        ops.append(dist.P2POp(dist.irecv, head, peer(rank - 1), group))
     if rank < active - 1:
         tail = recv()
-        ops.append(dist.P2POp(dist.isend, edge(own[-2:]), rank + 1, group))
-        ops.append(dist.P2POp(dist.irecv, tail, rank + 1, group))
+        ops.append(dist.P2POp(dist.isend, edge(own[-2:]), peer(rank + 1), group))
+        ops.append(dist.P2POp(dist.irecv, tail, peer(rank + 1), group))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return torch.cat((head.to(own.device), own, tail.to(own.device)), 0)
+
+
+class Halo:
+    """Which form the halo exchange of a clip-parallel run takes, decided once per process group.
+
+    mode "p2p": two raw frames to / from each neighbour (`assemble_window`); "allgather": round 4's collective form; "auto" (default): p2p,
+    and if the FIRST exchange raises on any rank -- every rank learns it through one all-reduce of a failure flag -- all ranks switch to the
+    all-gather form together, say so once (`log`), and redo that exchange.  The first call must be made by every rank of the group (idle ranks
+    of a partial round included; they get None back as from `assemble_window`).  A p2p exchange that neither completes nor raises within
+    `timeout_s` cannot be recovered from inside the process (the communicator's stream is blocked): that raises with the advice to run with
+    --halo allgather.  `form` is what ran ("p2p" / "allgather"); one-rank groups always use the collective form (nobody to talk to)."""
+
+    def __init__(self, mode: str = "auto", timeout_s: float = 120.0, log=None) -> None:
+        if mode not in ("auto", "p2p", "allgather"):
+            raise ValueError(f"halo mode {mode!r}: expected auto, p2p or allgather")
+        self.mode, self.timeout_s, self.log = mode, timeout_s, log
+        self.form: Optional[str] = "allgather" if mode == "allgather" else None
+        self.fell_back = False
+
+    def _completed(self, own: torch.Tensor) -> None:
+        if not own.is_cuda:
+            return
+        import time
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(own.device))
+        t0 = time.time()
+        while not ev.query():
+            if time.time() - t0 > self.timeout_s:
+                raise TimeoutError(f"clip-parallel halo exchange (point to point) did not complete within {self.timeout_s:.0f} s: "
+                                   "re-run with --halo allgather")
+            time.sleep(0.002)
+
+    def assemble(self, own: torch.Tensor, first_edge, last_edge, rank: int = 0, world: int = 1, group=None, active: Optional[int] = None):
+        if world == 1 or not (dist.is_available() and dist.is_initialized()):
+            self.form = self.form or ("allgather" if dist.is_available() and dist.is_initialized() else "none")
+            return assemble_window(own, first_edge, last_edge, rank, world, group, active)
+        if self.form is not None:
+            return assemble_window(own, first_edge, last_edge, rank, world, group, active, all_gather=self.form == "allgather")
+        err: Optional[BaseException] = None
+        win = None
+        try:                                                     # the first exchange of this group: try point to point
+            win = assemble_window(own, first_edge, last_edge, rank, world, group, active)
+            self._completed(own)
+        except TimeoutError:
+            raise
+        except Exception as e:                                   # noqa: BLE001
+            err = e
+        on_host = dist.get_backend(group) == "gloo" or not own.is_cuda
+        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device="cpu" if on_host else own.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if int(flag.item()) == 0:
+            self.form = "p2p"
+            return win
+        if self.mode == "p2p":
+            raise RuntimeError(f"clip-parallel halo exchange (point to point) failed on some rank (this rank: {err!r})")
+        self.form, self.fell_back = "allgather", True
+        if self.log is not None:
+            self.log(f"clip-parallel: the point-to-point halo exchange failed ({'this rank: %r' % (err,) if err is not None else 'on another rank'}); "
+                     "every rank now uses the all-gather form")
+        return assemble_window(own, first_edge, last_edge, rank, world, group, active, all_gather=True)
 
 
 def rounds(n_windows: int, world: int) -> List[List[int]]:

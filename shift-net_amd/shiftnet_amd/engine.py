@@ -249,6 +249,11 @@ class Engine:
     def _new(self, T: int, h: int, w: int, cs: int) -> torch.Tensor:
         return torch.empty((T, h, w, cs), dtype=self.act_dtype, device=self.dev)
 
+    # single-input 3x3 stride-1 convs: the persistent streaming kernel (csrc/sn_conv3p.hip) or, SN_CONV_TILES=1, the one-workgroup-per-tile kernel
+    conv_tiles = os.environ.get("SN_CONV_TILES", "0") == "1"
+    conv_stream_all = os.environ.get("SN_CONV_STREAM_ALL", "0") == "1"      # measurements / tests: the streaming kernel also where the library prefers the tile kernel
+    conv_wgs = int(os.environ.get("SN_CONV_WGS", "0"))            # measurements: persistent workgroups per CU of the streaming kernel (0: the library's choice)
+
     def conv(self, name: str, ins: Sequence[Act], *, stride: int = 1, pad: Optional[int] = None, prelu: Optional[float] = None,
              res: Optional[Act] = None, out_mode: int = 0, pool: bool = False, in_mode: int = 0, oscale: Optional[torch.Tensor] = None,
              nchw_out: Optional[torch.Tensor] = None, nchw_sc: Optional[torch.Tensor] = None, res2: Optional[Act] = None):
@@ -282,6 +287,7 @@ class Engine:
             out_act = Act(o, c_log)
             d.out, d.cs_out, d.c_out = o.data_ptr(), cs_out, cout
         d.out_mode = out_mode
+        d.flags = L.SN_CONV_TILE_KERNEL if self.conv_tiles else ((self.conv_wgs << 4) | (256 if self.conv_stream_all else 0))
         if res is not None:
             assert out_mode == 0 and res.dims == out_act.dims
             d.res = res.t.data_ptr()
@@ -331,6 +337,10 @@ class Engine:
             p = self.P.cas[pre + "CA"]
             T, h, w, cs = x.dims
             slope = self.P.scalar(pre + "body.1.weight")
+            if self.cab_fused != "0":
+                out = self._cab_fused(pre, x, extra, slope)
+                if out is not None:
+                    return out
             scratch = torch.empty((self.lib.sn_cab_ca_scratch_floats(T),), dtype=torch.float32, device=self.dev)
             mid, pool, _ = self.conv(pre + "body.0", [x], prelu=slope, pool=True)
             _, nblk, cpad = pool.shape
@@ -342,6 +352,60 @@ class Engine:
         r = self.conv(pre + "body.0", [x], prelu=self.P.scalar(pre + "body.1.weight"))
         r, pool, npix = self.conv(pre + "body.2", [r], pool=True)
         return self.scale_residual(r, x, self.ca_mlp(pre + "CA", pool, npix), extra)
+
+    # Fused dense CAB (csrc/sn_cabf.hip): statistics pass + one kernel with `mid` in LDS, three tensor passes instead of five, bit-identical to the
+    # two-launch form.  SN_CAB_FUSED: "0" (default: measured faster) two sn_conv2d launches, "8" / "16" the fused form with that many tile rows.
+    cab_fused = os.environ.get("SN_CAB_FUSED", "0")
+
+    def _conv_desc(self, name: str, x: Act, *, prelu: Optional[float] = None) -> L.ConvDesc:
+        """sn_conv_desc of a single-input 3x3 stride-1 conv of a CAB on x (no output, residual or pool operands yet)."""
+        p = self.P.convs[name]
+        T, h, w, cs = x.dims
+        assert cs == p["cs_in"] and p["n_in"] == 1 and int(p["k"]) == 3
+        d = L.ConvDesc()
+        d.inp[0] = x.t.data_ptr()
+        d.n_in, d.cs_in, d.T, d.h_in, d.w_in, d.in_mode = 1, cs, T, h, w, 0
+        d.k, d.stride, d.pad, d.h_out, d.w_out = 3, 1, 1, h, w
+        d.wfrag, d.mt, d.ks = p["wfrag"].data_ptr(), int(p["mt"]), int(p["ks"])
+        d.bias = p["bias"].data_ptr() if p["bias"] is not None else None
+        d.act, d.prelu = (1, prelu) if prelu is not None else (0, 0.0)
+        d.cs_out, d.c_out, d.out_mode = prep.ceil8(int(p["cout"])), int(p["cout"]), 0
+        d.flags = L.SN_CONV_TILE_KERNEL          # the statistics pass and the fused kernel are tile kernels: their pool rows are per tile
+        return d
+
+    def _cab_fused(self, pre: str, x: Act, extra: Optional[Act], slope: float) -> Optional[Act]:
+        """CAB as sn_cab_stats -> sn_cab_ca_lines -> sn_cab_fused; None when the library has no fused instance for this width."""
+        lib = self.lib
+        T, h, w, cs = x.dims
+        if h < 2 or w < 2:
+            return None
+        d1 = self._conv_desc(pre + "body.0", x, prelu=slope)
+        d2 = self._conv_desc(pre + "body.2", x)
+        if d1.cs_out != cs or d2.cs_out != cs or not lib.sn_cab_fused_supported(C.byref(d1), C.byref(d2)):
+            return None
+        p = self.P.cas[pre + "CA"]
+        ll = max(h, w)
+        lines = torch.empty((T, 4, ll, cs), dtype=self.act_dtype, device=self.dev)
+        nblk = lib.sn_conv_pool_blocks(C.byref(d1))
+        pool = torch.empty((T, nblk, 16 * d1.mt), dtype=torch.float32, device=self.dev)
+        scratch = torch.empty((lib.sn_cab_ca_scratch_floats(T),), dtype=torch.float32, device=self.dev)
+        ca = torch.empty((T, 16 * d1.mt), dtype=torch.float32, device=self.dev)
+        out = self._new(T, h, w, cs)
+        d1.out, d1.pool = lines.data_ptr(), pool.data_ptr()
+        d2.out, d2.res, d2.oscale, d2.oscale_stride = out.data_ptr(), x.t.data_ptr(), ca.data_ptr(), ca.shape[1]
+        if extra is not None:
+            assert extra.dims == x.dims
+            d2.res2 = extra.t.data_ptr()
+        rows = int(self.cab_fused) if self.cab_fused in ("8", "16") else 8
+        st = self._stream()
+        self._meta = ("cabf", T, h, w, cs, 1)                   # statistics pass: reads x
+        self._call("sn_cab_stats", f"sn_cab_stats[{pre}]", C.byref(d1), ll, st)
+        self._meta = ()
+        self._call("sn_cab_ca_lines", f"sn_cab_ca[{pre}]", pool.data_ptr(), nblk, 16 * d1.mt, lines.data_ptr(), ll, cs, p["c"], p["cr"], h, w,
+                   p["w2"].data_ptr(), p["wa"].data_ptr(), p["wb"].data_ptr(), scratch.data_ptr(), ca.data_ptr(), T, st)
+        self._meta = ("cabf", T, h, w, cs, 3 if extra is not None else 2)      # fused pass: reads x (+ extra), writes out
+        self._call("sn_cab_fused", f"sn_cab_fused[{pre}]", C.byref(d1), C.byref(d2), rows, st)
+        return Act(out, x.c)
 
     def _wrap_flag(self, mode: int, circular: bool) -> int:
         """sn_unit_src.wrap: 0 keep the window's boundary frame, 1 circular, 2 the neighbour frame's half arrives from the adjacent rank."""

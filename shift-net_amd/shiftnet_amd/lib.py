@@ -15,11 +15,11 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libshiftnet_hip.so")
 
 SN_F32, SN_F16, SN_BF16 = 0, 1, 2
 
-ABI_VERSION = 14     # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so from before a struct / signature change fails the check in load()
+ABI_VERSION = 15     # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so from before a struct / signature change fails the check in load()
 
 SYMBOLS = [          # include/shiftnet_hip.h, production ABI
     "sn_abi_version", "sn_selftest_mfma", "sn_ingest", "sn_conv2d", "sn_conv_pool_blocks", "sn_ca_mlp",
-    "sn_cab_ca", "sn_cab_ca_scratch_floats", "sn_planar_pitch", "sn_nhwc_to_planar", "sn_dw5m_blocks",
+    "sn_cab_ca", "sn_cab_ca_scratch_floats", "sn_cab_fused_supported", "sn_cab_stats", "sn_cab_ca_lines", "sn_cab_fused", "sn_planar_pitch", "sn_nhwc_to_planar", "sn_dw5m_blocks",
     "sn_dw5m_gemm_gate", "sn_gsts_gather", "sn_temporal_roll", "sn_gsts_shiftconv", "sn_gsts_cab2_phase2", "sn_cab1_phase2",
     "sn_ingest_u8", "sn_egress_blocks", "sn_egress_u8", "sn_ssim_blocks", "sn_ssim_u8",
     "sn32_conv2d", "sn32_gsts_gather", "sn32_layernorm", "sn32_gate", "sn32_gate_sum", "sn32_chan_sum", "sn32_scale_residual", "sn32_ingest", "sn32_cab_ca", "sn32_dw_gate", "sn32_conv1x1_gate2", "sn32_gsts_shiftconv", "sn32_conv_csum_tiles",
@@ -61,7 +61,11 @@ class ConvDesc(C.Structure):
         ("act", C.c_int), ("prelu", C.c_float), ("res", C.c_void_p), ("out", C.c_void_p),
         ("cs_out", C.c_int), ("out_mode", C.c_int), ("c_out", C.c_int), ("nchw_dtype", C.c_int),
         ("sc", C.c_void_p), ("sc_dtype", C.c_int), ("pool", C.c_void_p), ("oscale", C.c_void_p), ("oscale_stride", C.c_int), ("res2", C.c_void_p),
+        ("flags", C.c_int),
     ]
+
+
+SN_CONV_TILE_KERNEL = 1
 
 
 class Conv32Desc(C.Structure):
@@ -119,6 +123,10 @@ def load() -> C.CDLL:
     lib.sn_dw5m_gemm_gate.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.sn_cab_ca.argtypes = [vp, ci, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp]
     lib.sn_cab_ca_scratch_floats.argtypes = [ci]
+    lib.sn_cab_fused_supported.argtypes = [C.POINTER(ConvDesc), C.POINTER(ConvDesc)]
+    lib.sn_cab_stats.argtypes = [C.POINTER(ConvDesc), ci, vp]
+    lib.sn_cab_ca_lines.argtypes = [vp, ci, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp]
+    lib.sn_cab_fused.argtypes = [C.POINTER(ConvDesc), C.POINTER(ConvDesc), ci, vp]
     lib.sn32_cab_ca.argtypes = [vp, ci, ci, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp]
     lib.sn_gsts_gather.argtypes = [C.POINTER(UnitSrc), vp, vp, vp]
     lib.sn_temporal_roll.argtypes = [C.POINTER(UnitSrc), vp, vp]

@@ -223,6 +223,71 @@ def test_cab(name, pre, c, hw, engines):
     check(f"cab_extra_{name}_{pre}_{hw[0]}x{hw[1]}", to_cpu(out2.t, c), ref + e, 8e-3)
 
 
+@pytest.mark.parametrize("name,pre,c", [("gshift_deblur2", "stage1.concat.", 14), ("gshift_deblur2", "orb1.encoder_level2.1.", 18),
+                                        ("gshift_deblur2", "orb1.encoder_level3.1.", 22), ("gshift_deblur1", "stage1.concat.", 24),
+                                        ("gshift_denoise1", "stage1.encoder_level0.", 24)])
+@pytest.mark.parametrize("T,hw", [(3, (45, 150)), (2, (24, 40)), (2, (8, 32)), (1, (16, 64)), (3, (2, 3)), (2, (37, 33)), (1, (9, 34))])
+def test_fused_cab_is_bit_identical_to_the_two_launch_form(name, pre, c, T, hw, engines):
+    """csrc/sn_cabf.hip: statistics pass (channel sums + border lines of mid, nothing else stored) -> closed-form CALayer -> one kernel with `mid` in
+    LDS.  Same operand layouts, k order, accumulation order and roundings as sn_conv2d twice, so the result must be BIT-IDENTICAL to the two-launch
+    form, for both tile heights, with and without the second residual, on interior tiles, ragged right / bottom tiles, maps smaller than a tile
+    and one-tile maps whose ring lies entirely outside the image; and within the CAB tolerance of the CPU oracle (gshift_deblur1.py:141-156)."""
+    eng, sd = engines(name)
+    two = _sibling_engine(eng, cab_fused="0", conv_tiles=True)      # (the streaming conv kernel adds the channel sums in another order)
+    x = bf(torch.from_numpy(synth.unit_noise((T, c, hw[0], hw[1]), seed=73)))
+    e = bf(torch.from_numpy(synth.unit_noise((T, c, hw[0], hw[1]), seed=74)))
+    xa, ea = act(to_dev(x), c), act(to_dev(e), c)
+    ref0 = two.cab(pre, xa).t
+    ref1 = two.cab(pre, xa, ea).t
+    for rows in ("8", "16"):
+        fz = _sibling_engine(eng, cab_fused=rows)
+        called = []
+        orig = fz._call
+        fz._call = lambda fn, *a: (called.append(fn), orig(fn, *a))[1]
+        got0 = fz.cab(pre, xa).t
+        got1 = fz.cab(pre, xa, ea).t
+        torch.cuda.synchronize()
+        assert called.count("sn_cab_fused") == 2 and "sn_conv2d" not in called, called      # the fused path really ran
+        assert torch.equal(ref0, got0) and torch.equal(ref1, got1), (name, pre, rows, T, hw,
+                                                                     (ref0.float() - got0.float()).abs().max().item(), (ref1.float() - got1.float()).abs().max().item())
+    check(f"cab_fused_{name}_{pre}_{T}x{hw[0]}x{hw[1]}", to_cpu(got0, c), O.cab(sd, pre, x), 8e-3)
+    check(f"cab_fused_extra_{name}_{pre}_{T}x{hw[0]}x{hw[1]}", to_cpu(got1, c), O.cab(sd, pre, x) + e, 8e-3)
+    if got0.shape[-1] > c:
+        assert got0[..., c:].float().abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("name,pre,c", [("gshift_deblur2", "stage1.concat.", 14), ("gshift_deblur2", "orb1.encoder_level2.1.", 18),
+                                        ("gshift_deblur2", "orb1.encoder_level3.1.", 22), ("gshift_deblur1", "stage1.concat.", 24),
+                                        ("gshift_deblur1", "orb1.encoder_level2.0.", 36), ("gshift_deblur1", "orb1.encoder_level3.0.", 48),
+                                        ("gshift_deblur2", "stage1.skip_attn1.", 64)])      # >= 36 channels: weight fragments staged in LDS
+@pytest.mark.parametrize("T,hw", [(3, (45, 150)), (2, (24, 40)), (2, (8, 32)), (1, (16, 64)), (3, (2, 3)), (2, (37, 33)), (5, (72, 200)), (1, (360, 640))])
+@pytest.mark.parametrize("wgs", [0, 1])
+def test_streaming_conv_is_bit_identical_to_the_tile_kernel(name, pre, c, T, hw, wgs, engines):
+    """csrc/sn_conv3p.hip (persistent workgroups, LDS-DMA loader wave, zero padding by the buffer range check) against conv3_fast_kernel: the first
+    conv of a CAB (bias-free 3x3 + PReLU + channel sums) and the second one (CALayer scale + residual) must be BIT-IDENTICAL -- same operands,
+    same k order -- for interior tiles, ragged right / bottom tiles, maps smaller than a tile, chunks that cross column and frame boundaries
+    (wgs = 1: one workgroup per CU, long chunks; 0: the library's choice); the channel sums are the same numbers added in another order."""
+    eng, sd = engines(name)
+    new = _sibling_engine(eng, conv_tiles=False, conv_wgs=wgs, conv_stream_all=True)
+    old = _sibling_engine(eng, conv_tiles=True)
+    x = act(to_dev(bf(torch.from_numpy(synth.unit_noise((T, c, hw[0], hw[1]), seed=75)))), c)
+    slope = eng.P.scalar(pre + "body.1.weight")
+    m_new, p_new, _ = new.conv(pre + "body.0", [x], prelu=slope, pool=True)
+    m_old, p_old, _ = old.conv(pre + "body.0", [x], prelu=slope, pool=True)
+    torch.cuda.synchronize()
+    assert torch.equal(m_new.t, m_old.t), (name, pre, T, hw, (m_new.t.float() - m_old.t.float()).abs().max().item())
+    s_new, s_old = p_new.sum(1), p_old.sum(1)
+    assert torch.isfinite(s_new).all() and (s_new - s_old).abs().max().item() <= 1e-4 * max(1.0, s_old.abs().max().item())
+    ca = (0.5 + torch.rand(T, p_old.shape[2], device=DEV)).float()
+    o_new = new.conv(pre + "body.2", [m_old], res=x, oscale=ca)
+    o_old = old.conv(pre + "body.2", [m_old], res=x, oscale=ca)
+    torch.cuda.synchronize()
+    assert torch.equal(o_new.t, o_old.t), (name, pre, T, hw, (o_new.t.float() - o_old.t.float()).abs().max().item())
+    check(f"conv3p_{name}_{pre}_{T}x{hw[0]}x{hw[1]}", to_cpu(m_new.t, c),
+          torch.nn.functional.prelu(torch.nn.functional.conv2d(to_cpu(x.t, c), sd[pre + "body.0.weight"].to(torch.bfloat16).float(), None, padding=1),
+                                    torch.tensor([slope])), 8e-3)
+
+
 @pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_denoise2", "gshift_deblur1", "gshift_denoise1"])
 def test_gsts_pieces(name, engines):
     """shiftconv alone, then CAB2 (both directions), CAB1, a whole unit and a whole Encoder_shift_block (production chain)."""

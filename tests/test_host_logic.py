@@ -361,6 +361,48 @@ def test_halo_exchange_gloo(world, L, active, all_gather):
     mp.spawn(_halo_worker, args=(world, port, L, active, all_gather), nprocs=world, join=True)
 
 
+def _halo_form_worker(rank, world, port, L, mode, break_p2p, active):
+    sys.path.insert(0, os.path.join(ROOT, "shift-net_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from shiftnet_amd import clip_parallel as CP
+    if break_p2p and rank in break_p2p:              # the point-to-point launch raises on these ranks BEFORE anything is posted (what an
+        def boom(ops):                               # unsupported transport does); the other ranks may or may not have failed too
+            raise RuntimeError("simulated: point-to-point transport unavailable")
+        CP.dist.batch_isend_irecv = boom
+    logs = []
+    halo = CP.Halo(mode, timeout_s=60, log=logs.append)
+    n = world * L + 4
+    clip = torch.arange(n * 3 * 4 * 6, dtype=torch.float32).reshape(n, 3, 4, 6)
+    try:
+        for rnd, act in enumerate((world, active, world)):   # three rounds, the middle one possibly partial (idle ranks); the form is decided in the first
+            r = rank if rank < act else 0
+            own = clip[r * L + 2: r * L + 2 + L]
+            win = halo.assemble(own, clip[:2] if rank == 0 else None, clip[act * L + 2: act * L + 4] if rank == act - 1 else None, rank, world, active=act)
+            if rank >= act:
+                assert win is None
+            else:
+                assert torch.equal(win, clip[rank * L: rank * L + L + 4]), (rank, rnd)
+        want = "allgather" if (mode == "allgather" or break_p2p) else "p2p"
+        assert halo.form == want and halo.fell_back == bool(break_p2p and mode == "auto"), (halo.form, halo.fell_back)
+        assert bool(logs) == halo.fell_back
+        failed = False
+    except RuntimeError as e:
+        failed = "point to point" in str(e)
+    assert failed == (mode == "p2p" and bool(break_p2p)), (mode, break_p2p, failed)       # a forced p2p run fails on EVERY rank, nobody hangs
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode,break_p2p,active", [(2, "auto", None, 2), (3, "p2p", None, 2), (2, "allgather", None, 2), (4, "auto", (0, 1, 2, 3), 3),
+                                                         (3, "p2p", (0, 1, 2), 3)])
+def test_halo_form_selection_and_fallback_gloo(world, mode, break_p2p, active):
+    """clip_parallel.Halo (bench.py / the CLIs' --halo): point to point by default; when the first exchange raises, ALL ranks learn it through one
+    all-reduce and continue with the all-gather form (logged once); --halo p2p turns the same failure into an error on every rank; --halo allgather
+    never tries point to point.  Every later round -- including one with idle ranks -- uses the form chosen in the first."""
+    mp.spawn(_halo_form_worker, args=(world, _free_port(), 4, mode, break_p2p, active), nprocs=world, join=True)
+
+
 def test_cli_refuses_clip_parallel_modes_it_cannot_run():
     """--gpus N with one_len < 2 (a halo would span two neighbour windows) or with --host_io (a single-process mode) must stop in the argument
     parser of EVERY rank, before any process group exists (the single-process CLI accepts both)."""
