@@ -79,7 +79,7 @@ typedef struct sn_conv_desc {
     int flags;           /* SN_CONV_TILE_KERNEL: run single-input 3x3 stride-1 convs on the one-workgroup-per-tile kernel instead of the
                             persistent streaming kernel (csrc/sn_conv3p.hip) -- A/B measurements; results are bit-identical.
                             Bits 4..7: persistent workgroups per CU of the streaming kernel, 0 = the library's choice; bit 8: the streaming kernel also
-                            where the library prefers the tile kernel (measurements) */
+                            where the library prefers the tile kernel; bit 9: its residual operand through registers instead of LDS (measurements) */
 } sn_conv_desc;
 #define SN_CONV_TILE_KERNEL 1
 int sn_conv2d(const sn_conv_desc* d, void* stream);   /* d is a HOST pointer, read during the call */

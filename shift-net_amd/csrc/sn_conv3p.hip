@@ -49,6 +49,12 @@ __device__ __forceinline__ float mul_then_add(float a, float b, float c) {
     return r;
 }
 
+// 64 lanes x 16 bytes, global (range-checked buffer) -> LDS at the wave-uniform address dst + lane * 16.  A device-only helper: the builtin (and its
+// address-space cast) written more than once inside the __global__ body itself makes hipcc 7.2 silently drop the kernel's HOST stub.
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t rs, char* dst, int voffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)dst, 16, voffset, 0, 0, 0);
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t frame_rsrc(const bf16_t* base, int frame_bytes) {
@@ -60,13 +66,17 @@ constexpr int c3p_waves(int mt) { return mt == 1 ? 4 : mt == 2 ? 3 : 2; }      /
 // D: tiles in flight ahead of the one being computed (D + 1 LDS buffers).  MODE: the epilogue, fixed at compile time (no wave-uniform branches
 // per N-tile): 0 bias only (conv_trans); 1 PReLU with a slope in [0, 1] + per-wave channel sums (first conv of a CAB); 2 CALayer scale +
 // residual (its second conv).  Any other combination stays on the tile kernel.
-template <int MT, int CS, int TH, int D, int MODE>
+// RL (MODE 2): the residual operand's tile is staged in LDS by the loader as well (no load at all in the compute waves); otherwise the compute
+// waves fetch it into registers one tile ahead.
+template <int MT, int CS, int TH, int D, int MODE, bool RL = false>
 __global__ __launch_bounds__(320, c3p_waves(MT)) void conv3p_kernel(const C3P P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TW = 32, RH = TH + 2, RW = TW + 2, NPB = CS / 8, PSB = CS * 2;
     constexpr int KTOT = 9 * CS, KS = (KTOT + 31) / 32;
     constexpr int ROWP = RW * NPB, NITEM = RH * ROWP, NDMA = (NITEM + 63) / 64, XBUF = NDMA * 1024;
-    constexpr int NBUF = D + 1, BUFSZ = XBUF, NL = NDMA;
+    static_assert(!RL || MODE == 2, "residual staging belongs to MODE 2");
+    constexpr int RDMA = RL ? (TH * TW * NPB) / 64 : 0;             // residual tile, [row][pixel][CS] linear: a tile row is one contiguous run of 32 * CS * 2 bytes
+    constexpr int NBUF = D + 1, BUFSZ = XBUF + RDMA * 1024, NL = NDMA + RDMA;
     constexpr bool WLDS = MT * KS > 16;                            // weights: registers up to 64 per lane, else staged once into LDS (1 KB per fragment)
     constexpr int WBYTES = WLDS ? MT * KS * 1024 : 0;
     constexpr int RPW = TH / 4, NTW = RPW * 2;                     // rows / N-tiles (16 pixels) per compute wave
@@ -109,28 +119,43 @@ __global__ __launch_bounds__(320, c3p_waves(MT)) void conv3p_kernel(const C3P P)
             voff[k] = r * rowpitch + j * 16;
             pxk[k] = j / NPB;
         }
-        auto issue = [&](int ft, int ftx, int fty, int buf) {
-            const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P.in + (size_t)ft * frame_elems, frame_bytes);
-            const int ix0 = ftx * TW - 1;
-            const int o = ((fty * TH - 1) * P.w + ix0) * PSB;                       // may be negative: 32-bit wrap -> out of range -> 0
-            const bool edge = ftx == 0 || ix0 + RW > P.w;                           // wave-uniform
-            char* const dst = xbufs + buf * BUFSZ;
-            // (one loop with the wave-uniform test inside: written as two loops, hipcc 7.2 silently drops the kernel's HOST stub)
+        int rvoff[RL ? RDMA : 1];
+        if constexpr (RL) {
 #pragma unroll
-            for (int k = 0; k < NDMA; ++k) {
-                int vo = voff[k] + o;
-                if (edge) { const int gx = ix0 + pxk[k]; vo = (gx < 0 || gx >= P.w) ? (int)0x80000000 : vo; }      // left / right of the image: reads 0
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(dst + k * 1024), 16, vo, 0, 0, 0);
+            for (int k = 0; k < RDMA; ++k) {
+                const int i = k * 64 + lane, row = i / (TW * NPB), rem = i - row * (TW * NPB);
+                rvoff[k] = row * rowpitch + rem * 16;
             }
-        };
-        int ft = t, ftx = tx, fty = ty;                             // the tile the next issue() fetches
-        auto advance = [&]() { if (++fty == P.nty) { fty = 0; if (++ftx == P.ntx) { ftx = 0; ++ft; } } };
-        int issued = 0;
-        for (; issued < D && issued < n; ++issued) { issue(ft, ftx, fty, issued); advance(); }
-        for (int i = 0; i < n; ++i) {
-            if (n - 1 - i >= D - 1) wait_vmcnt<NL * (D - 1)>(); else wait_vmcnt<0>();      // tile i has landed (the newer ones may be in flight)
-            __builtin_amdgcn_s_barrier();
-            if (issued < n) { issue(ft, ftx, fty, issued % NBUF); advance(); ++issued; }      // into the buffer tile i - 1 was computed from
+        }
+        // tiles first .. first + D - 1 are requested before the first barrier, tile i + D right after barrier i (into the buffer tile i - 1 was computed from)
+        int ft = t, ftx = tx, fty = ty;                             // the tile the next request fetches
+        for (int i = -D; i < n; ++i) {
+            if (i >= 0) {
+                if (n - 1 - i >= D - 1) wait_vmcnt<NL * (D - 1)>(); else wait_vmcnt<0>();      // tile i has landed (the newer ones may be in flight)
+                __builtin_amdgcn_s_barrier();
+            }
+            const int j = i + D;
+            if (j < n) {
+                const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P.in + (size_t)ft * frame_elems, frame_bytes);
+                const int ix0 = ftx * TW - 1;
+                const int o = ((fty * TH - 1) * P.w + ix0) * PSB;                   // may be negative: 32-bit wrap -> out of range -> 0
+                const bool edge = ftx == 0 || ix0 + RW > P.w;                       // wave-uniform
+                char* const dst = xbufs + (j % NBUF) * BUFSZ;
+#pragma unroll
+                for (int k = 0; k < NDMA; ++k) {
+                    int vo = voff[k] + o;
+                    if (edge) { const int gx = ix0 + pxk[k]; vo = (gx < 0 || gx >= P.w) ? (int)0x80000000 : vo; }      // left / right of the image: reads 0
+                    dma16(rs, dst + k * 1024, vo);
+                }
+                if constexpr (RL) {                                                 // rows below the frame read 0; columns right of it land in pixels nobody stores
+                    const __amdgpu_buffer_rsrc_t rr = frame_rsrc(P.res + (size_t)ft * frame_elems, frame_bytes);
+                    const int o2 = ((fty * TH) * P.w + ftx * TW) * PSB;
+#pragma unroll
+                    for (int k = 0; k < RDMA; ++k)
+                        dma16(rr, dst + XBUF + k * 1024, rvoff[k] + o2);
+                }
+                if (++fty == P.nty) { fty = 0; if (++ftx == P.ntx) { ftx = 0; ++ft; } }
+            }
         }
         return;
     }
@@ -194,10 +219,10 @@ __global__ __launch_bounds__(320, c3p_waves(MT)) void conv3p_kernel(const C3P P)
     // hipcc's counted vmcnt waits for them without draining those stores.
     // (two named sets used alternately by a tile loop unrolled twice: with one set plus a copy per tile hipcc hoists the copy -- and with it the
     // wait for loads issued a moment ago -- into the MFMA phase)
-    typedef rword_t rset_t[MODE == 2 ? NTW : 1][MODE == 2 ? NP : 1];
+    typedef rword_t rset_t[(MODE == 2 && !RL) ? NTW : 1][(MODE == 2 && !RL) ? NP : 1];
     rset_t rA, rB;
     auto load_res = [&](rset_t& rnxt, int ft, int ftx, int fty) __attribute__((always_inline)) {
-        if constexpr (MODE == 2) {
+        if constexpr (MODE == 2 && !RL) {
             const __amdgpu_buffer_rsrc_t rr = frame_rsrc(P.res + (size_t)ft * frame_elems, frame_bytes);
             const int o2 = ((fty * TH) * P.w + ftx * TW) * PSB;
 #pragma unroll
@@ -235,8 +260,9 @@ __global__ __launch_bounds__(320, c3p_waves(MT)) void conv3p_kernel(const C3P P)
 
     // one N-tile of the epilogue; MASKED: the tile crosses the right / bottom image border (pixels beyond it must reach neither a store nor the sums)
     // (plain lambdas called with literal arguments and force-inlined: generic lambdas in a __global__ template lose the host-side stub)
-    auto finish = [&](const f32x4_t (&acc)[MT][NH], const rset_t& rres, const int N0, const __amdgpu_buffer_rsrc_t ro, int o2, const bool MASKED, int ylim,
-                      int xlim) __attribute__((always_inline)) {
+    const int raddr = XBUF + ((wv * RPW) * TW + p) * PSB + c0 * 2;   // RL: this lane's channels of pixel p of the wave's first row in the staged residual tile
+    auto finish = [&](const f32x4_t (&acc)[MT][NH], const rset_t& rres, const char* xs, const int N0, const __amdgpu_buffer_rsrc_t ro, int o2, const bool MASKED,
+                      int ylim, int xlim) __attribute__((always_inline)) {
 #pragma unroll
         for (int nh = 0; nh < NH; ++nh) {
             const int nn = N0 + nh, rr = nn >> 1, xb = nn & 1;
@@ -254,7 +280,9 @@ __global__ __launch_bounds__(320, c3p_waves(MT)) void conv3p_kernel(const C3P P)
             if constexpr (MODE == 2) {      // round(conv * scale) + x: the tile kernel's two steps sit in different blocks and are NOT contracted to an fma
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    const rword_t qv = rres[nn][(m * 8) / PIECE];
+                    rword_t qv;
+                    if constexpr (RL) qv = *(const rword_t*)(xs + raddr + (rr * TW + xb * 16) * PSB + ((m * 8) / PIECE) * PIECE);
+                    else qv = rres[nn][(m * 8) / PIECE];
                     const unsigned lo = qv[((m * 8) % PIECE) / 4], hi = qv[((m * 8) % PIECE) / 4 + 1];
                     v[m][0] = mul_then_add(v[m][0], osc[m].x, bf_lo(lo)); v[m][1] = mul_then_add(v[m][1], osc[m].y, bf_hi(lo));
                     v[m][2] = mul_then_add(v[m][2], osc[m].z, bf_lo(hi)); v[m][3] = mul_then_add(v[m][3], osc[m].w, bf_hi(hi));
@@ -330,8 +358,8 @@ __global__ __launch_bounds__(320, c3p_waves(MT)) void conv3p_kernel(const C3P P)
                 __builtin_amdgcn_sched_barrier(0);
             }
             // ---- epilogue (arithmetic of conv3_fast_kernel): PReLU + channel sums | CALayer scale + residual; store ----
-            if (full) finish(acc, rres, N0, ro, o2, false, 0, 0);
-            else finish(acc, rres, N0, ro, o2, true, P.h - oy0 - wv * RPW, P.w - ox0 - p);
+            if (full) finish(acc, rres, xs, N0, ro, o2, false, 0, 0);
+            else finish(acc, rres, xs, N0, ro, o2, true, P.h - oy0 - wv * RPW, P.w - ox0 - p);
         }
         // next tile of the chunk (down the column, then the next column, then the next frame)
         if (--sleft == 0) {                                          // the segment ends with this tile (after S tiles or with the column)
@@ -383,24 +411,26 @@ C3PPlan c3p_plan(int T, int h, int w, int th, int ncu, int wgs) {
     return p;
 }
 
-template <int MT, int CS, int TH, int D, int MODE>
-int launch_conv3p_mode(const C3P& P, const C3PPlan& pl, hipStream_t st) {
-    constexpr int NPB = CS / 8, NDMA = ((TH + 2) * 34 * NPB + 63) / 64, KS = (9 * CS + 31) / 32;
-    const size_t lds = (size_t)(D + 1) * NDMA * 1024 + (MT * KS > 16 ? MT * KS * 1024 : 0);
-    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv3p_kernel<MT, CS, TH, D, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+template <int MT, int CS, int TH, int D, int MODE, bool RL>
+int launch_conv3p_mode(const C3P& K, const C3PPlan& pl, hipStream_t st) {
+    constexpr int NPB = CS / 8, NDMA = ((TH + 2) * 34 * NPB + 63) / 64, KS = (9 * CS + 31) / 32, RDMA = RL ? (TH * 32 * NPB) / 64 : 0;
+    C3P P = K;
+    P.ntx = pl.ntx; P.nty = pl.nty; P.S = pl.S; P.nseg = pl.nseg; P.nsg = pl.nsg; P.qs = pl.qs; P.pool_rows = pl.pool_rows;
+    const size_t lds = (size_t)(D + 1) * (NDMA + RDMA) * 1024 + (MT * KS > 16 ? MT * KS * 1024 : 0);
+    if (lds > 160 * 1024) return SN_EINVAL;
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)conv3p_kernel<MT, CS, TH, D, MODE, RL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return SN_ELAUNCH;
-    hipLaunchKernelGGL((conv3p_kernel<MT, CS, TH, D, MODE>), dim3(pl.grid), dim3(320), lds, st, P);
+    hipLaunchKernelGGL((conv3p_kernel<MT, CS, TH, D, MODE, RL>), dim3(pl.grid), dim3(320), lds, st, P);
     return sn_check_launch();
 }
 
-template <int MT, int CS, int TH, int D>
+// D2 / RL2: prefetch depth and residual staging of the MODE 2 instance (the residual tile costs LDS: fewer buffers or fewer workgroups per CU)
+template <int MT, int CS, int TH, int D, int D2, bool RL2>
 int launch_conv3p(const C3P& K, const C3PPlan& pl, int mode, hipStream_t st) {
-    C3P P = K;
-    P.ntx = pl.ntx; P.nty = pl.nty; P.S = pl.S; P.nseg = pl.nseg; P.nsg = pl.nsg; P.qs = pl.qs; P.pool_rows = pl.pool_rows;
     switch (mode) {
-        case 0: return launch_conv3p_mode<MT, CS, TH, D, 0>(P, pl, st);
-        case 1: return launch_conv3p_mode<MT, CS, TH, D, 1>(P, pl, st);
-        case 2: return launch_conv3p_mode<MT, CS, TH, D, 2>(P, pl, st);
+        case 0: return launch_conv3p_mode<MT, CS, TH, D, 0, false>(K, pl, st);
+        case 1: return launch_conv3p_mode<MT, CS, TH, D, 1, false>(K, pl, st);
+        case 2: return launch_conv3p_mode<MT, CS, TH, D2, 2, RL2>(K, pl, st);
         default: return SN_EINVAL;
     }
 }
@@ -439,17 +469,24 @@ static int c3p_ncu() {
     return ncu;
 }
 // persistent workgroups per CU (LDS: 3 buffers of 11 / 16 KB; registers: 5-wave workgroups); bits 4..7 of sn_conv_desc.flags override it (measurements)
-static int c3p_wgs(const sn_conv_desc* d, int key) {
+// MODE 2 may stage the residual tile in LDS (RL); bit 9 of flags asks for the register form everywhere (measurements)
+// (measured, conv2 of a CAB, LDS vs registers: 24 channels 141 vs 153 us at 20 x 360 x 640 and 1327 vs 1347 at 52 x 720 x 1280; 40 channels 591 vs 576;
+// 48 channels 184 vs 182: staged for <= 24 channels, registers above, where the tile would also cost a prefetch buffer)
+static bool c3p_rl(const sn_conv_desc* d, int key, int mode) { return mode == 2 && (key == 1016 || key == 2024) && !(d->flags & 512); }
+static int c3p_wgs(const sn_conv_desc* d, int key, int mode) {
     const int o = (d->flags >> 4) & 15;
-    // 16 channels: 3 (measured best of 1-4); 24 channels: 2 (one: +6 % time); >= 40 channels: weights (36-72 KB) + buffers fill the LDS of a CU
-    return o ? o : (key == 1016 ? 3 : key == 2024 ? 2 : 1);
+    if (o) return o;
+    // 16 channels: 3 (measured best of 1-4), 2 with the residual tile in LDS (3 x 19 KB per workgroup); 24 channels: 2 (one: +6 % time);
+    // >= 40 channels: weights (36-72 KB) + buffers fill the LDS of a CU
+    if (key == 1016) return c3p_rl(d, key, mode) ? 2 : 3;
+    return key == 2024 ? 2 : 1;
 }
 
 // rows of `pool` per frame when sn_conv2d runs this descriptor on the streaming kernel; 0: it will not (no instance, or no device to plan for)
 int sn_conv3p_pool_rows(const sn_conv_desc* d) {
     const int key = sn_conv3p_key(d, true), ncu = key ? c3p_ncu() : 0;
     if (!key || !ncu) return 0;
-    return c3p_plan(d->T, d->h_out, d->w_out, 8, ncu, c3p_wgs(d, key)).pool_rows;
+    return c3p_plan(d->T, d->h_out, d->w_out, 8, ncu, c3p_wgs(d, key, 1)).pool_rows;
 }
 
 int sn_conv3p_launch(const sn_conv_desc* d, void* stream) {
@@ -460,15 +497,17 @@ int sn_conv3p_launch(const sn_conv_desc* d, void* stream) {
     K.wfrag = (const uint4*)d->wfrag; K.bias = d->bias; K.oscale = d->oscale; K.oscale_stride = d->oscale_stride;
     K.pool = d->pool; K.pool_rows = 0; K.act = d->act; K.prelu = d->prelu;
     K.T = d->T; K.h = d->h_out; K.w = d->w_out;
-    const C3PPlan pl = c3p_plan(d->T, d->h_out, d->w_out, 8, ncu, c3p_wgs(d, key));
-    hipStream_t st = (hipStream_t)stream;
     const int mode = c3p_mode(d);
+    const C3PPlan pl = c3p_plan(d->T, d->h_out, d->w_out, 8, ncu, c3p_wgs(d, key, mode));
+    hipStream_t st = (hipStream_t)stream;
+    const bool rl = c3p_rl(d, key, mode);
+    // <M-tiles, channels, tile rows, prefetch depth, prefetch depth of MODE 2, MODE 2 with the residual in LDS>
     switch (key) {
-        case 1016: return launch_conv3p<1, 16, 8, 2>(K, pl, mode, st);
-        case 2024: return launch_conv3p<2, 24, 8, 2>(K, pl, mode, st);
-        case 3040: return launch_conv3p<3, 40, 8, 2>(K, pl, mode, st);
-        case 3048: return launch_conv3p<3, 48, 8, 2>(K, pl, mode, st);
-        case 4064: return launch_conv3p<4, 64, 8, 1>(K, pl, mode, st);      // 72 KB of weights: two buffers of 43 KB
+        case 1016: return rl ? launch_conv3p<1, 16, 8, 2, 2, true>(K, pl, mode, st) : launch_conv3p<1, 16, 8, 2, 2, false>(K, pl, mode, st);
+        case 2024: return rl ? launch_conv3p<2, 24, 8, 2, 1, true>(K, pl, mode, st) : launch_conv3p<2, 24, 8, 2, 2, false>(K, pl, mode, st);
+        case 3040: return launch_conv3p<3, 40, 8, 2, 2, false>(K, pl, mode, st);
+        case 3048: return launch_conv3p<3, 48, 8, 2, 2, false>(K, pl, mode, st);
+        case 4064: return launch_conv3p<4, 64, 8, 1, 1, false>(K, pl, mode, st);      // 72 KB of weights: two buffers of 43 KB
         default: return SN_EINVAL;
     }
 }

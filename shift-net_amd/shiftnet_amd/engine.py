@@ -252,6 +252,7 @@ class Engine:
     # single-input 3x3 stride-1 convs: the persistent streaming kernel (csrc/sn_conv3p.hip) or, SN_CONV_TILES=1, the one-workgroup-per-tile kernel
     conv_tiles = os.environ.get("SN_CONV_TILES", "0") == "1"
     conv_stream_all = os.environ.get("SN_CONV_STREAM_ALL", "0") == "1"      # measurements / tests: the streaming kernel also where the library prefers the tile kernel
+    conv_res_regs = os.environ.get("SN_CONV_RES_REGS", "0") == "1"          # measurements: the residual operand of the streaming kernel through registers, not LDS
     conv_wgs = int(os.environ.get("SN_CONV_WGS", "0"))            # measurements: persistent workgroups per CU of the streaming kernel (0: the library's choice)
 
     def conv(self, name: str, ins: Sequence[Act], *, stride: int = 1, pad: Optional[int] = None, prelu: Optional[float] = None,
@@ -287,7 +288,7 @@ class Engine:
             out_act = Act(o, c_log)
             d.out, d.cs_out, d.c_out = o.data_ptr(), cs_out, cout
         d.out_mode = out_mode
-        d.flags = L.SN_CONV_TILE_KERNEL if self.conv_tiles else ((self.conv_wgs << 4) | (256 if self.conv_stream_all else 0))
+        d.flags = L.SN_CONV_TILE_KERNEL if self.conv_tiles else ((self.conv_wgs << 4) | (256 if self.conv_stream_all else 0) | (512 if self.conv_res_regs else 0))
         if res is not None:
             assert out_mode == 0 and res.dims == out_act.dims
             d.res = res.t.data_ptr()

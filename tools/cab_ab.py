@@ -41,6 +41,10 @@ def main():
             e.cab_fused = v if v in ("8", "16") else "0"            # per CU; "8" / "16": the fused tile form
             e.conv_tiles = v == "t"
             e.conv_wgs = int(v[1:]) if v.startswith("w") else 0
+            e.conv_stream_all = v != "d"                            # "d": the library's default routing (16-channel conv2 on the tile kernel)
+            e.conv_res_regs = v.startswith("r")                     # "r": residual through registers; "rN": with N workgroups per CU
+            if v.startswith("r") and len(v) > 1:
+                e.conv_wgs = int(v[1:])
             engs[v] = e
         cs = (c + 7) // 8 * 8
         x = torch.zeros((T, h, w, cs), dtype=torch.bfloat16, device=dev)
