@@ -28,10 +28,10 @@ import torch.distributed as dist  # noqa: E402
 
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS command line with --no-parity --no-cpu-baseline (tools/make_profiles_r04.sh), one file
 # per preset; every file records the hash of the kernel sources it was measured on and is ignored when they have changed since.
-PMC_FILES = {(2, "bf16"): "r05_pmc_hbm_traffic_cfg2.json", (3, "bf16"): "r05_pmc_hbm_traffic_cfg3.json",
+PMC_FILES = {(2, "bf16"): "r06_pmc_hbm_traffic_cfg2.json", (3, "bf16"): "r06_pmc_hbm_traffic_cfg3.json",
              # config 4: ONE of the CLI's four quadrants traced (bench.py --config 4 --one-quadrant: a quarter of the ~2900 launches, the four differ
              # only in their crop); tools/pmc_summary.py scales the per-window totals by 4 (PMC_WINDOW_FRACTION=0.25, recorded in the file)
-             (4, "bf16"): "r05_pmc_hbm_traffic_cfg4_bf16.json"}
+             (4, "bf16"): "r06_pmc_hbm_traffic_cfg4_bf16.json"}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 VARIANT = "gshift_deblur2"
 H, W, ONE_LEN = 720, 1280, 16
@@ -123,6 +123,9 @@ def symbol_key(sym):
                      ("ingest_kernel", "sn_ingest")):
         if pat in s:
             return key
+    m = re.search(r"conv3p_kernel<(\d+), ", s)
+    if m:
+        return f"sn_conv2d<mt{m.group(1)},8x32>"
     m = re.search(r"cab_fused_kernel<(\d+), ", s)
     if m:
         return f"sn_cab_fused<mt{m.group(1)}>"
@@ -397,8 +400,13 @@ def main():
         barrier()
         log("warm-up done, timing")
         t0 = time.perf_counter()
+        step_ev = []                                    # per-step GPU time: events on the launching stream around every step (the median is reported beside the mean)
         for _ in range(args.steps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             out = step(timed=True)
+            e1.record()
+            step_ev.append((e0, e1))
         torch.cuda.synchronize()
         own_elapsed = time.perf_counter() - t0          # this rank alone, before it waits for the others
         barrier()
@@ -424,6 +432,24 @@ def main():
         log(f"timed {args.steps} steps in {elapsed:.3f} s; profiling one extra step with stream events")
         ms = elapsed / args.steps * 1e3
         fps = world * L * args.steps / elapsed
+        step_ms = sorted(a.elapsed_time(b) for a, b in step_ev)
+        ms_median = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
+        # Host <-> device transfers of a window as the CLIs ship it (uint8 frames in, uint8 restored frames out; pinned host buffers), measured here,
+        # NOT part of `value` ("excluded but reported")
+        hin = torch.empty((L + 4, h, w, 3), dtype=torch.uint8).pin_memory()
+        hout = torch.empty((L, h, w, 3), dtype=torch.uint8).pin_memory()
+        din, dout = torch.empty_like(hin, device=dev), torch.empty_like(hout, device=dev)
+        xfer = {}
+        for nm, src, dst in (("h2d_uint8_in_ms", hin, din), ("d2h_uint8_out_ms", dout, hout)):
+            ts = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); dst.copy_(src, non_blocking=True); e1.record(); torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            xfer[nm] = round(sorted(ts)[2], 3)
+        xfer["bytes_in"], xfer["bytes_out"] = hin.numel(), hout.numel()
+        xfer["frames_per_s_including_transfers"] = round(world * L / ((ms + xfer["h2d_uint8_in_ms"] + xfer["d2h_uint8_out_ms"]) * 1e-3), 3)
+        del hin, hout, din, dout
         # ---- per-kernel durations, live, from events on the launch stream (one extra, untimed step) -----------
         eng = net.prepare()
         eng.prof = []
@@ -476,7 +502,7 @@ def main():
             if k in ("sn_gsts_cab2_phase1", "sn_cab1_phase1"):
                 return "cab_phase1r_kernel (sn_gsts_cab2_phase1 + sn_cab1_phase1)"
             if k.startswith("sn_conv2d<") or k.startswith("sn_cab_stats<") or k.startswith("sn_cab_fused<"):
-                return "dense convs (conv3_fast_kernel + conv_mfma_kernel + cab_fused_kernel, every instance)"
+                return "dense convs (conv3p_kernel + conv3_fast_kernel + conv_mfma_kernel, every instance)"
             return k
         groups = {}
         for k, v in agg.items():
@@ -546,7 +572,8 @@ def main():
         dlabel = {"bf16": "bf16", "fp16": "fp16", "fp32": "fp32"}[args.dtype]
         result = {
             "metric": f"restored frames/sec at {w}x{h} T={L} {dlabel}", "value": round(fps, 3), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "ms_per_step_median": round(ms_median, 3),
+            "ms_per_step_min_max": [round(step_ms[0], 3), round(step_ms[-1], 3)], "host_transfers": xfer,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
             # module dtype; fp16 / bf16 modules both compute with bf16 storage + fp32 accumulation
             "dtype": {"bf16": "bf16", "fp16": "fp16 module on bf16 storage",

@@ -16,6 +16,8 @@
 #include "sn_common.h"
 #include "../../include/shiftnet_hip.h"
 
+int sn_cabp_launch(const sn_conv_desc* a, const sn_conv_desc* b, void* stream);      // sn_conv3p.hip
+
 namespace {
 
 struct CabK {
@@ -325,6 +327,10 @@ int sn_cab_fused(const sn_conv_desc* a, const sn_conv_desc* b, int tile_rows, vo
     sn_clear_error();
     const int key = cabf_key(a, b);
     if (!key) return SN_EINVAL;
+    if (tile_rows == 0) {                                   // the streaming form (csrc/sn_conv3p.hip: cabp_kernel); 8 / 16: the one-workgroup-per-tile form below
+        if (!a->in[0] || a->res || a->res2 || a->oscale || b->pool || b->act != 0 || !b->out || b->res != a->in[0] || a->h_in < 2 || a->w_in < 2) return SN_EINVAL;
+        return sn_cabp_launch(a, b, stream);
+    }
     // conv1: x -> PReLU(conv + bias), nothing else; conv2: mid -> conv (+ bias) * oscale + res (= x) + res2
     if (!a->in[0] || a->res || a->res2 || a->oscale || b->pool || b->act != 0 || !b->out || b->res != a->in[0]) return SN_EINVAL;   // (a->pool / a->out: sn_cab_stats')
     if (b->oscale && b->oscale_stride < 16 * b->mt) return SN_EINVAL;

@@ -17,7 +17,7 @@
 // the streaming form of the single-input 3x3 convs (sn_conv3p.hip); sn_conv2d routes to it unless the descriptor asks for the tile kernel
 int sn_conv3p_key(const sn_conv_desc* d, bool want_pool);   // want_pool: the caller is about to attach a pool buffer (sn_conv_pool_blocks)
 int sn_conv3p_pool_rows(const sn_conv_desc* d);
-int sn_conv3p_launch(const sn_conv_desc* d, void* stream);
+int sn_conv3p_launch(const sn_conv_desc* d, int lines_len, void* stream);
 
 namespace {
 
@@ -838,7 +838,7 @@ int sn_conv2d(const sn_conv_desc* d, void* stream) {
     K.ps = d->stride == 1 ? 16 * sn_lds_slots(blocks) : ((blocks & 1) ? K.cv * 2 : K.cv * 2 + 16);     // stride 2: odd slot count (pixels 2 apart)
     K.rh = K.rw = 0; K.lines_len = 0;
     if (!(d->flags & SN_CONV_TILE_KERNEL) && sn_conv3p_key(d, false)) {
-        const int rc = sn_conv3p_launch(d, stream);
+        const int rc = sn_conv3p_launch(d, 0, stream);
         if (rc != SN_EINVAL) return rc;                      // (SN_EINVAL: no device to plan for -- fall through to the tile kernel's own checks)
     }
     int th, tw; conv_tile(d, &th, &tw);
@@ -898,6 +898,10 @@ int sn_cab_stats(const sn_conv_desc* d, int lines_len, void* stream) {
     sn_clear_error();
     if (!d || !d->out || !d->pool || !d->wfrag || !d->in[0] || d->res || d->res2 || d->oscale || d->cs_in != d->cs_out) return SN_EINVAL;
     if (lines_len < (d->h_out > d->w_out ? d->h_out : d->w_out) || d->h_out < 2 || d->w_out < 2) return SN_EINVAL;
+    if (!(d->flags & SN_CONV_TILE_KERNEL) && sn_conv3p_key(d, false)) {      // the streaming kernel's statistics mode (pool rows: sn_conv_pool_blocks(d))
+        const int rc = sn_conv3p_launch(d, lines_len, stream);
+        if (rc != SN_EINVAL) return rc;
+    }
     const int key = conv3_key(d);
     if (key != 1016 && key != 2024) return SN_EINVAL;
     ConvK K;

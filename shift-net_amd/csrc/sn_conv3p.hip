@@ -28,9 +28,12 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 struct C3P {
     const bf16_t* in; const bf16_t* res; bf16_t* out;
     const uint4* wfrag; const float* bias; const float* oscale; int oscale_stride;
+    const uint4* w2; const float* b2;      // cabp_kernel: the CAB's second conv
     float* pool; int pool_rows;
     int act; float prelu;
     int T, h, w, ntx, nty;
+    int dbg;                     // measurements only (sn_conv_desc.flags bits 12..14): 1 no DMA, 2 no B reads / MFMAs, 4 no stores -- wrong results
+    int lines_len;               // MODE 3: `out` is the border-line buffer [T][4][lines_len][CS]
     int S, nseg, nsg, qs;        // a tile column is cut into nseg segments of S tiles (the last one shorter); nsg segments in all; qs per chunk (workgroup)
 };
 
@@ -65,7 +68,8 @@ constexpr int c3p_waves(int mt) { return mt == 1 ? 4 : mt == 2 ? 3 : 2; }      /
 
 // D: tiles in flight ahead of the one being computed (D + 1 LDS buffers).  MODE: the epilogue, fixed at compile time (no wave-uniform branches
 // per N-tile): 0 bias only (conv_trans); 1 PReLU with a slope in [0, 1] + per-wave channel sums (first conv of a CAB); 2 CALayer scale +
-// residual (its second conv).  Any other combination stays on the tile kernel.
+// residual (its second conv); 3 = 1 without the store: only the border lines of the result (statistics pass of the fused CAB).  Any other
+// combination stays on the tile kernel.
 // RL (MODE 2): the residual operand's tile is staged in LDS by the loader as well (no load at all in the compute waves); otherwise the compute
 // waves fetch it into registers one tile ahead.
 template <int MT, int CS, int TH, int D, int MODE, bool RL = false>
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(320, c3p_waves(MT)) void conv3p_kernel(const C3P P)
                 __builtin_amdgcn_s_barrier();
             }
             const int j = i + D;
-            if (j < n) {
+            if (j < n && !(P.dbg & 1)) {
                 const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P.in + (size_t)ft * frame_elems, frame_bytes);
                 const int ix0 = ftx * TW - 1;
                 const int o = ((fty * TH - 1) * P.w + ix0) * PSB;                   // may be negative: 32-bit wrap -> out of range -> 0
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(320, c3p_waves(MT)) void conv3p_kernel(const C3P P)
     // this wave's channel sums over ONE segment -> pool row (column, segment, wave) of the frame: the rows are a property of the image (not of
     // the frame's position in the window, the chunking or the device), so equal frames give bit-equal sums wherever they sit
     auto flush_pool = [&](int ft, int ftx, int fsg) {
-        if constexpr (MODE == 1) {
+        if constexpr (MODE == 1 || MODE == 3) {
             const int row = (ftx * P.nseg + fsg) * 4 + wv;
             float* dst = P.pool + ((size_t)ft * P.pool_rows + row) * (16 * MT);
 #pragma unroll
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(320, c3p_waves(MT)) void conv3p_kernel(const C3P P)
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 v[m][0] = acc[m][nh][0]; v[m][1] = acc[m][nh][1]; v[m][2] = acc[m][nh][2]; v[m][3] = acc[m][nh][3];
-                if constexpr (MODE == 1) {
+                if constexpr (MODE == 1 || MODE == 3) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {                    // max(x, a x), a in [0, 1]; the bare instruction: fmaxf adds a canonicalising v_max per operand
                         v[m][r] = max_bare(v[m][r], slope * v[m][r]);
@@ -290,16 +294,36 @@ __global__ __launch_bounds__(320, c3p_waves(MT)) void conv3p_kernel(const C3P P)
             }
             bool ok = true;
             if (MASKED) ok = (rr < ylim) && (xb * 16 < xlim);
-            if constexpr (MODE == 1) {
+            if constexpr (MODE == 1 || MODE == 3) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) psum[m][r] += (MASKED && !ok) ? 0.f : v[m][r];
             }
+            if constexpr (MODE == 3) {
+                // statistics pass of the fused CAB: nothing is stored but the first / last rows and columns of the result, bf16-rounded like the tensor
+                // would be, into the line buffer P.out = [T][4][lines_len][CS] (row 0, row h-1, column 0, column w-1).  MASKED is set for every tile on
+                // the image border (and for ragged ones).
+                if (MASKED && ok && c0 < CS) {
+                    const int oy = ty * TH + wv * RPW + rr, ox = tx * TW + xb * 16 + p;
+                    bf16_t* const lb = P.out + (size_t)t * 4 * P.lines_len * CS + c0;
+                    bf16_t* tgt[4] = {oy == 0 ? lb + (size_t)ox * CS : nullptr, oy == P.h - 1 ? lb + ((size_t)P.lines_len + ox) * CS : nullptr,
+                                      ox == 0 ? lb + ((size_t)2 * P.lines_len + oy) * CS : nullptr, ox == P.w - 1 ? lb + ((size_t)3 * P.lines_len + oy) * CS : nullptr};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (!tgt[e]) continue;
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            if (c0 + m * 4 < CS) *(uint2*)(tgt[e] + m * 4) = make_uint2(pack_bf2(v[m][0], v[m][1]), pack_bf2(v[m][2], v[m][3]));
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
                 int vo = o2 + ooff[rr][q] + xb * 16 * PSB;
                 if (MASKED) vo = ok ? vo : OOR;
+                if (P.dbg & 4) vo = OOR;
                 if constexpr (PIECE == 16) {
                     const int m = q * 2;
                     const rword_t d = {pack_bf2(v[m][0], v[m][1]), pack_bf2(v[m][2], v[m][3]), pack_bf2(v[m + 1][0], v[m + 1][1]), pack_bf2(v[m + 1][2], v[m + 1][3])};
@@ -332,6 +356,11 @@ __global__ __launch_bounds__(320, c3p_waves(MT)) void conv3p_kernel(const C3P P)
             f32x4_t acc[MT][NH];
             bf16x8_t bq[2][NH], aq[2][WLDS ? MT : 1];
 #pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int nh = 0; nh < NH; ++nh) acc[m][nh] = biasv[m];
+            if (!(P.dbg & 2)) {
+#pragma unroll
             for (int nh = 0; nh < NH; ++nh)
                 bq[0][nh] = as_frag(*(const uint4*)(xs + addr_s[0] + (((N0 + nh) >> 1) * RW + ((N0 + nh) & 1) * 16) * PSB));
             if constexpr (WLDS) {
@@ -357,8 +386,10 @@ __global__ __launch_bounds__(320, c3p_waves(MT)) void conv3p_kernel(const C3P P)
                         acc[m][nh] = mfma16(WLDS ? aq[s & 1][m] : A[WLDS ? 0 : m][WLDS ? 0 : s], bq[s & 1][nh], s == 0 ? biasv[m] : acc[m][nh]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            }
             // ---- epilogue (arithmetic of conv3_fast_kernel): PReLU + channel sums | CALayer scale + residual; store ----
-            if (full) finish(acc, rres, xs, N0, ro, o2, false, 0, 0);
+            const bool plain = full && !(MODE == 3 && (ty == 0 || ty == P.nty - 1 || tx == 0 || tx == P.ntx - 1));      // wave-uniform
+            if (plain) finish(acc, rres, xs, N0, ro, o2, false, 0, 0);
             else finish(acc, rres, xs, N0, ro, o2, true, P.h - oy0 - wv * RPW, P.w - ox0 - p);
         }
         // next tile of the chunk (down the column, then the next column, then the next frame)
@@ -380,6 +411,298 @@ __global__ __launch_bounds__(320, c3p_waves(MT)) void conv3p_kernel(const C3P P)
     for (int i = 0; i < n; i += 2) {
         tile(i, rA, rB);
         if (i + 1 < n) tile(i + 1, rB, rA);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// Fused dense CAB on the streaming structure (pass 2 of the fused CAB; pass 1 is conv3p_kernel<.., MODE 3>, the closed-form CALayer sits between):
+//   out = x + ca * conv2(PReLU(conv1(x) + b1)) + b2-scaled terms exactly as the two-launch form computes them, with `mid` only ever in LDS.
+// Per TH x 32 output tile the loader brings the (TH+4) x 36 region of x; the compute waves run conv1 + PReLU on the (TH+2) x 34 ring conv2 needs
+// (16-pixel N-tiles over the ring's pixels in row-major order, zero outside the image = conv2's zero padding) into one bf16 `mid` tile, meet at
+// a second barrier, and run conv2 from it with the scale / + x (the region's centre) / store epilogue of MODE 2.  Two barriers per tile: "region
+// landed and mid free" and "mid written".  Same operand layouts, k order and roundings as conv3_fast_kernel twice: bit-identical to the two-launch
+// form.  conv1 runs 1.33x (TH = 8) redundantly -- on matrix cores that the ablations of round 6 show idle (the kernel's time is its memory traffic).
+template <int MT, int CS, int TH, int D>
+__global__ __launch_bounds__(320, MT == 1 ? 3 : c3p_waves(MT)) void cabp_kernel(const C3P P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TW = 32, RH = TH + 4, RW = TW + 4, MH = TH + 2, MW = TW + 2, NPB = CS / 8, PSB = CS * 2;
+    constexpr int KTOT = 9 * CS, KS = (KTOT + 31) / 32;
+    constexpr int ROWP = RW * NPB, NITEM = RH * ROWP, NDMA = (NITEM + 63) / 64, XBUF = NDMA * 1024;
+    constexpr int NBUF = D + 1, NL = NDMA;
+    // Weight fragments of both convs: 16 channels in REGISTERS (2 x 5 fragments = 40 per lane; the kernel runs two workgroups per CU, <= 170
+    // registers, and every A fragment read from LDS is a ds_read_b128 on the one LDS pipe that already carries a B read per MFMA: measured
+    // 353 -> see DESIGN.md); 24 channels (2 x 14 fragments) in LDS, 1 KB per fragment.
+    constexpr bool W1L = MT != 1, W2L = MT != 1;
+    constexpr int WSET = MT * KS * 1024, W2OFF = W1L ? WSET : 0, WBYTES = W2OFF + (W2L ? WSET : 0);
+    constexpr int NM = MH * MW, NT1 = (NM + 15) / 16, PER1 = (NT1 + 3) / 4;      // conv1: N-tiles of the ring, per wave (interleaved)
+    constexpr int NH1 = MT == 1 ? 3 : 2;                            // N-tiles per accumulation pass of conv1 / conv2
+    constexpr int RPW = TH / 4, NTW = RPW * 2, NH = MT == 1 ? (NTW < 4 ? NTW : 4) : 2;
+    constexpr int MIDB = (NM * PSB + 15) / 16 * 16;
+    static_assert(TH % 4 == 0 && NL * (D - 1) <= 63 && D >= 1 && PER1 % NH1 == 0 && NTW % NH == 0, "tile / prefetch shape");
+    const int lane = threadIdx.x & 63, wv = wave_id();
+    const int G = (int)gridDim.x, c = ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);
+    const int fseg = c * P.qs, nsegs = min(P.qs, P.nsg - fseg);
+    if (nsegs <= 0) return;                                         // workgroup-uniform
+    int t = fseg / (P.ntx * P.nseg), tx, ty, n = 0;
+    {
+        const int rem = fseg - t * (P.ntx * P.nseg);
+        tx = rem / P.nseg;
+        const int sg = rem - tx * P.nseg;
+        ty = sg * P.S;
+        const int tail = P.nty - (P.nseg - 1) * P.S;
+        for (int k = 0, g2 = sg; k < nsegs; ++k) { n += g2 == P.nseg - 1 ? tail : P.S; if (++g2 == P.nseg) g2 = 0; }
+    }
+    n = __builtin_amdgcn_readfirstlane(n);
+    t = __builtin_amdgcn_readfirstlane(t); tx = __builtin_amdgcn_readfirstlane(tx); ty = __builtin_amdgcn_readfirstlane(ty);
+    const int rowpitch = P.w * PSB, frame_bytes = P.h * rowpitch;
+    const size_t frame_elems = (size_t)P.h * P.w * CS;
+    char* const mids = smem + WBYTES;
+    char* const xbufs = mids + MIDB;
+    if constexpr (W1L || W2L) {
+        for (int i = (int)threadIdx.x; i < MT * KS * 64; i += 320) {
+            if constexpr (W1L) *(uint4*)(smem + i * 16) = P.wfrag[i];
+            if constexpr (W2L) *(uint4*)(smem + W2OFF + i * 16) = P.w2[i];
+        }
+        __syncthreads();
+    }
+
+    if (wv == 4) {
+        // =================================================== LOADER ===================================================
+        int voff[NDMA], pxk[NDMA];
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) {
+            const int i = k * 64 + lane, ic = i < NITEM ? i : NITEM - 1;
+            const int r = ic / ROWP, j = ic - r * ROWP;
+            voff[k] = r * rowpitch + j * 16;
+            pxk[k] = j / NPB;
+        }
+        int ft = t, ftx = tx, fty = ty;
+        for (int i = -D; i < n; ++i) {
+            if (i >= 0) {
+                if (n - 1 - i >= D - 1) wait_vmcnt<NL * (D - 1)>(); else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();                        // region i landed; mid is free (every compute wave is through tile i - 1)
+            }
+            const int j = i + D;
+            if (j < n) {
+                const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P.in + (size_t)ft * frame_elems, frame_bytes);
+                const int ix0 = ftx * TW - 2;
+                const int o = ((fty * TH - 2) * P.w + ix0) * PSB;
+                const bool edge = ftx == 0 || ix0 + RW > P.w;
+                char* const dst = xbufs + (j % NBUF) * XBUF;
+#pragma unroll
+                for (int k = 0; k < NDMA; ++k) {
+                    int vo = voff[k] + o;
+                    if (edge) { const int gx = ix0 + pxk[k]; vo = (gx < 0 || gx >= P.w) ? (int)0x80000000 : vo; }
+                    dma16(rs, dst + k * 1024, vo);
+                }
+                if (++fty == P.nty) { fty = 0; if (++ftx == P.ntx) { ftx = 0; ++ft; } }
+            }
+            if (i >= 0) __builtin_amdgcn_s_barrier();                // (the compute waves' "mid written" barrier)
+        }
+        return;
+    }
+
+    // ====================================================== COMPUTE ======================================================
+    const int g = lane >> 4, p = lane & 15;
+    const int c0 = g * 4 * MT;
+    int toff1[KS], addr2[KS];
+    const int lane_base2 = ((wv * RPW) * MW + p) * PSB;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        int o1 = 0, o2 = 0;
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            const int kk0 = (s * 4 + gg) * 8;
+            const int tap = kk0 / CS, cc0 = kk0 - tap * CS, dy = tap / 3, dx = tap - dy * 3;
+            const int a = kk0 < KTOT ? (dy * RW + dx) * PSB + cc0 * 2 : 0, b = kk0 < KTOT ? (dy * MW + dx) * PSB + cc0 * 2 : 0;
+            o1 = g == gg ? a : o1; o2 = g == gg ? b : o2;
+        }
+        toff1[s] = o1;
+        addr2[s] = lane_base2 + o2;
+    }
+    // conv1: this lane's pixel of each of the wave's ring N-tiles (tile-independent): region offset, mid offset, ring coordinates
+    int pix1[PER1], mwr[PER1];
+#pragma unroll
+    for (int i = 0; i < PER1; ++i) {
+        const int q = (wv + 4 * i) * 16 + p, qc = q < NM ? q : NM - 1;
+        const int my = qc / MW, mx = qc - my * MW;
+        pix1[i] = (my * RW + mx) * PSB;
+        mwr[i] = (q < NM && c0 < CS) ? qc * PSB + c0 * 2 : -1;      // -1: nothing to write (beyond the ring, or a lane whose channels are all padding)
+    }
+    bf16x8_t A1[W1L ? 1 : MT][W1L ? 1 : KS], A2[W2L ? 1 : MT][W2L ? 1 : KS];
+    if constexpr (!W1L) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) A1[m][s] = as_frag(P.wfrag[(m * KS + s) * 64 + lane]);
+    }
+    if constexpr (!W2L) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) A2[m][s] = as_frag(P.w2[(m * KS + s) * 64 + lane]);
+    }
+    const char* const wl = smem + lane * 16;
+    f32x4_t bias1[MT], bias2[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const float4 a4 = P.bias ? *(const float4*)(P.bias + c0 + m * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 b4 = P.b2 ? *(const float4*)(P.b2 + c0 + m * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bias1[m] = (f32x4_t){a4.x, a4.y, a4.z, a4.w};
+        bias2[m] = (f32x4_t){b4.x, b4.y, b4.z, b4.w};
+    }
+    const float slope = P.prelu;
+    float4 osc[MT];
+    auto load_osc = [&](int ft) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) osc[m] = *(const float4*)(P.oscale + (size_t)ft * P.oscale_stride + c0 + m * 4);
+    };
+    load_osc(t);
+    constexpr int OOR = (int)0x80000000;
+    constexpr int PIECE = (MT == 2 || MT == 4) ? 16 : 8, NP = (MT * 8) / PIECE;
+    typedef unsigned rword_t __attribute__((ext_vector_type(PIECE / 4)));
+    int ooff[RPW][NP];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+            ooff[rr][q] = (c0 + q * (PIECE / 2) < CS) ? ((wv * RPW + rr) * P.w + p) * PSB + c0 * 2 + q * PIECE : OOR;
+    const int raddr = ((wv * RPW + 2) * RW + p + 2) * PSB + c0 * 2;  // x at this lane's output pixel: the region's centre
+
+    for (int i = 0; i < n; ++i) {
+        __builtin_amdgcn_s_barrier();                                // region i is in LDS; mid is free
+        const char* const xs = xbufs + (i % NBUF) * XBUF;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        const bool inner = oy0 >= 1 && oy0 + TH + 1 <= P.h && ox0 >= 1 && ox0 + TW + 1 <= P.w;      // the whole ring lies inside the image (wave-uniform)
+        // ---- conv1 + PReLU on the ring -> mid (bf16, [ring pixel][CS]) ----
+#pragma unroll
+        for (int ps = 0; ps < PER1 / NH1; ++ps) {
+            f32x4_t acc[MT][NH1];
+            bf16x8_t bq[2][NH1], aq[2][W1L ? MT : 1];
+#pragma unroll
+            for (int nh = 0; nh < NH1; ++nh) bq[0][nh] = as_frag(*(const uint4*)(xs + pix1[ps * NH1 + nh] + toff1[0]));
+            if constexpr (W1L) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) aq[0][m] = as_frag(*(const uint4*)(wl + (m * KS) * 1024));
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (s + 1 < KS) {
+#pragma unroll
+                    for (int nh = 0; nh < NH1; ++nh) bq[(s + 1) & 1][nh] = as_frag(*(const uint4*)(xs + pix1[ps * NH1 + nh] + toff1[s + 1]));
+                    if constexpr (W1L) {
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) aq[(s + 1) & 1][m] = as_frag(*(const uint4*)(wl + (m * KS + s + 1) * 1024));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int nh = 0; nh < NH1; ++nh)
+                        acc[m][nh] = mfma16(W1L ? aq[s & 1][m] : A1[W1L ? 0 : m][W1L ? 0 : s], bq[s & 1][nh], s == 0 ? bias1[m] : acc[m][nh]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int nh = 0; nh < NH1; ++nh) {
+                const int i1 = ps * NH1 + nh;
+                bool in = true;
+                if (!inner) {                                        // (border tiles only: the ring coordinates back from the region offset)
+                    const int pq = pix1[i1] / PSB, my = pq / RW, mx = pq - my * RW;
+                    const int gy = oy0 - 1 + my, gx = ox0 - 1 + mx;
+                    in = gy >= 0 && gy < P.h && gx >= 0 && gx < P.w;
+                }
+                unsigned wd[MT][2];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    float v[4] = {acc[m][nh][0], acc[m][nh][1], acc[m][nh][2], acc[m][nh][3]};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = max_bare(v[r], slope * v[r]);
+                    wd[m][0] = in ? pack_bf2(v[0], v[1]) : 0u;
+                    wd[m][1] = in ? pack_bf2(v[2], v[3]) : 0u;
+                }
+                if (mwr[i1] >= 0) {
+                    char* dst = mids + mwr[i1];
+                    if constexpr (MT == 2 || MT == 4) {
+#pragma unroll
+                        for (int m = 0; m < MT; m += 2)
+                            if (c0 + m * 4 < CS) *(uint4*)(dst + m * 8) = make_uint4(wd[m][0], wd[m][1], wd[m + 1][0], wd[m + 1][1]);
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            if (c0 + m * 4 < CS) *(uint2*)(dst + m * 8) = make_uint2(wd[m][0], wd[m][1]);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_s_barrier();                                // mid is complete
+        // ---- conv2 from mid; epilogue: * ca, + x, store (MODE 2 of conv3p_kernel) ----
+        const __amdgpu_buffer_rsrc_t ro = frame_rsrc(P.out + (size_t)t * frame_elems, frame_bytes);
+        const int o2 = (oy0 * P.w + ox0) * PSB;
+        const bool full = (oy0 + TH <= P.h) && (ox0 + TW <= P.w);
+        const int ylim = P.h - oy0 - wv * RPW, xlim = P.w - ox0 - p;
+#pragma unroll
+        for (int ps = 0; ps < NTW / NH; ++ps) {
+            const int N0 = ps * NH;
+            f32x4_t acc[MT][NH];
+            bf16x8_t bq[2][NH], aq[2][W2L ? MT : 1];
+#pragma unroll
+            for (int nh = 0; nh < NH; ++nh)
+                bq[0][nh] = as_frag(*(const uint4*)(mids + addr2[0] + (((N0 + nh) >> 1) * MW + ((N0 + nh) & 1) * 16) * PSB));
+            if constexpr (W2L) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) aq[0][m] = as_frag(*(const uint4*)(wl + W2OFF + (m * KS) * 1024));
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (s + 1 < KS) {
+#pragma unroll
+                    for (int nh = 0; nh < NH; ++nh)
+                        bq[(s + 1) & 1][nh] = as_frag(*(const uint4*)(mids + addr2[s + 1] + (((N0 + nh) >> 1) * MW + ((N0 + nh) & 1) * 16) * PSB));
+                    if constexpr (W2L) {
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) aq[(s + 1) & 1][m] = as_frag(*(const uint4*)(wl + W2OFF + (m * KS + s + 1) * 1024));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int nh = 0; nh < NH; ++nh)
+                        acc[m][nh] = mfma16(W2L ? aq[s & 1][m] : A2[W2L ? 0 : m][W2L ? 0 : s], bq[s & 1][nh], s == 0 ? bias2[m] : acc[m][nh]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int nh = 0; nh < NH; ++nh) {
+                const int nn = N0 + nh, rr = nn >> 1, xb = nn & 1;
+                float v[MT][4];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const rword_t qv = *(const rword_t*)(xs + raddr + (rr * RW + xb * 16) * PSB + ((m * 8) / PIECE) * PIECE);
+                    const unsigned lo = qv[((m * 8) % PIECE) / 4], hi = qv[((m * 8) % PIECE) / 4 + 1];
+                    v[m][0] = mul_then_add(acc[m][nh][0], osc[m].x, bf_lo(lo)); v[m][1] = mul_then_add(acc[m][nh][1], osc[m].y, bf_hi(lo));
+                    v[m][2] = mul_then_add(acc[m][nh][2], osc[m].z, bf_lo(hi)); v[m][3] = mul_then_add(acc[m][nh][3], osc[m].w, bf_hi(hi));
+                }
+                const bool ok = full || ((rr < ylim) && (xb * 16 < xlim));
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    int vo = o2 + ooff[rr][q] + xb * 16 * PSB;
+                    vo = ok ? vo : OOR;
+                    if constexpr (PIECE == 16) {
+                        const int m = q * 2;
+                        const rword_t d = {pack_bf2(v[m][0], v[m][1]), pack_bf2(v[m][2], v[m][3]), pack_bf2(v[m + 1][0], v[m + 1][1]), pack_bf2(v[m + 1][2], v[m + 1][3])};
+                        __builtin_amdgcn_raw_buffer_store_b128(d, ro, vo, 0, 0);
+                    } else {
+                        const rword_t d = {pack_bf2(v[q][0], v[q][1]), pack_bf2(v[q][2], v[q][3])};
+                        __builtin_amdgcn_raw_buffer_store_b64(d, ro, vo, 0, 0);
+                    }
+                }
+            }
+        }
+        if (++ty == P.nty) {
+            ty = 0;
+            if (++tx == P.ntx) { tx = 0; ++t; if (i + 1 < n) load_osc(t); }
+        }
     }
 }
 
@@ -431,8 +754,22 @@ int launch_conv3p(const C3P& K, const C3PPlan& pl, int mode, hipStream_t st) {
         case 0: return launch_conv3p_mode<MT, CS, TH, D, 0, false>(K, pl, st);
         case 1: return launch_conv3p_mode<MT, CS, TH, D, 1, false>(K, pl, st);
         case 2: return launch_conv3p_mode<MT, CS, TH, D2, 2, RL2>(K, pl, st);
+        case 3: return launch_conv3p_mode<MT, CS, TH, D, 3, false>(K, pl, st);
         default: return SN_EINVAL;
     }
+}
+
+template <int MT, int CS, int TH, int D>
+int launch_cabp(const C3P& K, const C3PPlan& pl, hipStream_t st) {
+    constexpr int NPB = CS / 8, NDMA = ((TH + 4) * 36 * NPB + 63) / 64, KS = (9 * CS + 31) / 32;
+    C3P P = K;
+    P.ntx = pl.ntx; P.nty = pl.nty; P.S = pl.S; P.nseg = pl.nseg; P.nsg = pl.nsg; P.qs = pl.qs; P.pool_rows = 0;
+    const size_t lds = (size_t)(D + 1) * NDMA * 1024 + ((TH + 2) * 34 * CS * 2 + 15) / 16 * 16 + (MT != 1 ? 2 * MT * KS * 1024 : 0);
+    if (lds > 160 * 1024) return SN_EINVAL;
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)cabp_kernel<MT, CS, TH, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return SN_ELAUNCH;
+    hipLaunchKernelGGL((cabp_kernel<MT, CS, TH, D>), dim3(pl.grid), dim3(320), lds, st, P);
+    return sn_check_launch();
 }
 
 // epilogue mode of a descriptor (conv3p_kernel), -1: a combination the streaming kernel does not implement
@@ -489,25 +826,50 @@ int sn_conv3p_pool_rows(const sn_conv_desc* d) {
     return c3p_plan(d->T, d->h_out, d->w_out, 8, ncu, c3p_wgs(d, key, 1)).pool_rows;
 }
 
-int sn_conv3p_launch(const sn_conv_desc* d, void* stream) {
+// lines_len > 0: the statistics pass of the fused CAB (sn_cab_stats): d is a MODE-1 descriptor whose `out` is the border-line buffer
+int sn_conv3p_launch(const sn_conv_desc* d, int lines_len, void* stream) {
     const int key = sn_conv3p_key(d, false), ncu = key ? c3p_ncu() : 0;
     if (!key || !ncu) return SN_EINVAL;
     C3P K;
     K.in = (const bf16_t*)d->in[0]; K.res = (const bf16_t*)d->res; K.out = (bf16_t*)d->out;
     K.wfrag = (const uint4*)d->wfrag; K.bias = d->bias; K.oscale = d->oscale; K.oscale_stride = d->oscale_stride;
     K.pool = d->pool; K.pool_rows = 0; K.act = d->act; K.prelu = d->prelu;
-    K.T = d->T; K.h = d->h_out; K.w = d->w_out;
-    const int mode = c3p_mode(d);
+    K.T = d->T; K.h = d->h_out; K.w = d->w_out; K.lines_len = lines_len; K.dbg = (d->flags >> 12) & 7;
+    const int mode = lines_len > 0 ? 3 : c3p_mode(d);
+    if (lines_len > 0 && c3p_mode(d) != 1) return SN_EINVAL;
     const C3PPlan pl = c3p_plan(d->T, d->h_out, d->w_out, 8, ncu, c3p_wgs(d, key, mode));
     hipStream_t st = (hipStream_t)stream;
     const bool rl = c3p_rl(d, key, mode);
     // <M-tiles, channels, tile rows, prefetch depth, prefetch depth of MODE 2, MODE 2 with the residual in LDS>
     switch (key) {
-        case 1016: return rl ? launch_conv3p<1, 16, 8, 2, 2, true>(K, pl, mode, st) : launch_conv3p<1, 16, 8, 2, 2, false>(K, pl, mode, st);
+        case 1016:
+            if (((d->flags >> 10) & 3) == 1) return launch_conv3p<1, 16, 8, 3, 3, false>(K, pl, mode, st);      // bits 10..11: deeper prefetch (measurements)
+            if (((d->flags >> 10) & 3) == 2) return launch_conv3p<1, 16, 8, 4, 4, false>(K, pl, mode, st);
+            return rl ? launch_conv3p<1, 16, 8, 2, 2, true>(K, pl, mode, st) : launch_conv3p<1, 16, 8, 2, 2, false>(K, pl, mode, st);
         case 2024: return rl ? launch_conv3p<2, 24, 8, 2, 1, true>(K, pl, mode, st) : launch_conv3p<2, 24, 8, 2, 2, false>(K, pl, mode, st);
         case 3040: return launch_conv3p<3, 40, 8, 2, 2, false>(K, pl, mode, st);
         case 3048: return launch_conv3p<3, 48, 8, 2, 2, false>(K, pl, mode, st);
         case 4064: return launch_conv3p<4, 64, 8, 1, 1, false>(K, pl, mode, st);      // 72 KB of weights: two buffers of 43 KB
         default: return SN_EINVAL;
     }
+}
+
+// pass 2 of the fused CAB on the streaming structure (sn_cab_fused routes here unless the tile form is asked for); SN_EINVAL: no instance / no device
+int sn_cabp_launch(const sn_conv_desc* a, const sn_conv_desc* b, void* stream) {
+    const int key = a->mt * 1000 + a->cs_in, ncu = c3p_ncu();
+    if (!ncu || !(key == 1016 || key == 2024) || a->act != 1 || !(a->prelu >= 0.f && a->prelu <= 1.f) || !b->oscale || b->res2) return SN_EINVAL;
+    if ((size_t)a->h_out * a->w_out * a->cs_out * 2 >= 0x7fffffffull) return SN_EINVAL;
+    C3P K;
+    K.in = (const bf16_t*)a->in[0]; K.res = nullptr; K.out = (bf16_t*)b->out;
+    K.wfrag = (const uint4*)a->wfrag; K.bias = a->bias; K.w2 = (const uint4*)b->wfrag; K.b2 = b->bias;
+    K.oscale = b->oscale; K.oscale_stride = b->oscale_stride; K.pool = nullptr; K.pool_rows = 0; K.act = 1; K.prelu = a->prelu;
+    K.T = a->T; K.h = a->h_out; K.w = a->w_out; K.lines_len = 0; K.dbg = 0;
+    // LDS per workgroup (region buffers + mid + both weight sets): 16 channels 63 KB with three region buffers (two workgroups per CU), 49 KB with
+    // two (three per CU); 24 channels 107 / 86 KB (one per CU).  Bits 4..7 / 10..11 of conv1's flags override the count / ask for two buffers (measurements).
+    const int o = (a->flags >> 4) & 15;
+    const bool shallow = ((a->flags >> 10) & 3) == 3;      // (codes 1 and 2 mean deeper prefetch to the statistics pass that shares these flags)
+    const C3PPlan pl = c3p_plan(a->T, a->h_out, a->w_out, 8, ncu, o ? o : (key == 1016 ? (shallow ? 3 : 2) : 1));
+    hipStream_t st = (hipStream_t)stream;
+    if (shallow) return key == 1016 ? launch_cabp<1, 16, 8, 1>(K, pl, st) : launch_cabp<2, 24, 8, 1>(K, pl, st);
+    return key == 1016 ? launch_cabp<1, 16, 8, 2>(K, pl, st) : launch_cabp<2, 24, 8, 2>(K, pl, st);
 }

@@ -253,6 +253,8 @@ class Engine:
     conv_tiles = os.environ.get("SN_CONV_TILES", "0") == "1"
     conv_stream_all = os.environ.get("SN_CONV_STREAM_ALL", "0") == "1"      # measurements / tests: the streaming kernel also where the library prefers the tile kernel
     conv_res_regs = os.environ.get("SN_CONV_RES_REGS", "0") == "1"          # measurements: the residual operand of the streaming kernel through registers, not LDS
+    conv_dbg = int(os.environ.get("SN_CONV_DBG", "0"))                      # measurements (wrong results): 1 no DMA, 2 no B reads / MFMAs, 4 no stores
+    conv_depth = int(os.environ.get("SN_CONV_DEPTH", "0"))                  # measurements: 1 / 2 = three / four tiles of prefetch (16 channels)
     conv_wgs = int(os.environ.get("SN_CONV_WGS", "0"))            # measurements: persistent workgroups per CU of the streaming kernel (0: the library's choice)
 
     def conv(self, name: str, ins: Sequence[Act], *, stride: int = 1, pad: Optional[int] = None, prelu: Optional[float] = None,
@@ -288,7 +290,7 @@ class Engine:
             out_act = Act(o, c_log)
             d.out, d.cs_out, d.c_out = o.data_ptr(), cs_out, cout
         d.out_mode = out_mode
-        d.flags = L.SN_CONV_TILE_KERNEL if self.conv_tiles else ((self.conv_wgs << 4) | (256 if self.conv_stream_all else 0) | (512 if self.conv_res_regs else 0))
+        d.flags = L.SN_CONV_TILE_KERNEL if self.conv_tiles else ((self.conv_wgs << 4) | (256 if self.conv_stream_all else 0) | (512 if self.conv_res_regs else 0) | (self.conv_depth << 10) | (self.conv_dbg << 12))
         if res is not None:
             assert out_mode == 0 and res.dims == out_act.dims
             d.res = res.t.data_ptr()
@@ -338,7 +340,7 @@ class Engine:
             p = self.P.cas[pre + "CA"]
             T, h, w, cs = x.dims
             slope = self.P.scalar(pre + "body.1.weight")
-            if self.cab_fused != "0":
+            if self.cab_fused in ("8", "16", "s8", "s16") or (self.cab_fused == "p" and extra is None and not self.conv_tiles):
                 out = self._cab_fused(pre, x, extra, slope)
                 if out is not None:
                     return out
@@ -382,6 +384,8 @@ class Engine:
             return None
         d1 = self._conv_desc(pre + "body.0", x, prelu=slope)
         d2 = self._conv_desc(pre + "body.2", x)
+        if self.cab_fused[0] in "sp" and not self.conv_tiles:
+            d1.flags = (self.conv_wgs << 4) | (self.conv_depth << 10) | (self.conv_dbg << 12)                         # statistics pass on the streaming kernel (its own pool rows: sn_conv_pool_blocks)
         if d1.cs_out != cs or d2.cs_out != cs or not lib.sn_cab_fused_supported(C.byref(d1), C.byref(d2)):
             return None
         p = self.P.cas[pre + "CA"]
@@ -397,7 +401,7 @@ class Engine:
         if extra is not None:
             assert extra.dims == x.dims
             d2.res2 = extra.t.data_ptr()
-        rows = int(self.cab_fused) if self.cab_fused in ("8", "16") else 8
+        rows = 0 if self.cab_fused == "p" else 16 if self.cab_fused.endswith("16") else 8      # 0: the streaming form (csrc/sn_conv3p.hip: cabp_kernel)
         st = self._stream()
         self._meta = ("cabf", T, h, w, cs, 1)                   # statistics pass: reads x
         self._call("sn_cab_stats", f"sn_cab_stats[{pre}]", C.byref(d1), ll, st)

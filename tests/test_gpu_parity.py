@@ -257,6 +257,34 @@ def test_fused_cab_is_bit_identical_to_the_two_launch_form(name, pre, c, T, hw, 
 
 
 @pytest.mark.parametrize("name,pre,c", [("gshift_deblur2", "stage1.concat.", 14), ("gshift_deblur2", "orb1.encoder_level2.1.", 18),
+                                        ("gshift_deblur2", "orb1.encoder_level3.1.", 22), ("gshift_deblur1", "stage1.concat.", 24)])
+@pytest.mark.parametrize("T,hw", [(3, (45, 150)), (2, (24, 40)), (2, (8, 32)), (1, (16, 64)), (3, (2, 3)), (2, (37, 33)), (5, (72, 200)), (1, (360, 640))])
+@pytest.mark.parametrize("depth,wgs", [(0, 0), (3, 0), (0, 1)])
+def test_streaming_fused_cab_is_bit_identical_to_the_two_launch_form(name, pre, c, T, hw, depth, wgs, engines):
+    """csrc/sn_conv3p.hip cabp_kernel: statistics pass on the streaming conv (MODE 3) -> closed-form CALayer -> ONE persistent kernel that keeps
+    `mid` in LDS (loader wave + LDS-DMA, conv1 on the ring, conv2 from mid, scale + x + store).  Operand layouts, k order and roundings are those of
+    the two-launch streaming form, so the result must be BIT-IDENTICAL to it -- interior tiles, ragged right / bottom tiles, maps smaller than a
+    tile, chunks crossing column and frame boundaries, both prefetch depths -- and within the CAB tolerance of the CPU oracle
+    (gshift_deblur1.py:141-156)."""
+    eng, sd = engines(name)
+    two = _sibling_engine(eng, cab_fused="0", conv_tiles=False, conv_stream_all=True, conv_wgs=wgs)
+    fz = _sibling_engine(eng, cab_fused="p", conv_tiles=False, conv_depth=depth, conv_wgs=wgs)
+    x = bf(torch.from_numpy(synth.unit_noise((T, c, hw[0], hw[1]), seed=76)))
+    xa = act(to_dev(x), c)
+    ref = two.cab(pre, xa).t
+    called = []
+    orig = fz._call
+    fz._call = lambda fn, *a: (called.append(fn), orig(fn, *a))[1]
+    got = fz.cab(pre, xa).t
+    torch.cuda.synchronize()
+    assert called.count("sn_cab_fused") == 1 and "sn_conv2d" not in called, called
+    assert torch.equal(ref, got), (name, pre, T, hw, depth, wgs, (ref.float() - got.float()).abs().max().item())
+    check(f"cab_streamfused_{name}_{pre}_{T}x{hw[0]}x{hw[1]}", to_cpu(got, c), O.cab(sd, pre, x), 8e-3)
+    if got.shape[-1] > c:
+        assert got[..., c:].float().abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("name,pre,c", [("gshift_deblur2", "stage1.concat.", 14), ("gshift_deblur2", "orb1.encoder_level2.1.", 18),
                                         ("gshift_deblur2", "orb1.encoder_level3.1.", 22), ("gshift_deblur1", "stage1.concat.", 24),
                                         ("gshift_deblur1", "orb1.encoder_level2.0.", 36), ("gshift_deblur1", "orb1.encoder_level3.0.", 48),
                                         ("gshift_deblur2", "stage1.skip_attn1.", 64)])      # >= 36 channels: weight fragments staged in LDS

@@ -37,14 +37,24 @@ def main():
             plans[name] = Plan(VARIANTS[name], synth_state_dict(name), dev)
         engs = {}
         for v in a.variants.split(","):
+            vfull, v = v, v.split("/")[0]
             e = Engine(plans[name])                                 # "0": two launches on the streaming conv kernel; "t": on the tile kernel; "wN": N workgroups
-            e.cab_fused = v if v in ("8", "16") else "0"            # per CU; "8" / "16": the fused tile form
+            e.cab_fused = v if v in ("8", "16", "s8", "s16", "p") else "0"   # per CU; "8" / "16": the fused tile form; "s8": with the statistics pass on the streaming kernel
             e.conv_tiles = v == "t"
             e.conv_wgs = int(v[1:]) if v.startswith("w") else 0
             e.conv_stream_all = v != "d"                            # "d": the library's default routing (16-channel conv2 on the tile kernel)
-            e.conv_res_regs = v.startswith("r")                     # "r": residual through registers; "rN": with N workgroups per CU
+            e.conv_res_regs = v.startswith("r") and v[1:].isdigit() or v == "r"                     # "r": residual through registers; "rN": with N workgroups per CU
             if v.startswith("r") and len(v) > 1:
                 e.conv_wgs = int(v[1:])
+            if "/" in vfull:                                        # "<variant>/dN/wM": prefetch depth code N and M workgroups per CU on top of a variant
+                for opt in vfull.split("/")[1:]:
+                    if opt[0] == "d":
+                        e.conv_depth = int(opt[1:])
+                    if opt[0] == "w":
+                        e.conv_wgs = int(opt[1:])
+                    if opt[0] == "x":                               # ablations (wrong results): xN = SN_CONV_DBG bits
+                        e.conv_dbg = int(opt[1:])
+            v = vfull
             engs[v] = e
         cs = (c + 7) // 8 * 8
         x = torch.zeros((T, h, w, cs), dtype=torch.bfloat16, device=dev)
