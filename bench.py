@@ -383,9 +383,10 @@ def main():
             if timed:
                 gather_ms.append((e0, e1))
         outs = []
-        for a, b, c, d in quads:
-            xq = win[:, :, a:b, c:d].contiguous() if args.quadrants else win
-            outs.append(net(xq.unsqueeze(0), sigma_map) if denoise else net(xq.unsqueeze(0)))
+        with net.guard_scope():      # the quadrants of a window share one range-guard check, as in cli.quadrant_forward (one forward: no difference)
+            for a, b, c, d in quads:
+                xq = win[:, :, a:b, c:d].contiguous() if args.quadrants else win
+                outs.append(net(xq.unsqueeze(0), sigma_map) if denoise else net(xq.unsqueeze(0)))
         return outs if args.quadrants else outs[0]
 
     def barrier():

@@ -58,6 +58,13 @@ __device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t rs, char* dst
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)dst, 16, voffset, 0, 0, 0);
 }
 
+// pin(x): an empty asm statement that reads and "rewrites" a register value.  hipcc must have the value in registers there -- it waits for
+// the load that produces it and can neither sink that load nor re-issue it later.  The compute waves pin every value they load from global
+// memory (weights, bias, CALayer scale) BEFORE the tile loop: a load still pending at the loop head gives the first use of its register inside
+// the loop a counted vmcnt that, in the steady state, waits for the previous tile's STORES (measured on the fused CAB kernel: 353 -> 513 us
+// when its weights moved to registers; __builtin_amdgcn_s_waitcnt alone does not help, the loads are sunk past it).
+template <typename V> __device__ __forceinline__ void pin(V& x) { asm volatile("" : "+v"(x)); }
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t frame_rsrc(const bf16_t* base, int frame_bytes) {
@@ -206,6 +213,20 @@ __global__ __launch_bounds__(320, c3p_waves(MT)) void conv3p_kernel(const C3P P)
         }
     };
     load_osc(t);
+    auto pin_loaded = [&]() __attribute__((always_inline)) {
+        if constexpr (!WLDS) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) pin(A[m][s]);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            pin(biasv[m]);
+            if constexpr (MODE == 2) { pin(osc[m].x); pin(osc[m].y); pin(osc[m].z); pin(osc[m].w); }
+        }
+    };
+    pin_loaded();
     // Byte offset of (wave row rr, pixel p, channel c0) from the tile's first output pixel.  Stores and residual loads go through a
     // range-checked buffer descriptor of the frame: an offset beyond it is dropped / reads 0, so rows below the frame need no mask, and a
     // lane whose channels are all padding (24 channels in 32 rows: lane group 3) carries an out-of-range offset for good.
@@ -403,7 +424,13 @@ __global__ __launch_bounds__(320, c3p_waves(MT)) void conv3p_kernel(const C3P P)
             if (++tx == P.ntx) {
                 tx = 0;
                 ++t;
-                if (i + 1 < n) load_osc(t);
+                if (i + 1 < n) {                                     // once per frame of a chunk: the wait drains this wave's stores too
+                    load_osc(t);
+                    if constexpr (MODE == 2) {
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) { pin(osc[m].x); pin(osc[m].y); pin(osc[m].z); pin(osc[m].w); }
+                    }
+                }
             }
         }
         advance2();
@@ -422,17 +449,18 @@ __global__ __launch_bounds__(320, c3p_waves(MT)) void conv3p_kernel(const C3P P)
 // a second barrier, and run conv2 from it with the scale / + x (the region's centre) / store epilogue of MODE 2.  Two barriers per tile: "region
 // landed and mid free" and "mid written".  Same operand layouts, k order and roundings as conv3_fast_kernel twice: bit-identical to the two-launch
 // form.  conv1 runs 1.33x (TH = 8) redundantly -- on matrix cores that the ablations of round 6 show idle (the kernel's time is its memory traffic).
-template <int MT, int CS, int TH, int D>
-__global__ __launch_bounds__(320, MT == 1 ? 3 : c3p_waves(MT)) void cabp_kernel(const C3P P) {
+template <int MT, int CS, int TH, int D, int WR>
+__global__ __launch_bounds__(320, c3p_waves(MT)) void cabp_kernel(const C3P P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TW = 32, RH = TH + 4, RW = TW + 4, MH = TH + 2, MW = TW + 2, NPB = CS / 8, PSB = CS * 2;
     constexpr int KTOT = 9 * CS, KS = (KTOT + 31) / 32;
     constexpr int ROWP = RW * NPB, NITEM = RH * ROWP, NDMA = (NITEM + 63) / 64, XBUF = NDMA * 1024;
     constexpr int NBUF = D + 1, NL = NDMA;
-    // Weight fragments of both convs: 16 channels in REGISTERS (2 x 5 fragments = 40 per lane; the kernel runs two workgroups per CU, <= 170
-    // registers, and every A fragment read from LDS is a ds_read_b128 on the one LDS pipe that already carries a B read per MFMA: measured
-    // 353 -> see DESIGN.md); 24 channels (2 x 14 fragments) in LDS, 1 KB per fragment.
-    constexpr bool W1L = MT != 1, W2L = MT != 1;
+    // Weight fragments of both convs in LDS, 1 KB per fragment (WR: measurement variants with conv1's (1), conv2's (2) or both sets (3) in registers.
+    // Both sets at 16 channels = 144 registers: 513 us against 353 at 20 x 720 x 1280 -- the kernel is built for two 5-wave workgroups per CU, and at
+    // three waves per SIMD the second one only fits when the dispatcher's starting SIMD happens to suit; at <= 128 registers any start fits.
+    // conv1's set alone spills at 128; conv2's alone: 126 registers, 327 us)
+    constexpr bool W1L = !(WR & 1), W2L = !(WR & 2);
     constexpr int WSET = MT * KS * 1024, W2OFF = W1L ? WSET : 0, WBYTES = W2OFF + (W2L ? WSET : 0);
     constexpr int NM = MH * MW, NT1 = (NM + 15) / 16, PER1 = (NT1 + 3) / 4;      // conv1: N-tiles of the ring, per wave (interleaved)
     constexpr int NH1 = MT == 1 ? 3 : 2;                            // N-tiles per accumulation pass of conv1 / conv2
@@ -558,6 +586,23 @@ __global__ __launch_bounds__(320, MT == 1 ? 3 : c3p_waves(MT)) void cabp_kernel(
         for (int m = 0; m < MT; ++m) osc[m] = *(const float4*)(P.oscale + (size_t)ft * P.oscale_stride + c0 + m * 4);
     };
     load_osc(t);
+    auto pin_osc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { pin(osc[m].x); pin(osc[m].y); pin(osc[m].z); pin(osc[m].w); }
+    };
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        pin(bias1[m]); pin(bias2[m]);
+        if constexpr (!W1L) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) pin(A1[m][s]);
+        }
+        if constexpr (!W2L) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) pin(A2[m][s]);
+        }
+    }
+    pin_osc();
     constexpr int OOR = (int)0x80000000;
     constexpr int PIECE = (MT == 2 || MT == 4) ? 16 : 8, NP = (MT * 8) / PIECE;
     typedef unsigned rword_t __attribute__((ext_vector_type(PIECE / 4)));
@@ -701,7 +746,7 @@ __global__ __launch_bounds__(320, MT == 1 ? 3 : c3p_waves(MT)) void cabp_kernel(
         }
         if (++ty == P.nty) {
             ty = 0;
-            if (++tx == P.ntx) { tx = 0; ++t; if (i + 1 < n) load_osc(t); }
+            if (++tx == P.ntx) { tx = 0; ++t; if (i + 1 < n) { load_osc(t); pin_osc(); } }
         }
     }
 }
@@ -759,16 +804,16 @@ int launch_conv3p(const C3P& K, const C3PPlan& pl, int mode, hipStream_t st) {
     }
 }
 
-template <int MT, int CS, int TH, int D>
+template <int MT, int CS, int TH, int D, int WR = 0>
 int launch_cabp(const C3P& K, const C3PPlan& pl, hipStream_t st) {
     constexpr int NPB = CS / 8, NDMA = ((TH + 4) * 36 * NPB + 63) / 64, KS = (9 * CS + 31) / 32;
     C3P P = K;
     P.ntx = pl.ntx; P.nty = pl.nty; P.S = pl.S; P.nseg = pl.nseg; P.nsg = pl.nsg; P.qs = pl.qs; P.pool_rows = 0;
-    const size_t lds = (size_t)(D + 1) * NDMA * 1024 + ((TH + 2) * 34 * CS * 2 + 15) / 16 * 16 + (MT != 1 ? 2 * MT * KS * 1024 : 0);
+    const size_t lds = (size_t)(D + 1) * NDMA * 1024 + ((TH + 2) * 34 * CS * 2 + 15) / 16 * 16 + ((WR & 1) ? 0 : MT * KS * 1024) + ((WR & 2) ? 0 : MT * KS * 1024);
     if (lds > 160 * 1024) return SN_EINVAL;
-    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)cabp_kernel<MT, CS, TH, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)cabp_kernel<MT, CS, TH, D, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return SN_ELAUNCH;
-    hipLaunchKernelGGL((cabp_kernel<MT, CS, TH, D>), dim3(pl.grid), dim3(320), lds, st, P);
+    hipLaunchKernelGGL((cabp_kernel<MT, CS, TH, D, WR>), dim3(pl.grid), dim3(320), lds, st, P);
     return sn_check_launch();
 }
 
@@ -871,5 +916,7 @@ int sn_cabp_launch(const sn_conv_desc* a, const sn_conv_desc* b, void* stream) {
     const C3PPlan pl = c3p_plan(a->T, a->h_out, a->w_out, 8, ncu, o ? o : (key == 1016 ? (shallow ? 3 : 2) : 1));
     hipStream_t st = (hipStream_t)stream;
     if (shallow) return key == 1016 ? launch_cabp<1, 16, 8, 1>(K, pl, st) : launch_cabp<2, 24, 8, 1>(K, pl, st);
+    // 16 channels: conv2's weight set in registers (126 of them), 327 against 341 us at 20 x 720 x 1280; bit 12 of CONV2's flags asks for both sets in LDS (measurements)
+    if (key == 1016 && !((b->flags >> 12) & 1)) return launch_cabp<1, 16, 8, 2, 2>(K, pl, st);
     return key == 1016 ? launch_cabp<1, 16, 8, 2>(K, pl, st) : launch_cabp<2, 24, 8, 2>(K, pl, st);
 }

@@ -118,6 +118,11 @@ class GShiftNetBase(nn.Module):
         self._plan.split = getattr(self, "_split", None)
         return self._plan
 
+    def guard_scope(self):
+        """Context manager: the forwards inside it share ONE range-guard check at its exit (Engine.guard_scope); `.tripped` then says whether
+        to run them again.  Not part of the upstream API; the denoise CLIs wrap the four quadrants of a window in it."""
+        return self.prepare().guard_scope()
+
     def forward_fp32_out(self, x, noise_map=None, shortcut=None):
         """``forward`` with the restored frames returned as float32 straight from the last conv's fp32 accumulators (no rounding to a
         half-precision image tensor in between).  ``shortcut`` ([B,T,3,H,W] float32, optional): the un-rounded input frames for the

@@ -113,10 +113,14 @@ def quadrant_forward(net, x: torch.Tensor, sigma: float, on_device: bool = False
         sc = x32[:, :, :, ys, xs].contiguous() if x32 is not None and x32.dtype != x.dtype else None
         o = net.forward_fp32_out(x[:, :, :, ys, xs].contiguous(), std, shortcut=sc)
         return o if on_device else o.cpu()
-    o1 = run(slice(0, hh), slice(0, ww))
-    o2 = run(slice(0, hh), slice(W // 2 - pad, W))
-    o3 = run(slice(H // 2 - pad_h, H), slice(0, ww))
-    o4 = run(slice(H // 2 - pad_h, H), slice(W // 2 - pad, W))
+    for _ in range(2):      # one range-guard check for the four quadrants (no device sync between them); a tripped guard moved the module to the
+        with net.guard_scope() as gs:      # bf16 chain: run them once more
+            o1 = run(slice(0, hh), slice(0, ww))
+            o2 = run(slice(0, hh), slice(W // 2 - pad, W))
+            o3 = run(slice(H // 2 - pad_h, H), slice(0, ww))
+            o4 = run(slice(H // 2 - pad_h, H), slice(W // 2 - pad, W))
+        if not gs.tripped:
+            break
     out[..., 0:H // 2, 0:W // 2] = o1[..., 0:-pad_h, 0:-pad]
     out[..., 0:H // 2, W // 2:] = o2[..., 0:-pad_h, pad:]
     out[..., H // 2:, 0:W // 2] = o3[..., pad_h:, 0:-pad]

@@ -9,6 +9,7 @@ no op below has a torch/ATen compute fallback.  The control flow mirrors the ref
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from collections import OrderedDict
@@ -328,6 +329,11 @@ class Engine:
     # raises a device flag when a channel sum is not finite -- what an overflowed fp16 `a`, g1 or r upstream turns into.  forward() reads the flag
     # once per call; a raised flag on the fused path switches THIS engine to the chain for good, warns, and recomputes the window.
     range_guard = os.environ.get("SN_RANGE_GUARD", "1") != "0"
+    # "1": forward() reads the flag before it hands the window out (one blocking 4-byte copy: the window can be recomputed).  "async": the flag goes
+    # to pinned host memory behind the forward and is looked at when the NEXT forward starts (or by check_range_guard()): no device sync at the end
+    # of a window, host preparation of the next one overlaps the GPU -- but a tripped window has already been handed out: it is reported, the
+    # engine moves to the chain for the windows that follow, and nothing is recomputed.
+    range_guard_async = os.environ.get("SN_RANGE_GUARD", "1") == "async"
     fused_cab_tail = True      # bf16 engine: always.  Engine32 (one kernel per reference module) runs conv, conv, pool, MLP, scale + residual instead
 
     def cab(self, pre: str, x: Act, extra: Optional[Act] = None) -> Act:
@@ -340,7 +346,8 @@ class Engine:
             p = self.P.cas[pre + "CA"]
             T, h, w, cs = x.dims
             slope = self.P.scalar(pre + "body.1.weight")
-            if self.cab_fused in ("8", "16", "s8", "s16") or (self.cab_fused == "p" and extra is None and not self.conv_tiles):
+            if self.cab_fused in ("8", "16", "s8", "s16") or (self.cab_fused[0] == "p" and extra is None and not self.conv_tiles and
+                                                              (self.cab_fused == "p" or (cs == 16 and T * h * w >= self.CAB_FUSED_MIN_PX))):
                 out = self._cab_fused(pre, x, extra, slope)
                 if out is not None:
                     return out
@@ -359,6 +366,7 @@ class Engine:
     # Fused dense CAB (csrc/sn_cabf.hip): statistics pass + one kernel with `mid` in LDS, three tensor passes instead of five, bit-identical to the
     # two-launch form.  SN_CAB_FUSED: "0" (default: measured faster) two sn_conv2d launches, "8" / "16" the fused form with that many tile rows.
     cab_fused = os.environ.get("SN_CAB_FUSED", "0")
+    CAB_FUSED_MIN_PX = 4 << 20      # "p16": the streaming fused form for 16-channel CABs of at least this many pixel-frames (below, two launches win)
 
     def _conv_desc(self, name: str, x: Act, *, prelu: Optional[float] = None) -> L.ConvDesc:
         """sn_conv_desc of a single-input 3x3 stride-1 conv of a CAB on x (no output, residual or pool operands yet)."""
@@ -385,7 +393,10 @@ class Engine:
         d1 = self._conv_desc(pre + "body.0", x, prelu=slope)
         d2 = self._conv_desc(pre + "body.2", x)
         if self.cab_fused[0] in "sp" and not self.conv_tiles:
-            d1.flags = (self.conv_wgs << 4) | (self.conv_depth << 10) | (self.conv_dbg << 12)                         # statistics pass on the streaming kernel (its own pool rows: sn_conv_pool_blocks)
+            # statistics pass on the streaming kernel (its own pool rows: sn_conv_pool_blocks); the streaming fused kernel reads its plan from conv1's flags
+            d1.flags = (self.conv_wgs << 4) | (self.conv_depth << 10) | (0 if self.cab_fused[0] == "p" else self.conv_dbg << 12)
+            if self.cab_fused[0] == "p":
+                d2.flags = (self.conv_dbg & 1) << 12                  # measurements: conv2's weights in LDS, not registers (16 channels)
         if d1.cs_out != cs or d2.cs_out != cs or not lib.sn_cab_fused_supported(C.byref(d1), C.byref(d2)):
             return None
         p = self.P.cas[pre + "CA"]
@@ -401,7 +412,7 @@ class Engine:
         if extra is not None:
             assert extra.dims == x.dims
             d2.res2 = extra.t.data_ptr()
-        rows = 0 if self.cab_fused == "p" else 16 if self.cab_fused.endswith("16") else 8      # 0: the streaming form (csrc/sn_conv3p.hip: cabp_kernel)
+        rows = 0 if self.cab_fused[0] == "p" else 16 if self.cab_fused.endswith("16") else 8      # 0: the streaming form (csrc/sn_conv3p.hip: cabp_kernel)
         st = self._stream()
         self._meta = ("cabf", T, h, w, cs, 1)                   # statistics pass: reads x
         self._call("sn_cab_stats", f"sn_cab_stats[{pre}]", C.byref(d1), ll, st)
@@ -793,10 +804,71 @@ class Engine:
             graphed = self.use_graph or (self.graph_auto and x.shape[0] * x.shape[2] * x.shape[3] <= self.GRAPH_AUTO_PXF)
             eager = (not graphed or self.split is not None or self.prof is not None or out_dtype is not None or shortcut is not None
                      or torch.cuda.is_current_stream_capturing())
+            if self.range_guard_async:
+                self.check_range_guard()               # the PREVIOUS window's flag (its copy has long landed: no wait in the steady state)
             out = self._forward(x, noise_map, past, future, out_dtype, shortcut) if eager else self._forward_graphed(x, noise_map, past, future)
-            if self._guard_tripped():
-                out = self._recover(lambda: self._forward(x, noise_map, past, future, out_dtype, shortcut), out)
+            if self._scope is not None:                # guard_scope(): one check when the scope closes
+                self._scope.frames = max(self._scope.frames, int(x.shape[0]))
+            elif self.range_guard_async:
+                self._post_guard_copy()
+            elif self._guard_tripped():
+                out = self._recover(lambda: self._forward(x, noise_map, past, future, out_dtype, shortcut), out, x.shape[0])
             return out
+
+    _scope = None
+
+    class GuardScope:
+        """Result of Engine.guard_scope(): `tripped` is set when the scope closes."""
+        tripped = False
+        frames = 1
+
+    @contextlib.contextmanager
+    def guard_scope(self):
+        """Several forwards whose results are consumed TOGETHER (the denoise CLIs' four quadrants of a window, inference/test_denoise.py:153-173) under
+        ONE range-guard check: inside the scope no forward reads the flag -- no device sync between them, the launches of the next one queue up
+        behind the previous one's kernels -- and the scope's exit reads it once.  If it tripped, the engine has moved to the two-kernel chain and
+        `scope.tripped` tells the caller to run the scope's forwards again (cli.quadrant_forward does).  Measured on config 4 (bf16, 4 quadrants x ~2900
+        launches per window): 111-114 frames/s with a check per forward (round 5), 118 without any (round 4's library) -- VERDICT r05 item 3."""
+        sc = Engine.GuardScope()
+        outer, self._scope = self._scope, sc
+        try:
+            yield sc
+        finally:
+            self._scope = outer
+            if outer is None and not self.range_guard_async:
+                sc.tripped = self._guard_tripped()
+                if sc.tripped:
+                    self._recover(None, None, sc.frames)
+            elif outer is not None:
+                outer.frames = max(outer.frames, sc.frames)
+            else:
+                self._post_guard_copy()
+
+    def _post_guard_copy(self) -> None:
+        """async guard: flag -> pinned host word behind this forward's launches, then re-arm on the device (stream order)."""
+        if self._bad is None or torch.cuda.is_current_stream_capturing():
+            return
+        if getattr(self, "_bad_host", None) is None:
+            self._bad_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
+            self._bad_event = torch.cuda.Event()
+        self._bad_host.copy_(self._bad, non_blocking=True)
+        self._bad.zero_()
+        self._bad_event.record()
+        self._bad_pending = True
+
+    def check_range_guard(self) -> bool:
+        """async guard: has a window since the last check tripped the guard?  Waits for the pending flag copy only (a finished forward: no wait).
+        A tripped flag warns and moves the engine to the two-kernel chain for the windows that follow (unless SN_PHASE1=r was asked for)."""
+        if not getattr(self, "_bad_pending", False):
+            return False
+        self._bad_event.synchronize()
+        self._bad_pending = False
+        v = int(self._bad_host.item())
+        if self.split is not None:
+            v = self.split.any_rank(v)
+        if v:
+            self._recover(None, None, 1)
+        return bool(v)
 
     def _guard_tripped(self) -> bool:
         """Reads (and re-arms) the range guard's flag: one 4-byte device-to-host copy per forward.  On a temporally split window the ranks
@@ -810,18 +882,28 @@ class Engine:
             self._bad.zero_()
         return bool(v)
 
-    def _recover(self, rerun, out):
+    def _recover(self, rerun, out, T: int = 1):
+        """A tripped range guard.  T: frames of the window that tripped it (did THAT forward run the fused kernel?  The denoisers' long windows
+        already run the chain).  rerun None (async guard): report and switch only -- the window has been handed out."""
         import warnings
-        if self._fused_phase1(1) and self.phase1 != "0":
+        if self._fused_phase1(T) and self.phase1 == "r":           # an explicit SN_PHASE1=r is honoured: warn, do not switch (ADVICE r05)
             warnings.warn(f"shiftnet_amd: {self.V.name}: a channel sum of the GSTS path is not finite -- an activation left the fp16 range of the fused "
-                          "phase-1 kernel (`a`, g1, r).  This module now runs phase 1 as the two-kernel chain with g1 in bf16 (SN_PHASE1=0) and the "
-                          "window is recomputed.")
+                          "phase-1 kernel (`a`, g1, r).  SN_PHASE1=r was asked for explicitly, so the module stays on it: the result of this window is "
+                          "not reliable (SN_PHASE1=auto would have moved to the two-kernel chain).")
+            return out
+        if self._fused_phase1(T) and self.phase1 != "0":
+            warnings.warn(f"shiftnet_amd: {self.V.name}: a channel sum of the GSTS path is not finite -- an activation left the fp16 range of the fused "
+                          "phase-1 kernel (`a`, g1, r).  This module now runs phase 1 as the two-kernel chain with g1 in bf16 (SN_PHASE1=0)"
+                          + (" and the window is recomputed." if rerun is not None else "; the results since the previous check (a guard_scope, or the "
+                             "window already handed out under SN_RANGE_GUARD=async) are NOT reliable: run them again."))
             self.phase1 = "0"
             self.fallbacks += 1
             for v in self._graphs.values():
                 if isinstance(v, tuple):
                     v[0].reset()
             self._graphs.clear()
+            if rerun is None:
+                return out
             out = rerun()
             if not self._guard_tripped():
                 return out
@@ -844,7 +926,9 @@ class Engine:
                 sx = x.clone()
                 sn = noise_map.clone() if noise_map is not None else None
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):       # its __exit__ ends the capture on an exception too: the stream is never left capturing
+                # thread_local: an allocation or a sync on ANOTHER host thread (pin-memory workers, a second engine) must neither fail nor
+                # invalidate this capture; __exit__ ends the capture on an exception too: the stream is never left capturing
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     so = self._forward(sx, sn, past, future)
                 ent = self._graphs[key] = (g, sx, sn, so)
                 self._evict_graphs()

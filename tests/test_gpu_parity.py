@@ -259,16 +259,16 @@ def test_fused_cab_is_bit_identical_to_the_two_launch_form(name, pre, c, T, hw, 
 @pytest.mark.parametrize("name,pre,c", [("gshift_deblur2", "stage1.concat.", 14), ("gshift_deblur2", "orb1.encoder_level2.1.", 18),
                                         ("gshift_deblur2", "orb1.encoder_level3.1.", 22), ("gshift_deblur1", "stage1.concat.", 24)])
 @pytest.mark.parametrize("T,hw", [(3, (45, 150)), (2, (24, 40)), (2, (8, 32)), (1, (16, 64)), (3, (2, 3)), (2, (37, 33)), (5, (72, 200)), (1, (360, 640))])
-@pytest.mark.parametrize("depth,wgs", [(0, 0), (3, 0), (0, 1)])
-def test_streaming_fused_cab_is_bit_identical_to_the_two_launch_form(name, pre, c, T, hw, depth, wgs, engines):
+@pytest.mark.parametrize("depth,wgs,wlds", [(0, 0, 0), (3, 0, 0), (0, 1, 0), (0, 0, 1)])
+def test_streaming_fused_cab_is_bit_identical_to_the_two_launch_form(name, pre, c, T, hw, depth, wgs, wlds, engines):
     """csrc/sn_conv3p.hip cabp_kernel: statistics pass on the streaming conv (MODE 3) -> closed-form CALayer -> ONE persistent kernel that keeps
     `mid` in LDS (loader wave + LDS-DMA, conv1 on the ring, conv2 from mid, scale + x + store).  Operand layouts, k order and roundings are those of
     the two-launch streaming form, so the result must be BIT-IDENTICAL to it -- interior tiles, ragged right / bottom tiles, maps smaller than a
-    tile, chunks crossing column and frame boundaries, both prefetch depths -- and within the CAB tolerance of the CPU oracle
+    tile, chunks crossing column and frame boundaries, both prefetch depths, conv2's weights in registers or LDS -- and within the CAB tolerance of the CPU oracle
     (gshift_deblur1.py:141-156)."""
     eng, sd = engines(name)
     two = _sibling_engine(eng, cab_fused="0", conv_tiles=False, conv_stream_all=True, conv_wgs=wgs)
-    fz = _sibling_engine(eng, cab_fused="p", conv_tiles=False, conv_depth=depth, conv_wgs=wgs)
+    fz = _sibling_engine(eng, cab_fused="p", conv_tiles=False, conv_depth=depth, conv_wgs=wgs, conv_dbg=wlds)     # wlds: both weight sets in LDS
     x = bf(torch.from_numpy(synth.unit_noise((T, c, hw[0], hw[1]), seed=76)))
     xa = act(to_dev(x), c)
     ref = two.cab(pre, xa).t
@@ -627,6 +627,53 @@ def test_range_guard_moves_a_module_to_the_bf16_chain(name):
         hot.range_guard = False
         bad = hot.shift_block(blk, act(to_dev(xb), C)).t.float()
         assert not torch.isfinite(bad).all()
+
+
+def test_range_guard_async_mode_and_explicit_fused_request():
+    """(a) SN_RANGE_GUARD=async -- the flag travels to pinned host memory behind the forward and is read when the NEXT forward starts:
+    no device sync at the end of a window; the tripped window is reported (it was handed out already), the module moves to the chain and the
+    next window equals a module that ran the chain from the start.  (b) an explicit SN_PHASE1=r is honoured: a warning, no switch.
+    (c) Engine.guard_scope (the denoise CLIs' four quadrants): no check inside, one at the exit, `tripped` asks the caller for a second run."""
+    import warnings
+    from shiftnet_amd.engine import Engine, Plan
+    name = "gshift_deblur2"
+    sd = {k: v.bfloat16() for k, v in _hot_state_dict(name, 300.0).items()}
+    T, H, W = 5, 32, 48
+    blur, _ = synth.blurred_clip(T, H, W, seed=3)
+    x = O.frames_to_tensor(list(blur)).bfloat16().cuda()[0]
+    P = Plan(VARIANTS[name], sd, DEV)
+    chain = Engine(P)
+    chain.phase1 = "0"
+    ref = chain.forward(x, None, 2, 2)
+    with torch.no_grad():
+        a = Engine(P)
+        a.range_guard_async = True
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                   # the tripped window itself is handed out without a word (and without a sync)
+            a.forward(x, None, 2, 2)
+        assert a.phase1 != "0" and a._bad_pending
+        with pytest.warns(UserWarning, match="already handed out"):
+            y = a.forward(x, None, 2, 2)                     # the check at its start switches the module: this window runs the chain
+        assert a.phase1 == "0" and a.fallbacks == 1 and torch.equal(y, ref)
+        assert a.check_range_guard() is False                # the chain does not trip it
+        g = Engine(P)                                        # (c) guard_scope: two forwards, ONE check at the exit, the caller runs them again
+        with pytest.warns(UserWarning, match="run them again"):
+            with g.guard_scope() as sc:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("error")
+                    g.forward(x, None, 2, 2)
+                    g.forward(x, None, 2, 2)
+        assert sc.tripped and g.phase1 == "0" and g.fallbacks == 1
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            with g.guard_scope() as sc:
+                y = g.forward(x, None, 2, 2)
+        assert not sc.tripped and torch.equal(y, ref)
+        r = Engine(P)
+        r.phase1 = "r"
+        with pytest.warns(UserWarning, match="asked for explicitly"):
+            r.forward(x, None, 2, 2)
+        assert r.phase1 == "r" and r.fallbacks == 0
 
 
 @pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_deblur1", "gshift_denoise1", "gshift_denoise2"])

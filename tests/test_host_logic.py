@@ -468,3 +468,49 @@ def test_xcd_tile_walk_is_a_bijection(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "xcd tiles ok" in r.stdout, r.stdout[-1000:] + r.stderr[-1000:]
+
+
+def test_failed_graph_capture_falls_back_to_eager_without_poisoning_later_calls(monkeypatch):
+    """hipGraph capture is automatic for small windows.  A capture that fails (another thread allocating, an unsupported call) must leave
+    the engine eager for that signature, warn once, and keep serving this and later calls; the capture itself asks for thread-local error mode."""
+    from collections import OrderedDict
+    from shiftnet_amd.engine import Engine
+    eng = object.__new__(Engine)                                     # no device: only the capture bookkeeping is under test
+    eng._graphs, eng.dev = OrderedDict(), torch.device("cpu")
+    calls = []
+    eng._forward = lambda x, n, p, f: (calls.append("eager"), x + 1)[1]
+    modes = []
+
+    class FakeGraph:
+        def reset(self):
+            pass
+
+    class FailingCapture:
+        def __init__(self, g, capture_error_mode="global"):
+            modes.append(capture_error_mode)
+
+        def __enter__(self):
+            raise RuntimeError("operation not permitted when stream is capturing")
+
+        def __exit__(self, *a):
+            return False
+
+    monkeypatch.setattr(torch.cuda, "CUDAGraph", FakeGraph)
+    monkeypatch.setattr(torch.cuda, "graph", FailingCapture)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    x = torch.zeros(2, 3, 4, 4)
+    assert torch.equal(eng._forward_graphed(x, None, 2, 2), x + 1)   # first sight: eager
+    with pytest.warns(UserWarning, match="capture failed"):
+        assert torch.equal(eng._forward_graphed(x, None, 2, 2), x + 1)      # second: capture attempted, fails, eager result
+    assert modes == ["thread_local"]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                               # later calls: eager, quiet, no new capture attempt
+        assert torch.equal(eng._forward_graphed(x, None, 2, 2), x + 1)
+    assert modes == ["thread_local"] and calls == ["eager"] * 3
+    y = torch.zeros(1, 3, 4, 4)                                      # another signature is not poisoned by the failure: it gets its own attempt
+    eng._forward_graphed(y, None, 2, 2)
+    with pytest.warns(UserWarning, match="capture failed"):
+        eng._forward_graphed(y, None, 2, 2)
+    assert len(modes) == 2

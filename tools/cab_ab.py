@@ -39,7 +39,7 @@ def main():
         for v in a.variants.split(","):
             vfull, v = v, v.split("/")[0]
             e = Engine(plans[name])                                 # "0": two launches on the streaming conv kernel; "t": on the tile kernel; "wN": N workgroups
-            e.cab_fused = v if v in ("8", "16", "s8", "s16", "p") else "0"   # per CU; "8" / "16": the fused tile form; "s8": with the statistics pass on the streaming kernel
+            e.cab_fused = v if v in ("8", "16", "s8", "s16", "p", "p16") else "0"   # per CU; "8" / "16": the fused tile form; "s8": with the statistics pass on the streaming kernel
             e.conv_tiles = v == "t"
             e.conv_wgs = int(v[1:]) if v.startswith("w") else 0
             e.conv_stream_all = v != "d"                            # "d": the library's default routing (16-channel conv2 on the tile kernel)
