@@ -123,10 +123,10 @@ def symbol_key(sym):
                      ("ingest_kernel", "sn_ingest")):
         if pat in s:
             return key
-    m = re.search(r"conv3p_kernel<(\d+), ", s)
+    m = re.search(r"conv3p_kernel<(\d+), \d+, \d+, \d+, (\d+)", s)      # <M-tiles, channels, tile rows, depth, MODE, ...>: MODE 3 = the fused CAB's statistics pass
     if m:
-        return f"sn_conv2d<mt{m.group(1)},8x32>"
-    m = re.search(r"cab_fused_kernel<(\d+), ", s)
+        return f"sn_cab_stats<mt{m.group(1)}>" if m.group(2) == "3" else f"sn_conv2d<mt{m.group(1)},8x32>"
+    m = re.search(r"(?:cab_fused|cabp)_kernel<(\d+), ", s)
     if m:
         return f"sn_cab_fused<mt{m.group(1)}>"
     m = re.search(r"conv3_fast_kernel<(\d+), \d+, \d+, true>", s)

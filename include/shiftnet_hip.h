@@ -79,7 +79,10 @@ typedef struct sn_conv_desc {
     int flags;           /* SN_CONV_TILE_KERNEL: run single-input 3x3 stride-1 convs on the one-workgroup-per-tile kernel instead of the
                             persistent streaming kernel (csrc/sn_conv3p.hip) -- A/B measurements; results are bit-identical.
                             Bits 4..7: persistent workgroups per CU of the streaming kernel, 0 = the library's choice; bit 8: the streaming kernel also
-                            where the library prefers the tile kernel; bit 9: its residual operand through registers instead of LDS (measurements) */
+                            where the library prefers the tile kernel; bit 9: its residual operand through registers instead of LDS; bits 10..11:
+                            prefetch depth code (1 / 2: three / four tiles ahead at 16 channels; 3: the streaming fused CAB with two region buffers);
+                            bits 12..14: MEASUREMENTS ONLY, WRONG RESULTS -- the streaming conv without its DMA (1), B reads / MFMAs (2), stores (4);
+                            on conv2 of sn_cab_fused(rows = 0) bit 12 means "both weight sets in LDS" (results unchanged) */
 } sn_conv_desc;
 #define SN_CONV_TILE_KERNEL 1
 int sn_conv2d(const sn_conv_desc* d, void* stream);   /* d is a HOST pointer, read during the call */
@@ -111,7 +114,10 @@ int sn_cab_ca(const float* partial, int nblk, int cpad, const void* mid, int cs,
  *      but conv1->out is the LINE buffer [T][4][lines_len][cs] bf16 (lines_len >= max(h, w)): row 0, row h-1, column 0, column w-1 of mid;
  *   2. sn_cab_ca_lines: sn_cab_ca reading those lines instead of the tensor;
  *   3. sn_cab_fused(conv1, conv2, tile_rows): per (tile_rows x 32)-pixel tile conv1 + PReLU on the tile's 1-pixel ring into LDS, conv2 from there,
- *      * conv2->oscale, + x (conv2->res must be conv1->in[0]), + conv2->res2, stored to conv2->out.  tile_rows: 8 or 16.
+ *      * conv2->oscale, + x (conv2->res must be conv1->in[0]), + conv2->res2, stored to conv2->out.  tile_rows: 8 or 16 = one workgroup per
+ *      tile (csrc/sn_cabf.hip); 0 = the STREAMING form (csrc/sn_conv3p.hip: cabp_kernel -- persistent workgroups, a loader wave that moves the next
+ *      (8 + 4) x 36 pixel regions HBM -> LDS with LDS-DMA, four compute waves: conv1 on the ring -> mid in LDS -> conv2 -> scale + x -> store;
+ *      no res2; its statistics pass is sn_cab_stats on a descriptor WITHOUT SN_CONV_TILE_KERNEL, i.e. the streaming conv's own pool rows).
  * Both descriptors are those of the two-launch form (3x3, stride 1, pad 1, one input, cs_in == cs_out, NHWC); conv1->pool / conv1->out are only
  * read by sn_cab_stats.  Results are bit-identical to the two-launch form.  sn_cab_fused_supported: 1 when an instance for the pair exists
  * (16- and 24-channel storage), else 0 -- the caller then uses the two-launch form. */

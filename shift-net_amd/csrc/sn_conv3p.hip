@@ -751,28 +751,51 @@ __global__ __launch_bounds__(320, c3p_waves(MT)) void cabp_kernel(const C3P P) {
     }
 }
 
+// Segment length S of a launch's tile columns -- the unit the channel sums of a CAB's first conv are flushed in, i.e. what a pool row covers.
+// It is a function of the IMAGE (h, w) and the kernel instance only, never of the frame count, the device or a measurement override: the
+// sums of equal frames are then bit-equal whatever window they sit in (a temporally split window must equal the long one bit for bit,
+// tests/test_temporal_split.py), on whatever device.  Chosen on a MODEL machine (256 CUs x the instance's default workgroups per CU) over the
+// window lengths of the BASELINE configs: of 8, 6, 4, 3, 2, 1 tiles the one with the smallest modelled time, (1 + F / S) / balance averaged
+// over those lengths -- balance = mean tiles per workgroup / the busiest one's (chunks are whole segments), F = 0.25 = a flush of the channel
+// sums (~64 VALU instructions per wave) relative to a tile (measured: the 24-channel conv at 20 x 360 x 640 runs 92 us with S = 3, 106 with S = 1).
+int c3p_segment(int h, int w, int th, int wgs_model) {
+    const int ntx = (w + 31) / 32, nty = (h + th - 1) / th;
+    const int cand[6] = {8, 6, 4, 3, 2, 1}, Ts[5] = {12, 16, 20, 36, 52};
+    double best = 1e30;
+    int bestS = 1;
+    for (int k = 0; k < 6; ++k) {
+        const int S = cand[k] < nty ? cand[k] : nty;
+        const int nseg = (nty + S - 1) / S;
+        double cost = 0.0;
+        for (int j = 0; j < 5; ++j) {
+            const long ntiles = (long)ntx * nty * Ts[j];
+            long g = 256L * wgs_model;
+            if (g > (ntiles + 7) / 8) g = (ntiles + 7) / 8;
+            if (g < 1) g = 1;
+            const long nsg = (long)nseg * ntx * Ts[j], qs = (nsg + g - 1) / g;
+            cost += (1.0 + 0.25 / S) * (double)(qs * S) * (double)g / (double)ntiles;
+        }
+        if (cost < best - 1e-9) { best = cost; bestS = S; }
+    }
+    return bestS;
+}
+
 struct C3PPlan { int ntx, nty, S, nseg, nsg, qs, grid, pool_rows; };
 
-// `wgs` persistent workgroups per CU.  Segment length S: the longest of 8, 6, 4, 3, 2, 1 tiles whose chunks (whole segments) keep the busiest
-// workgroup within 6 % of the mean -- a flush of the channel sums costs ~64 VALU instructions per wave, so segments should not be shorter than needed.
-C3PPlan c3p_plan(int T, int h, int w, int th, int ncu, int wgs) {
+// `wgs` persistent workgroups per CU on `ncu` CUs; S from c3p_segment.  A chunk (workgroup) is qs consecutive segments of the
+// (frame > tile column > segment) list.
+C3PPlan c3p_plan(int T, int h, int w, int th, int ncu, int wgs, int S) {
     C3PPlan p;
     p.ntx = (w + 31) / 32; p.nty = (h + th - 1) / th;
     const long ntiles = (long)p.ntx * p.nty * T;
     long g = (long)ncu * wgs;
     if (g > (ntiles + 7) / 8) g = (ntiles + 7) / 8;                  // every workgroup at least 8 tiles to amortise its prologue
     if (g < 1) g = 1;
-    const int cand[6] = {8, 6, 4, 3, 2, 1};
-    double best = -1.0;
-    for (int k = 0; k < 6; ++k) {
-        const int S = cand[k] < p.nty ? cand[k] : p.nty;
-        const int nseg = (p.nty + S - 1) / S;
-        const long nsg = (long)nseg * p.ntx * T;
-        const long qs = (nsg + g - 1) / g;
-        const double eff = (double)ntiles / (double)g / (double)(qs * S);      // mean tiles per workgroup / the busiest one's (upper bound)
-        if (eff > best + 1e-9) { best = eff; p.S = S; p.nseg = nseg; p.nsg = (int)nsg; p.qs = (int)qs; }
-        if (eff >= 0.94) break;
-    }
+    p.S = S < p.nty ? S : p.nty;
+    p.nseg = (p.nty + p.S - 1) / p.S;
+    const long nsg = (long)p.nseg * p.ntx * T;
+    p.nsg = (int)nsg;
+    p.qs = (int)((nsg + g - 1) / g);
     const int chunks = (p.nsg + p.qs - 1) / p.qs;
     p.grid = (chunks + 7) / 8 * 8;
     p.pool_rows = 4 * p.ntx * p.nseg;
@@ -855,6 +878,8 @@ static int c3p_ncu() {
 // (measured, conv2 of a CAB, LDS vs registers: 24 channels 141 vs 153 us at 20 x 360 x 640 and 1327 vs 1347 at 52 x 720 x 1280; 40 channels 591 vs 576;
 // 48 channels 184 vs 182: staged for <= 24 channels, registers above, where the tile would also cost a prefetch buffer)
 static bool c3p_rl(const sn_conv_desc* d, int key, int mode) { return mode == 2 && (key == 1016 || key == 2024) && !(d->flags & 512); }
+// workgroups per CU of an instance's first-conv / statistics modes: the MODEL occupancy c3p_segment balances for (no override, no device query)
+static int c3p_wgs_default(int key) { return key == 1016 ? 3 : key == 2024 ? 2 : 1; }
 static int c3p_wgs(const sn_conv_desc* d, int key, int mode) {
     const int o = (d->flags >> 4) & 15;
     if (o) return o;
@@ -868,7 +893,7 @@ static int c3p_wgs(const sn_conv_desc* d, int key, int mode) {
 int sn_conv3p_pool_rows(const sn_conv_desc* d) {
     const int key = sn_conv3p_key(d, true), ncu = key ? c3p_ncu() : 0;
     if (!key || !ncu) return 0;
-    return c3p_plan(d->T, d->h_out, d->w_out, 8, ncu, c3p_wgs(d, key, 1)).pool_rows;
+    return c3p_plan(d->T, d->h_out, d->w_out, 8, ncu, c3p_wgs(d, key, 1), c3p_segment(d->h_out, d->w_out, 8, c3p_wgs_default(key))).pool_rows;
 }
 
 // lines_len > 0: the statistics pass of the fused CAB (sn_cab_stats): d is a MODE-1 descriptor whose `out` is the border-line buffer
@@ -882,7 +907,7 @@ int sn_conv3p_launch(const sn_conv_desc* d, int lines_len, void* stream) {
     K.T = d->T; K.h = d->h_out; K.w = d->w_out; K.lines_len = lines_len; K.dbg = (d->flags >> 12) & 7;
     const int mode = lines_len > 0 ? 3 : c3p_mode(d);
     if (lines_len > 0 && c3p_mode(d) != 1) return SN_EINVAL;
-    const C3PPlan pl = c3p_plan(d->T, d->h_out, d->w_out, 8, ncu, c3p_wgs(d, key, mode));
+    const C3PPlan pl = c3p_plan(d->T, d->h_out, d->w_out, 8, ncu, c3p_wgs(d, key, mode), c3p_segment(d->h_out, d->w_out, 8, c3p_wgs_default(key)));
     hipStream_t st = (hipStream_t)stream;
     const bool rl = c3p_rl(d, key, mode);
     // <M-tiles, channels, tile rows, prefetch depth, prefetch depth of MODE 2, MODE 2 with the residual in LDS>
@@ -913,7 +938,7 @@ int sn_cabp_launch(const sn_conv_desc* a, const sn_conv_desc* b, void* stream) {
     // two (three per CU); 24 channels 107 / 86 KB (one per CU).  Bits 4..7 / 10..11 of conv1's flags override the count / ask for two buffers (measurements).
     const int o = (a->flags >> 4) & 15;
     const bool shallow = ((a->flags >> 10) & 3) == 3;      // (codes 1 and 2 mean deeper prefetch to the statistics pass that shares these flags)
-    const C3PPlan pl = c3p_plan(a->T, a->h_out, a->w_out, 8, ncu, o ? o : (key == 1016 ? (shallow ? 3 : 2) : 1));
+    const C3PPlan pl = c3p_plan(a->T, a->h_out, a->w_out, 8, ncu, o ? o : (key == 1016 ? (shallow ? 3 : 2) : 1), c3p_segment(a->h_out, a->w_out, 8, c3p_wgs_default(key)));
     hipStream_t st = (hipStream_t)stream;
     if (shallow) return key == 1016 ? launch_cabp<1, 16, 8, 1>(K, pl, st) : launch_cabp<2, 24, 8, 1>(K, pl, st);
     // 16 channels: conv2's weight set in registers (126 of them), 327 against 341 us at 20 x 720 x 1280; bit 12 of CONV2's flags asks for both sets in LDS (measurements)

@@ -341,7 +341,7 @@ class Engine:
 
         The CALayer scale is known BEFORE the second conv (its pooled input is linear in `mid`, sn_cab_ca), so scale and residual
         (and the optional second residual `extra`) are applied in conv2's epilogue: two sn_conv2d launches, 5 tensor passes.
-        (A fused CAB with `mid` in LDS -- 3 passes -- was built and measured slower in round 2)"""
+        Large 16-channel CABs run the streaming fused form instead (3 passes, `mid` in LDS, bit-identical: `cab_fused` below)."""
         if self.fused_cab_tail:
             p = self.P.cas[pre + "CA"]
             T, h, w, cs = x.dims
@@ -363,10 +363,13 @@ class Engine:
         r, pool, npix = self.conv(pre + "body.2", [r], pool=True)
         return self.scale_residual(r, x, self.ca_mlp(pre + "CA", pool, npix), extra)
 
-    # Fused dense CAB (csrc/sn_cabf.hip): statistics pass + one kernel with `mid` in LDS, three tensor passes instead of five, bit-identical to the
-    # two-launch form.  SN_CAB_FUSED: "0" (default: measured faster) two sn_conv2d launches, "8" / "16" the fused form with that many tile rows.
-    cab_fused = os.environ.get("SN_CAB_FUSED", "0")
-    CAB_FUSED_MIN_PX = 4 << 20      # "p16": the streaming fused form for 16-channel CABs of at least this many pixel-frames (below, two launches win)
+    # Fused dense CAB: statistics pass + one kernel with `mid` in LDS, three tensor passes instead of five, bit-identical to the two-launch form.
+    # SN_CAB_FUSED: "0" two sn_conv2d launches; "p" the streaming form (csrc/sn_conv3p.hip: cabp_kernel; 16 / 24 channels) wherever it exists;
+    # "p16" (default) the streaming form for 16-channel CABs of at least CAB_FUSED_MIN_PX pixel-frames -- the one case it wins: 504 against 606 us
+    # per CAB at 20 x 720 x 1280 alone, 496 against 534 inside a config-2 window (-0.75 ms of 101); 24 channels lose (one workgroup per CU);
+    # "8" / "16" / "s8" / "s16": the one-workgroup-per-tile form of csrc/sn_cabf.hip with that many tile rows ("s": statistics on the streaming conv).
+    cab_fused = os.environ.get("SN_CAB_FUSED", "p16")
+    CAB_FUSED_MIN_PX = 4 << 20
 
     def _conv_desc(self, name: str, x: Act, *, prelu: Optional[float] = None) -> L.ConvDesc:
         """sn_conv_desc of a single-input 3x3 stride-1 conv of a CAB on x (no output, residual or pool operands yet)."""
