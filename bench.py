@@ -120,7 +120,7 @@ def symbol_key(sym):
         return "sn_ln_gemm_gate<cab2>" if m.group(1) == "true" else "sn_ln_gemm_gate<cab1>"
     for pat, key in (("scale_gemm_res_kernel", "sn_cab_phase2"), ("shiftconv_kernel", "sn_gsts_shiftconv"), ("grp5p_gemm_gate_kernel", "sn_grp5_gemm_gate"),
                      ("dw5m_gemm_gate_kernel", "sn_dw5m_gemm_gate"), ("ca_mlp_kernel", "sn_ca_mlp"), ("cab_ca", "sn_cab_ca"), ("gather_kernel", "sn_temporal_roll"),
-                     ("ingest_kernel", "sn_ingest")):
+                     ("ingest_kernel", "sn_ingest"), ("upsample2_add_kernel", "sn_upsample2_add")):
         if pat in s:
             return key
     m = re.search(r"conv3p_kernel<(\d+), \d+, \d+, \d+, (\d+)", s)      # <M-tiles, channels, tile rows, depth, MODE, ...>: MODE 3 = the fused CAB's statistics pass
@@ -158,6 +158,8 @@ def kernel_alg_bytes(fn, meta):
         p1 = px * (2.5 * c if mode else 2 * c)                                       # phase 1: read x (+ hw), write g2 (or g1)
         return {"sn_gsts_shiftconv": px * c, "sn_gsts_cab2_phase2": px * 3 * c, "sn_cab1_phase2": px * 3 * c, "sn_ln_gemm_gate": p1,
                 "sn_dw5m_gemm_gate": px * 2 * c, "sn_grp5_gemm_gate": px * 2 * c, "sn_gsts_cab2_phase1": p1, "sn_cab1_phase1": p1}.get(fn, 0)
+    if meta and meta[0] == "up2add":           # SkipUpSample's tail: low-resolution conv result in, skip in, result out
+        return 2 * meta[1] * meta[2] * meta[3] * meta[4] * (1 + 4 + 4)
     if meta and meta[0] == "roll":             # Shift_CAB's temporal roll: one read, one write
         return 2 * meta[1] * meta[2] * meta[3] * meta[4] * 2
     if meta and meta[0] == "cabf":             # fused dense CAB: statistics pass reads x; fused pass reads x (+ the second residual) and writes out

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 15     /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
+#define SN_ABI_VERSION 16     /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
 
 /* element types of NCHW tensors exchanged with the PyTorch side */
 #define SN_F32 0
@@ -61,7 +61,9 @@ typedef struct sn_conv_desc {
                             ("x = self.up(x); x = x + y" :348-349, "+ self.skip_conv(shortcut)" gshift_deblur2.py:611) */
     void* out;
     int cs_out;
-    int out_mode;        /* 0: NHWC; 1: F.pixel_shuffle(.,2) store -> [T][2h][2w][cs_out] (PixelShufflePack :277);
+    int out_mode;        /* 0: NHWC; 1: F.pixel_shuffle(.,2) store -> [T][2h][2w][cs_out] (PixelShufflePack :277) -- the weight ROWS (and bias) of such
+                            a conv are ordered [sub-pixel 2 i + j][output channel c < cs_out] (reference row 4 c + 2 i + j; zero rows for the storage
+                            padding), cs_out = 4 mt, so lane group g of the accumulator layout holds every channel of sub-pixel g (ABI 16; prep.pack_conv);
                             2: NCHW [T][c_out][h][w] of `nchw_dtype` plus the NCHW shortcut `sc`
                                ("return output_features + shortcut[...]" :791) */
     int c_out;           /* logical out channels (mode 2 only) */
@@ -88,6 +90,12 @@ typedef struct sn_conv_desc {
 int sn_conv2d(const sn_conv_desc* d, void* stream);   /* d is a HOST pointer, read during the call */
 /* number of workgroups per frame sn_conv2d launches for this descriptor (= rows of `pool` per frame); host only */
 int sn_conv_pool_blocks(const sn_conv_desc* d);
+
+/* SkipUpSample's tail (gshift_deblur1.py:341-350: x = up(x); x = x + y with up = bilinear x2 -> 1x1 conv).  The 1x1 is linear and the interpolation
+ * weights sum to one, so conv(up(x)) = up(conv(x)): the caller runs the 1x1 at LOW resolution with sn_conv2d (in_mode 0) and this pass computes
+ *   out[T][2 hs][2 ws][cs] = bilinear_x2(lo[T][hs][ws][cs]) + res[T][2 hs][2 ws][cs]      (bf16 NHWC, fp32 arithmetic, cs a multiple of 8;
+ * nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False)).  sn_conv2d's in_mode 1 (interpolation in the conv's loader) stays available. */
+int sn_upsample2_add(const void* lo, const void* res, void* out, int T, int hs, int ws, int cs, void* stream);
 
 /* CALayer / CALayer2 squeeze-excite: mean -> 1x1 -> ReLU -> 1x1 -> sigmoid (gshift_deblur1.py:61-70,84-87).
  * partial:[T][nblk][cpad] f32 sums, wa:[cr][c], wb:[c][cr] f32, ca:[T][cpad] f32 out (pad entries 0).

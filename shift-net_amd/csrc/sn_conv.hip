@@ -214,6 +214,7 @@ __global__ __launch_bounds__(256, sn_conv_waves(MT, TH)) void conv_mfma_kernel(c
         const int oy = oy0 + row, ox = ox0 + xb * 16 + p;
         const bool valid = (oy < P.hout) && (ox < P.wout);
         const size_t opix = ((size_t)t * P.hout + oy) * P.wout + ox;
+        uint2 shuf[MT];                                      // out_mode 1: this lane's 4 MT values = all cs_out channels of ONE output pixel
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int co0 = g * 4 * MT + m * 4;
@@ -246,12 +247,7 @@ __global__ __launch_bounds__(256, sn_conv_waves(MT, TH)) void conv_mfma_kernel(c
                         *(uint2*)(P.out + opix * P.cs_out + co0) = o;
                     }
                 } else if (P.out_mode == 1) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int co = co0 + r, c = co >> 2, i = (co >> 1) & 1, j = co & 1;
-                        if (c < P.cs_out)
-                            P.out[(((size_t)t * 2 * P.hout + 2 * oy + i) * (2 * P.wout) + 2 * ox + j) * P.cs_out + c] = f_to_bf(v[r]);
-                    }
+                    shuf[m].x = pack_bf2(v[0], v[1]); shuf[m].y = pack_bf2(v[2], v[3]);      // stored below, all M-tiles together
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -267,6 +263,15 @@ __global__ __launch_bounds__(256, sn_conv_waves(MT, TH)) void conv_mfma_kernel(c
                     }
                 }
             }
+        }
+        if (P.out_mode == 1 && valid) {
+            // pixel shuffle: the host ordered the rows [sub-pixel 2 i + j][output channel c < cs_out] with cs_out = 4 MT (prep.pack_conv, shuffle), so lane
+            // group g holds ALL channels of sub-pixel g of its pixel: cs_out x 2 contiguous bytes, and lane groups (0, 1) / (2, 3) of 16 pixels fill
+            // a contiguous run of 32 output pixels (round 5: four 2-byte stores per M-tile to four pixels, 0.6-0.9 TB/s of the conv's own bytes)
+            bf16_t* dst = P.out + (((size_t)t * 2 * P.hout + 2 * oy + (g >> 1)) * (2 * P.wout) + 2 * ox + (g & 1)) * P.cs_out;
+#pragma unroll
+            for (int m = 0; m + 1 < MT; m += 2) *(uint4*)(dst + m * 4) = make_uint4(shuf[m].x, shuf[m].y, shuf[m + 1].x, shuf[m + 1].y);
+            if constexpr (MT & 1) *(uint2*)(dst + (MT - 1) * 4) = shuf[MT - 1];
         }
     }
 
@@ -775,6 +780,45 @@ __global__ void selftest_mfma_kernel(const float* a, const float* b, float* d) {
     for (int r = 0; r < 4; ++r) d[(g * 4 + r) * 16 + m] = acc[r];   // D[row = g*4+r][col = lane&15]
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// SkipUpSample after the 1x1: out = bilinear_x2(lo) + res (gshift_deblur1.py:341-350).  The 1x1 conv is linear and the interpolation weights sum
+// to one, so conv(up(x)) = up(conv(x)): the conv runs at LOW resolution (a quarter of the pixels, sn_conv2d in_mode 0) and this streaming pass
+// does the rest -- the loader of the in_mode-1 conv interpolated cin channels per OUTPUT pixel in front of the MFMAs and moved its bytes at
+// 1.3-1.8 TB/s (round 6, tools/conv_labels.py).  One thread = one 8-channel piece of output column x of the row PAIR (2 i, 2 i + 1): six
+// low-resolution pieces (rows i - 1, i, i + 1 clamped, the two source columns of x), two residual pieces, two stores, all 16 bytes and
+// coalesced over consecutive pieces / columns.  nn.Upsample(scale_factor=2, bilinear, align_corners=False): src = dst / 2 - 0.25 clamped at 0.
+__global__ __launch_bounds__(256) void upsample2_add_kernel(const bf16_t* __restrict__ lo, const bf16_t* __restrict__ res, bf16_t* __restrict__ out,
+                                                            int hs, int ws, int npb) {
+    // grid (pieces of an output row / 256, hs, T): block-uniform row pair, one 32-bit division per thread
+    const int w2 = 2 * ws, cs = npb * 8, i = (int)blockIdx.y, t = (int)blockIdx.z;
+    const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (e >= w2 * npb) return;
+    const int x = e / npb, piece = e - x * npb;
+    float sx = x * 0.5f - 0.25f; if (sx < 0.f) sx = 0.f;
+    const int x0 = (int)sx, x1 = min(x0 + 1, ws - 1);
+    const float lx = sx - x0, hx = 1.f - lx;
+    const int ra = max(i - 1, 0), rc = min(i + 1, hs - 1);
+    const bf16_t* b = lo + (size_t)t * hs * ws * cs + piece * 8;
+    const uint4 qa0 = *(const uint4*)(b + ((size_t)ra * ws + x0) * cs), qa1 = *(const uint4*)(b + ((size_t)ra * ws + x1) * cs);
+    const uint4 qb0 = *(const uint4*)(b + ((size_t)i * ws + x0) * cs), qb1 = *(const uint4*)(b + ((size_t)i * ws + x1) * cs);
+    const uint4 qc0 = *(const uint4*)(b + ((size_t)rc * ws + x0) * cs), qc1 = *(const uint4*)(b + ((size_t)rc * ws + x1) * cs);
+    const size_t o0 = (((size_t)t * 2 * hs + 2 * i) * w2 + x) * cs + piece * 8, o1 = o0 + (size_t)w2 * cs;
+    const uint4 r0 = *(const uint4*)(res + o0), r1 = *(const uint4*)(res + o1);
+    float a0[8], a1[8], b0[8], b1[8], c0[8], c1[8], f0[8], f1[8], u0[8], u1[8];
+    unpack8(qa0, a0); unpack8(qa1, a1); unpack8(qb0, b0); unpack8(qb1, b1); unpack8(qc0, c0); unpack8(qc1, c1); unpack8(r0, f0); unpack8(r1, f1);
+    // row 2 i: source row i - 0.25 -> rows (i - 1, i) with weights (0.25, 0.75), row 0 alone for i = 0 (ra == i: the same numbers);
+    // row 2 i + 1: source row i + 0.25 -> rows (i, i + 1) with weights (0.75, 0.25)
+    const float ly0 = i > 0 ? 0.75f : 0.f, hy0 = 1.f - ly0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float va = hx * a0[j] + lx * a1[j], vb = hx * b0[j] + lx * b1[j], vc = hx * c0[j] + lx * c1[j];
+        u0[j] = (hy0 * va + ly0 * vb) + f0[j];
+        u1[j] = (0.75f * vb + 0.25f * vc) + f1[j];
+    }
+    *(uint4*)(out + o0) = pack8(u0);
+    *(uint4*)(out + o1) = pack8(u1);
+}
+
 }  // namespace
 
 extern "C" {
@@ -826,6 +870,7 @@ int sn_conv2d(const sn_conv_desc* d, void* stream) {
     if (d->ks * 32 < d->k * d->k * d->n_in * d->cs_in) return SN_EINVAL;
     if (d->oscale && d->oscale_stride < 16 * d->mt) return SN_EINVAL;
     if ((d->res || d->res2) && d->out_mode != 0) return SN_EINVAL;
+    if (d->out_mode == 1 && d->cs_out != 4 * d->mt) return SN_EINVAL;      // rows ordered [sub-pixel][cs_out channels]: a lane group = one sub-pixel
     ConvK K;
     K.in0 = (const bf16_t*)d->in[0]; K.in1 = (const bf16_t*)d->in[1]; K.in2 = (const bf16_t*)d->in[2];
     K.n_in = d->n_in; K.cs = d->cs_in; K.cv = d->n_in * d->cs_in;
@@ -927,3 +972,13 @@ int sn32_cab_ca(const float* partial, int nblk, int cpad, const float* mid, int 
 }
 
 }  // extern "C"
+
+// out[T][2 hs][2 ws][cs] = bilinear_x2(lo[T][hs][ws][cs]) + res[T][2 hs][2 ws][cs], bf16 NHWC, cs a multiple of 8 (SkipUpSample's tail, see the kernel)
+int sn_upsample2_add(const void* lo, const void* res, void* out, int T, int hs, int ws, int cs, void* stream) {
+    sn_clear_error();
+    if (!lo || !res || !out || T < 1 || hs < 1 || ws < 1 || cs < 8 || (cs & 7)) return SN_EINVAL;
+    if (hs > 65535 || T > 65535 || (long)2 * ws * (cs / 8) > 0x7fffffffL) return SN_EINVAL;
+    hipLaunchKernelGGL(upsample2_add_kernel, dim3((unsigned)((2 * ws * (cs / 8) + 255) / 256), (unsigned)hs, (unsigned)T), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)lo, (const bf16_t*)res, (bf16_t*)out, hs, ws, cs / 8);
+    return sn_check_launch();
+}

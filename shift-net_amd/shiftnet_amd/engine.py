@@ -73,11 +73,11 @@ class Plan:
     def _dev(self, t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
         return None if t is None else t.contiguous().to(self.device)
 
-    def add_conv(self, name: str, key: str, cins: Sequence[int]) -> None:
+    def add_conv(self, name: str, key: str, cins: Sequence[int], shuffle: bool = False) -> None:
         w = self.sd[key + "weight"]
         b = self.sd.get(key + "bias")
         cs_in = prep.ceil8(max(cins))
-        p = prep.pack_conv(w, b, cins, cs_in)
+        p = prep.pack_conv(w, b, cins, cs_in, shuffle)
         p["wfrag"] = self._dev(p["wfrag"])
         p["bias"] = self._dev(p["bias"])
         self.convs[name] = p
@@ -192,7 +192,7 @@ class Plan:
             self.add_shift_block(f"{p}{b}.", c1)
         self.add_cab(p + "skip_attn1.", c1)
         self.add_conv(p + "up21", p + "up21.up.1.", [c1])
-        self.add_conv(p + "upsample0", p + "upsample0.upsample_conv.", [c1])
+        self.add_conv(p + "upsample0", p + "upsample0.upsample_conv.", [c1], shuffle=True)
         self.add_cab(p + "skip_conv.", c0)
         self.add_cab(p + "out_conv.", c0)
         self.add_conv(p + "conv_hr0", p + "conv_hr0.", [c0, c0] if V.hr_cat else [c0])
@@ -725,9 +725,21 @@ class Engine:
             return self.conv(pre + "down", [x], stride=2, prelu=self.P.scalar(pre + "down.1.weight"))
         return self.conv(pre + "down", [x], stride=2)
 
+    # SkipUpSample: "1" (default) the 1x1 at LOW resolution, then one streaming pass bilinear x2 + skip (sn_upsample2_add: conv and interpolation
+    # commute); "0" round 2's form, the interpolation in the loader of a full-resolution conv (1.3-1.8 TB/s of its bytes)
+    skip_up_lowres = os.environ.get("SN_SKIPUP_LOWRES", "1") != "0"
+
     def skip_up(self, name: str, x: Act, y: Act) -> Act:
-        """SkipUpSample: bilinear x2 -> 1x1 -> + y (gshift_deblur1.py:341-350), upsample fused into the conv loader."""
-        return self.conv(name, [x], in_mode=1, res=y)
+        """SkipUpSample: bilinear x2 -> 1x1 -> + y (gshift_deblur1.py:341-350)."""
+        if not self.skip_up_lowres:
+            return self.conv(name, [x], in_mode=1, res=y)
+        lo = self.conv(name, [x])                             # [T][hs][ws][cs_out]
+        T, hs, ws, cs = lo.dims
+        assert y.dims == (T, 2 * hs, 2 * ws, cs), (y.dims, lo.dims)
+        out = self._new(T, 2 * hs, 2 * ws, cs)
+        self._meta = ("up2add", T, hs, ws, cs)
+        self._call("sn_upsample2_add", f"sn_upsample2_add[{name}]", lo.t.data_ptr(), y.t.data_ptr(), out.data_ptr(), T, hs, ws, cs, self._stream())
+        return Act(out, lo.c)
 
     def tfr_unet(self, pre: str, x: Act, extra: Optional[Act] = None) -> Act:
         """TFR_UNet.forward (gshift_deblur1.py:709-722).  `extra` is added to the result in the epilogue of the last CAB's

@@ -48,7 +48,7 @@ class Plan32(Plan):
         self.offs = prep.shift_offsets_i8(shift_table(V.c1)).to(device)
         self._build()
 
-    def add_conv(self, name: str, key: str, cins: Sequence[int]) -> None:
+    def add_conv(self, name: str, key: str, cins: Sequence[int], shuffle: bool = False) -> None:      # shuffle: the bf16 plan's row order (unused here)
         self.convs[name] = {"key": key, "cins": list(cins)}
 
     def add_cab(self, pre: str, c: int) -> None:
@@ -111,6 +111,7 @@ class Engine32(Engine):
 
     act_dtype = torch.float32
     fused_cab_tail = False
+    skip_up_lowres = False             # SkipUpSample stays "bilinear x2 in the 1x1's loader" here (sn_upsample2_add is a bf16 pass)
     # Dense k = 1 / 3 and grouped-by-8 k = 5 convs with their operands split into bf16 hi + lo parts (three bf16 MFMAs per k-step instead of
     # eight fp32 ones; ~2^-16 per product, fp32 accumulation).  False: exact fp32 products everywhere (v_mfma_f32_16x16x4_f32), about half as
     # fast -- SN_FP32_EXACT=1, `--fp32_exact` on the CLIs and bench.py.  Both are within 1e-4 of the reference (tests/test_gpu_fp32.py runs both).

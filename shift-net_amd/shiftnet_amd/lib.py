@@ -15,10 +15,10 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libshiftnet_hip.so")
 
 SN_F32, SN_F16, SN_BF16 = 0, 1, 2
 
-ABI_VERSION = 15     # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so from before a struct / signature change fails the check in load()
+ABI_VERSION = 16     # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so from before a struct / signature change fails the check in load()
 
 SYMBOLS = [          # include/shiftnet_hip.h, production ABI
-    "sn_abi_version", "sn_selftest_mfma", "sn_ingest", "sn_conv2d", "sn_conv_pool_blocks", "sn_ca_mlp",
+    "sn_abi_version", "sn_selftest_mfma", "sn_ingest", "sn_conv2d", "sn_conv_pool_blocks", "sn_upsample2_add", "sn_ca_mlp",
     "sn_cab_ca", "sn_cab_ca_scratch_floats", "sn_cab_fused_supported", "sn_cab_stats", "sn_cab_ca_lines", "sn_cab_fused", "sn_planar_pitch", "sn_nhwc_to_planar", "sn_dw5m_blocks",
     "sn_dw5m_gemm_gate", "sn_gsts_gather", "sn_temporal_roll", "sn_gsts_shiftconv", "sn_gsts_cab2_phase2", "sn_cab1_phase2",
     "sn_ingest_u8", "sn_egress_blocks", "sn_egress_u8", "sn_ssim_blocks", "sn_ssim_u8",
@@ -116,6 +116,7 @@ def load() -> C.CDLL:
     lib.sn_ingest.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, vp]
     lib.sn_conv2d.argtypes = [C.POINTER(ConvDesc), vp]
     lib.sn_conv_pool_blocks.argtypes = [C.POINTER(ConvDesc)]
+    lib.sn_upsample2_add.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
     lib.sn_ca_mlp.argtypes = [vp, ci, ci, ci, ci, cf, vp, vp, vp, ci, vp, vp]
     lib.sn_planar_pitch.argtypes = [ci]
     lib.sn_nhwc_to_planar.argtypes = [vp, vp, ci, ci, ci, ci, vp]

@@ -60,12 +60,29 @@ def pos_gate(c: int) -> np.ndarray:
     return g * 4 * mt + (2 * q + half) * 4 + r
 
 
-def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], cins: Sequence[int], cs_in: int) -> Dict[str, object]:
+def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], cins: Sequence[int], cs_in: int, shuffle: bool = False) -> Dict[str, object]:
     """Dense conv weight [Cout, sum(cins), k, k] -> implicit-GEMM fragments.
 
     K index = tap*(n_in*cs_in) + i*cs_in + c  (tap = ky*k + kx), rows in 'conv' order.
+    shuffle: the conv of a PixelShufflePack (gshift_deblur1.py:335-350; sn_conv2d out_mode 1).  nn.PixelShuffle(2) sends conv channel 4 c + 2 i + j to
+    output channel c of sub-pixel (i, j); the rows are re-ordered to [sub-pixel 2 i + j][c < cs_out] (zero rows for the storage padding), so the four
+    consecutive rows a lane owns are four consecutive OUTPUT channels of ONE sub-pixel: one 8-byte store instead of four 2-byte ones ('cout' stays the
+    reference's 4 x c_out, 'mt' covers the 4 x cs_out permuted rows).
     """
     w = weight.detach().float().cpu().numpy()
+    if shuffle:
+        c_log = w.shape[0] // 4
+        cs_out = ceil8(c_log)
+        ws = np.zeros((4 * cs_out,) + w.shape[1:], np.float32)
+        bs = np.zeros(4 * cs_out, np.float32)
+        bn = None if bias is None else bias.detach().float().cpu().numpy()
+        for sub in range(4):
+            ws[sub * cs_out:sub * cs_out + c_log] = w[sub::4]
+            if bn is not None:
+                bs[sub * cs_out:sub * cs_out + c_log] = bn[sub::4]
+        p = pack_conv(torch.from_numpy(ws), None if bias is None else torch.from_numpy(bs), cins, cs_in)
+        p["cout"] = w.shape[0]
+        return p
     cout, cin_tot, k, _ = w.shape
     assert cin_tot == sum(cins)
     n_in = len(cins)

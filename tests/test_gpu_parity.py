@@ -160,6 +160,31 @@ def test_conv(case, hw, engines):
         assert out.t[..., out.c:].float().abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("name,conv,cin,cout", [("gshift_deblur2", "stage1.up21", 64, 64), ("gshift_deblur2", "orb1.up21", 18, 14), ("gshift_deblur2", "orb1.up32", 22, 18),
+                                                ("gshift_deblur1", "stage1.up21", 80, 80), ("gshift_deblur1", "orb1.up21", 36, 24), ("gshift_deblur1", "orb1.up32", 48, 36)])
+@pytest.mark.parametrize("T,hw", [(2, (6, 20)), (3, (1, 1)), (1, (9, 37)), (2, (45, 80))])
+def test_skip_upsample_both_forms(name, conv, cin, cout, T, hw, engines):
+    """SkipUpSample (gshift_deblur1.py:341-350: bilinear x2 -> 1x1 -> + skip) in its two forms against the oracle: the 1x1 at low resolution followed by
+    sn_upsample2_add (conv and interpolation commute; the default since round 6) and round 2's interpolation in the loader of a full-resolution conv.
+    One-pixel maps (every source index clamps), odd sizes, pad channels (18 -> 24, 14 -> 16) that must stay zero."""
+    eng, sd = engines(name)
+    h, w = hw
+    lo = bf(torch.from_numpy(synth.unit_noise((T, cin, h, w), seed=63)))
+    sk = bf(torch.from_numpy(synth.unit_noise((T, cout, 2 * h, 2 * w), seed=64)))
+    ref = O.skip_up_sample(sd, conv + ".", lo, sk)
+    for lowres in (True, False):
+        e = _sibling_engine(eng, skip_up_lowres=lowres)
+        called = []
+        orig = e._call
+        e._call = lambda fn, *a: (called.append(fn), orig(fn, *a))[1]
+        out = e.skip_up(conv, act(to_dev(lo), cin), act(to_dev(sk), cout))
+        torch.cuda.synchronize()
+        assert ("sn_upsample2_add" in called) == lowres, called
+        check(f"skip_up_{'lowres' if lowres else 'loader'}_{name}_{conv}_{T}x{h}x{w}", to_cpu(out.t, cout), ref, 8e-3)
+        if out.t.shape[-1] > cout:
+            assert out.t[..., cout:].float().abs().max().item() == 0.0
+
+
 def test_conv_epilogues(engines):
     eng, sd = engines("gshift_deblur2")
     F = torch.nn.functional
