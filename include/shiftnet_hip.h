@@ -84,7 +84,8 @@ typedef struct sn_conv_desc {
                             where the library prefers the tile kernel; bit 9: its residual operand through registers instead of LDS; bits 10..11:
                             prefetch depth code (1 / 2: three / four tiles ahead at 16 channels; 3: the streaming fused CAB with two region buffers);
                             bits 12..14: MEASUREMENTS ONLY, WRONG RESULTS -- the streaming conv without its DMA (1), B reads / MFMAs (2), stores (4);
-                            on conv2 of sn_cab_fused(rows = 0) bit 12 means "both weight sets in LDS" (results unchanged) */
+                            on conv2 of sn_cab_fused(rows = 0) bit 12 means "both weight sets in LDS" (results unchanged); bit 15: stride-2 convs on
+                            4 x 16 tiles whatever their width (measurements; results unchanged) */
 } sn_conv_desc;
 #define SN_CONV_TILE_KERNEL 1
 int sn_conv2d(const sn_conv_desc* d, void* stream);   /* d is a HOST pointer, read during the call */

@@ -847,6 +847,10 @@ static int conv3_key(const sn_conv_desc* d) {
 }
 static void conv_tile(const sn_conv_desc* d, int* th, int* tw) {
     if (d->stride == 1) { *tw = 32; *th = 8; }   // (16x32 tiles for narrow convs measured slower: 47.4 vs 44.2 ms per window)
+    // stride 2: 8 x 32 tiles while the (17 x 65)-pixel input region stays near 50 KB (<= 24 input channels: three workgroups per CU) -- a wave of a
+    // 4 x 16 tile owns ONE N-tile and fetches every weight fragment for a single MFMA; wider inputs keep 4 x 16 (region 106-159 KB at 8 x 32).
+    // Bit 15 of flags: 4 x 16 everywhere (round 5's choice; measurements)
+    else if (d->n_in * d->cs_in <= 24 && !(d->flags & (1 << 15))) { *th = 8; *tw = 32; }
     else { *th = 4; *tw = 16; }
 }
 

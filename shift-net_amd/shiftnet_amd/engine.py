@@ -257,6 +257,7 @@ class Engine:
     conv_dbg = int(os.environ.get("SN_CONV_DBG", "0"))                      # measurements (wrong results): 1 no DMA, 2 no B reads / MFMAs, 4 no stores
     conv_depth = int(os.environ.get("SN_CONV_DEPTH", "0"))                  # measurements: 1 / 2 = three / four tiles of prefetch (16 channels)
     conv_wgs = int(os.environ.get("SN_CONV_WGS", "0"))            # measurements: persistent workgroups per CU of the streaming kernel (0: the library's choice)
+    conv_s2_small = os.environ.get("SN_CONV_S2_SMALL", "0") == "1"  # measurements: stride-2 convs on 4 x 16 tiles whatever their width (round 5's choice)
 
     def conv(self, name: str, ins: Sequence[Act], *, stride: int = 1, pad: Optional[int] = None, prelu: Optional[float] = None,
              res: Optional[Act] = None, out_mode: int = 0, pool: bool = False, in_mode: int = 0, oscale: Optional[torch.Tensor] = None,
@@ -292,6 +293,8 @@ class Engine:
             d.out, d.cs_out, d.c_out = o.data_ptr(), cs_out, cout
         d.out_mode = out_mode
         d.flags = L.SN_CONV_TILE_KERNEL if self.conv_tiles else ((self.conv_wgs << 4) | (256 if self.conv_stream_all else 0) | (512 if self.conv_res_regs else 0) | (self.conv_depth << 10) | (self.conv_dbg << 12))
+        if self.conv_s2_small:
+            d.flags |= 1 << 15
         if res is not None:
             assert out_mode == 0 and res.dims == out_act.dims
             d.res = res.t.data_ptr()
