@@ -42,7 +42,7 @@ def main():
         tot += gb; ms_all += ms_win
         if any(s in k for s in GSTS):
             gsts += gb
-        if ("conv" in k or "cabp" in k or "cab_fused" in k) and "shiftconv" not in k:
+        if ("conv" in k or "cabp" in k or "cab_fused" in k or "upsample2_add" in k) and "shiftconv" not in k:
             conv += gb
     doc = {"note": f"Per-kernel time, HBM traffic, MFMA busy, wave wait / issue share and LDS bank conflicts of bench.py --no-parity --no-cpu-baseline ({name}), every "
                    f"figure per WINDOW: {tag}_{name}_kernel_stats.csv ({nwin} traced steps, each {frac} of a window), {tag}_pmc_hbm_traffic_{name}.json, "

@@ -63,7 +63,7 @@ def main(out, windows, note, dirs):
         doc["window_totals_gb"] = {
             "all_kernels": round(sum(gb(e) for e in mine.values()), 1),
             "gsts_kernels": round(sum(gb(e) for k, e in mine.items() if any(s in k for s in GSTS)), 1),
-            "dense_conv_kernels": round(sum(gb(e) for k, e in mine.items() if ("conv" in k or "cabp" in k or "cab_fused" in k) and "shiftconv" not in k), 1),
+            "dense_conv_kernels": round(sum(gb(e) for k, e in mine.items() if ("conv" in k or "cabp" in k or "cab_fused" in k or "upsample2_add" in k) and "shiftconv" not in k), 1),
             "formula": "2 x FETCH_SIZE + WRITE_SIZE, summed over one window's launches"}
     json.dump(doc, open(out, "w"), indent=1)
     print(f"{len(per_win)} kernels, {len(by_grid)} (kernel, grid) groups, {windows} windows -> {out}", doc.get("window_totals_gb", ""))
