@@ -162,6 +162,143 @@ __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const Xcd
 
 
 // ------------------------------------------------------------------------------------------------------------
+// K0 ON THE MATRIX CORES (round 6; VERDICT r05 item 4 "K0 out of NHWC" -- inside the kernel: the tensors stay NHWC, the LDS window is planar).
+// The seven rebuilds above all kept the arithmetic of shiftconv_kernel -- per output pixel and channel nine 2-byte LDS reads and nine half-empty
+// v_dot2c, 288 + 288 per pixel, because a channel's displaced window is 2 bytes wide in a pixel-major layout.  A depthwise 3x3 has no reduction
+// over channels to feed an MFMA, but it has one over SPACE: for one channel k of a 16 x 16 output tile
+//     out[n][m] = sum_{ty} sum_{j = m .. m + 2} w[ty][j - m] * W_k[n + ty + 8 + sy][j + 8 + sx]          (W: the 34 x 34 window, origin - 9)
+// is a GEMM with M = 16 output columns m, N = 16 output rows n, K = (ty, j) = 3 x 18: A[m][(ty, j)] = w[ty][j - m] is a banded (Toeplitz) matrix of
+// the channel's nine weights (host: prep.pack_shiftconv_toeplitz, three k-steps of 32 slots = (ty, 24 columns j, 18 used)), B[(ty, j)][n] is the
+// window itself -- eight consecutive j are eight consecutive pixels of ONE row of ONE channel: 16 contiguous bytes in a CHANNEL-PLANAR window.  So the
+// loader transposes on its way into LDS (a 16-byte piece = 8 channels of a pixel -> eight 2-byte stores into eight planes; planes skewed by 32
+// bytes per 8 so that the pieces of a pixel hit different banks), and every B fragment is one 8-byte-aligned 16-byte read (shifts are multiples of
+// 4 pixels): 3 reads + 3 MFMAs per channel and 16 x 16 tile instead of 2304 + 2304 VALU-side operations per wave.  The accumulator holds
+// out[x = 4 g + r][y = p] of the channel; a wave owns the 8 channels of one 16-byte piece, so after its eight channels a lane stores four whole
+// pieces.  Workgroups are persistent (64 / 32 per XCD walk that XCD's tile list in order: x-neighbours run concurrently on one L2, as in
+// sn_xcd_tile), the wave's 24 weight fragments stay in registers.  Zero padding of the conv ([p + tap in image]) = masks on the B fragment of
+// border tiles; zero fill of the shift = the window's own zero fill.  Same bf16 products, fp32 accumulation in the MFMA's order: within rounding of
+// shiftconv_kernel, not bit-identical to it.
+#ifndef K0M_SKIP         // measurement builds (tools/k0_ab.py): 1 no window loads / LDS writes, 2 no B reads / MFMAs, 4 no stores -- wrong results
+#define K0M_SKIP 0
+#endif
+template <int CH>
+__global__ __launch_bounds__(CH * 8, 2) void shiftconv_mfma_kernel(const UnitK U, const XcdTiles G, const int nfr, const int per_xcd,
+                                                              const int8_t* __restrict__ offs, const uint4* __restrict__ w1t, bf16_t* hw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RW = 34, PB = 72, PLANE = RW * PB, NTH = CH * 8, PCS = CH / 8;
+    constexpr int NIT = (RW * RW * PCS + NTH - 1) / NTH, NB = 7;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), g = lane >> 4, n = lane & 15;
+    // this wave's channels 8 wv .. 8 wv + 7: Toeplitz fragments (3 k-steps each) and displacements
+    bf16x8_t A[8][3];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) A[c][s] = as_frag(w1t[((wv * 8 + c) * 3 + s) * 64 + lane]);
+    // per-lane geometry of the B fragments: k-step s, lane group g -> slot group q = 4 s + g = (ty, jg); q >= 9: no such slots
+    int boff[3];
+    uint4 bmask[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int q = 4 * s + g, ty = q / 3, jg = q - ty * 3;
+        boff[s] = q < 9 ? ty * PB + jg * 16 : 0;
+        const unsigned all = q < 9 ? 0xffffffffu : 0u;
+        bmask[s] = make_uint4(all, (q < 9 && jg < 2) ? 0xffffffffu : 0u, (q < 9 && jg < 2) ? 0xffffffffu : 0u, (q < 9 && jg < 2) ? 0xffffffffu : 0u);   // jg = 2: columns 16, 17 only
+    }
+    const int xcd = (int)blockIdx.x & 7, j0 = (int)blockIdx.x >> 3, nwg = (int)gridDim.x >> 3;
+    const int ntile_x = per_xcd * G.ntx;                      // tiles of this XCD's run of row-frames
+    for (int i = j0; i < ntile_x; i += nwg) {
+        const int rfl = i / G.ntx, tx_ = i - rfl * G.ntx;
+        const int rf = xcd * per_xcd + rfl;
+        if (rf >= G.nrf) break;                               // workgroup-uniform: the last XCD's run is shorter
+        int t = rf / G.nty;
+        const int ty_ = rf - t * G.nty;
+        t += U.t0;
+        const int y0 = ty_ * 16, x0 = tx_ * 16;
+        const SnSlabs<bf16_t> sl = unit_slabs(U, t);
+        const bf16_t* src = sl.pb;
+        const int sstr = sl.sb;
+        // window -> planar LDS in batches of NB pieces per thread (the whole window at once -- 19 pieces = 76 registers -- next to the 96 of the
+        // weight fragments does not fit two waves per SIMD): per batch all global loads first (branch-free, clamped addresses), then eight 2-byte
+        // stores per piece
+#pragma unroll
+        for (int k0 = 0; k0 < ((K0M_SKIP & 1) ? 0 : NIT); k0 += NB) {
+            uint4 v[NB];
+            int lo[NB];
+#pragma unroll
+            for (int kk = 0; kk < NB; ++kk) {
+                const int idx = tid + (k0 + kk) * NTH;
+                const int pix = idx / PCS, pc = idx - pix * PCS;
+                const int ry = pix / RW, rx = pix - ry * RW;
+                const int gy = y0 - 9 + ry, gx = x0 - 9 + rx;
+                const bool in = idx < RW * RW * PCS && gy >= 0 && gy < U.h && gx >= 0 && gx < U.w;
+                const int a = (pc * 8) * PLANE + pc * 32 + ry * PB + rx * 2;
+                lo[kk] = (k0 + kk < NIT && idx < RW * RW * PCS) ? (in ? a : -a - 1) : 0x7fffffff;
+                v[kk] = *(const uint4*)(src + (in ? ((size_t)gy * U.w + gx) * sstr + pc * 8 : 0));
+            }
+#pragma unroll
+            for (int kk = 0; kk < NB; ++kk) {
+                if (lo[kk] == 0x7fffffff) continue;
+                const bool in = lo[kk] >= 0;
+                char* d = smem + (in ? lo[kk] : -(lo[kk] + 1));
+                const uint4 q = in ? v[kk] : make_uint4(0, 0, 0, 0);
+                *(uint16_t*)(d + 0 * PLANE) = (uint16_t)(q.x & 0xffffu); *(uint16_t*)(d + 1 * PLANE) = (uint16_t)(q.x >> 16);
+                *(uint16_t*)(d + 2 * PLANE) = (uint16_t)(q.y & 0xffffu); *(uint16_t*)(d + 3 * PLANE) = (uint16_t)(q.y >> 16);
+                *(uint16_t*)(d + 4 * PLANE) = (uint16_t)(q.z & 0xffffu); *(uint16_t*)(d + 5 * PLANE) = (uint16_t)(q.z >> 16);
+                *(uint16_t*)(d + 6 * PLANE) = (uint16_t)(q.w & 0xffffu); *(uint16_t*)(d + 7 * PLANE) = (uint16_t)(q.w >> 16);
+            }
+        }
+        __syncthreads();
+        const bool interior = y0 >= 1 && x0 >= 1 && y0 + 16 < U.h && x0 + 16 < U.w;      // every tap of every output pixel inside the image
+        uint4 tmask[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) tmask[s] = bmask[s];
+        if (!interior) {            // conv zero padding: the UNSHIFTED position (y0 + n + ty - 1, x0 + j - 1) of a B element must be inside the image
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int q = 4 * s + g, ty = q / 3, jg = q - ty * 3;
+                const int qy = y0 + n + ty - 1;
+                const bool rowin = qy >= 0 && qy < U.h;
+                unsigned w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qx0 = x0 + jg * 8 + 2 * e - 1, qx1 = qx0 + 1;
+                    w[e] = ((rowin && qx0 >= 0 && qx0 < U.w) ? 0x0000ffffu : 0u) | ((rowin && qx1 >= 0 && qx1 < U.w) ? 0xffff0000u : 0u);
+                }
+                tmask[s].x &= w[0]; tmask[s].y &= w[1]; tmask[s].z &= w[2]; tmask[s].w &= w[3];
+            }
+        }
+        float res[8][4];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int k = wv * 8 + c;
+            const int sy = offs[2 * k], sx = offs[2 * k + 1];                       // multiples of 4: the 16-byte reads below are 8-byte aligned
+            const char* rb = smem + k * PLANE + wv * 32 + (n + 8 + sy) * PB + (8 + sx) * 2;
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < ((K0M_SKIP & 2) ? 0 : 3); ++s) {
+                const uint2 b0 = *(const uint2*)(rb + boff[s]), b1 = *(const uint2*)(rb + boff[s] + 8);
+                const uint4 b = make_uint4(b0.x & tmask[s].x, b0.y & tmask[s].y, b1.x & tmask[s].z, b1.y & tmask[s].w);
+                acc = mfma16(A[c][s], as_frag(b), acc);
+            }
+            res[c][0] = acc[0]; res[c][1] = acc[1]; res[c][2] = acc[2]; res[c][3] = acc[3];
+        }
+        // lane (g, n): out[y0 + n][x0 + 4 g + r] of the wave's 8 channels = one 16-byte piece per r
+        const int oy = y0 + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ox = x0 + 4 * g + r;
+            if (oy < U.h && ox < U.w && !(K0M_SKIP & 4)) {
+                float o[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) o[c] = res[c][r];
+                *(uint4*)(hw + (((size_t)t * U.h + oy) * U.w + ox) * CH + wv * 8) = pack8(o);
+            }
+        }
+        __syncthreads();                                     // every wave is done with the window before the next one is written
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // K4: y = shortcut + W3' . (ca * g2) (+ bias'), beta folded into W3'/bias'; shortcut = rolled x (CAB2) or x (CAB1)
 // waves-per-SIMD target: see the register-budget note in sn_conv.hip (91 VGPRs + 80 AGPRs = 2 waves without it; 148 / 152 = 3 waves)
 // NT = N-tiles (16 pixels) per wave = 4: 148 / 152 registers, 3 waves per SIMD, the shortcut is loaded after the MFMAs.  (NT = 2 with the
@@ -318,6 +455,35 @@ int cab_phase2(const sn_unit_src* s, const void* g2, const float* ca, const void
 }  // namespace
 
 extern "C" {
+
+// K0 on the matrix cores (shiftconv_mfma_kernel): w1t = prep.pack_shiftconv_toeplitz: bf16 [C/2][3][64][8] banded A fragments of the nine taps
+int sn_gsts_shiftconv_mfma(const sn_unit_src* s, const int8_t* offs, const void* w1t, void* hw, void* stream) {
+    sn_clear_error();
+    if (!unit_ok(s) || !offs || !w1t || !hw || s->mode == 0) return SN_EINVAL;
+    SN_FRAME_RANGE(s, t0, nt);
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) {
+        (void)hipGetLastError();
+        return SN_ELAUNCH;
+    }
+    XcdTiles G = sn_xcd_tiles((s->w + 15) / 16, (s->h + 15) / 16, nt);
+    const int per_xcd = (G.nrf + 7) / 8;
+    const int CH = s->C / 2;
+    const size_t lds = (size_t)CH * 34 * 72 + (CH / 8) * 32 + 64;
+    int wgs = (s->C == 64 ? 2 : 1) * ncu / 8;                                // persistent workgroups per XCD (LDS: 78 / 98 KB each)
+    const long tiles_x = (long)per_xcd * G.ntx;
+    if (wgs > tiles_x) wgs = (int)tiles_x;
+    if (wgs < 1) wgs = 1;
+    const dim3 grid(8u * (unsigned)wgs);
+    if (s->C == 64) {
+        if (hipFuncSetAttribute((const void*)shiftconv_mfma_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH;
+        hipLaunchKernelGGL((shiftconv_mfma_kernel<32>), grid, dim3(256), lds, (hipStream_t)stream, to_k(s), G, nt, per_xcd, offs, (const uint4*)w1t, (bf16_t*)hw);
+    } else {
+        if (hipFuncSetAttribute((const void*)shiftconv_mfma_kernel<40>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH;
+        hipLaunchKernelGGL((shiftconv_mfma_kernel<40>), grid, dim3(320), lds, (hipStream_t)stream, to_k(s), G, nt, per_xcd, offs, (const uint4*)w1t, (bf16_t*)hw);
+    }
+    return sn_check_launch();
+}
 
 int sn_gsts_cab2_phase2(const sn_unit_src* s, const void* g2, const float* ca, const void* wfrag, const float* bias, void* y, void* stream) {
     if (!s || (s->mode != 1 && s->mode != 2)) return SN_EINVAL;

@@ -108,6 +108,7 @@ class Plan:
         if with_shift:
             w1 = sd[pre + "conv1.weight"].reshape(c // 2, 9)
             u["w1"] = self._dev((w1.to(torch.bfloat16).view(torch.int16).to(torch.int32) & 0xFFFF).contiguous())   # bf16 in the low half
+            u["w1t"] = self._dev(prep.pack_shiftconv_toeplitz(sd[pre + "conv1.weight"]))                               # K0 on the matrix cores
         g = prep.pack_ln_gemm(sd[f"{pre}body.{i}.weight"], sd[pre + "norm.weight"], sd[pre + "norm.bias"], c); i += 1
         u["w_ln"], u["b_ln"] = self._dev(g["wfrag"]), self._dev(g["bias"])
         w3 = prep.pack_dw3_gate(sd[f"{pre}body.{i}.conv_2.weight"], c); i += 1
@@ -322,6 +323,9 @@ class Engine:
         return ca
 
     # ---- blocks (oracle/shiftnet_oracle.py has the same names) ----------------------------------------------
+    # K0 = CAB2.conv1(spatial_shift2(borrowed half)): "1" the depthwise 3x3 as a banded GEMM on the matrix cores over a channel-planar LDS window
+    # (sn_gsts_shiftconv_mfma, round 6); "0" the VALU kernel of rounds 1-5 (nine 2-byte LDS reads + nine v_dot2c per pixel and channel)
+    k0_mfma = os.environ.get("SN_K0_MFMA", "1") != "0"
     fold_se = True             # fused phase 1: CALayer2's MLP is finished by the frame's last workgroup (sn_se_fold) instead of an sn_ca_mlp launch
     # Phase 1 of CAB2 / CAB1.  "r": the role-split fused kernel (csrc/sn_phase1r.hip, every variant; `a`, g1 = a1 a2 2^-4 and r are fp16 inside it);
     # "0": the two-kernel chain sn_ln_gemm_gate + sn_dw5m_gemm_gate / sn_grp5_gemm_gate (g1 in bf16 through HBM: a product of two activations
@@ -541,7 +545,10 @@ class Engine:
             src = self._unit_src(x, mode, wrap=wrap, halo=halo, t0=t0, nt=nt)
             f0, n = (t0, nt) if nt else (0, T)           # frame range of this piece for the operators that take plain pointers
             if mode:
-                self._call("sn_gsts_shiftconv", "sn_gsts_shiftconv", C.byref(src), P.offs.data_ptr(), u["w1"].data_ptr(), hwb.data_ptr(), st)
+                if self.k0_mfma:
+                    self._call("sn_gsts_shiftconv_mfma", "sn_gsts_shiftconv", C.byref(src), P.offs.data_ptr(), u["w1t"].data_ptr(), hwb.data_ptr(), st)
+                else:
+                    self._call("sn_gsts_shiftconv", "sn_gsts_shiftconv", C.byref(src), P.offs.data_ptr(), u["w1"].data_ptr(), hwb.data_ptr(), st)
             hw_ptr = hwb.data_ptr() if mode else None
             folded = False
             if fused:

@@ -20,7 +20,7 @@ ABI_VERSION = 16     # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so 
 SYMBOLS = [          # include/shiftnet_hip.h, production ABI
     "sn_abi_version", "sn_selftest_mfma", "sn_ingest", "sn_conv2d", "sn_conv_pool_blocks", "sn_upsample2_add", "sn_ca_mlp",
     "sn_cab_ca", "sn_cab_ca_scratch_floats", "sn_cab_fused_supported", "sn_cab_stats", "sn_cab_ca_lines", "sn_cab_fused", "sn_planar_pitch", "sn_nhwc_to_planar", "sn_dw5m_blocks",
-    "sn_dw5m_gemm_gate", "sn_gsts_gather", "sn_temporal_roll", "sn_gsts_shiftconv", "sn_gsts_cab2_phase2", "sn_cab1_phase2",
+    "sn_dw5m_gemm_gate", "sn_gsts_gather", "sn_temporal_roll", "sn_gsts_shiftconv", "sn_gsts_shiftconv_mfma", "sn_gsts_cab2_phase2", "sn_cab1_phase2",
     "sn_ingest_u8", "sn_egress_blocks", "sn_egress_u8", "sn_ssim_blocks", "sn_ssim_u8",
     "sn32_conv2d", "sn32_gsts_gather", "sn32_layernorm", "sn32_gate", "sn32_gate_sum", "sn32_chan_sum", "sn32_scale_residual", "sn32_ingest", "sn32_cab_ca", "sn32_dw_gate", "sn32_conv1x1_gate2", "sn32_gsts_shiftconv", "sn32_conv_csum_tiles",
     "sn_ln_gemm_gate", "sn_lngate_blocks", "sn_grp5_gemm_gate", "sn_grp5_blocks", "sn_gsts_cab2_phase1", "sn_cab1_phase1", "sn_phase1_pool_blocks", "sn_p1r_plan", "sn_p1r_strip_begin",
@@ -132,6 +132,7 @@ def load() -> C.CDLL:
     lib.sn_gsts_gather.argtypes = [C.POINTER(UnitSrc), vp, vp, vp]
     lib.sn_temporal_roll.argtypes = [C.POINTER(UnitSrc), vp, vp]
     lib.sn_gsts_shiftconv.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp]
+    lib.sn_gsts_shiftconv_mfma.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp]
     lib.sn_ln_gemm_gate.argtypes = [C.POINTER(UnitSrc), vp, vp, vp, vp, vp, vp, ci, vp]
     lib.sn_lngate_blocks.argtypes = [ci, ci]
     lib.sn_grp5_gemm_gate.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]

@@ -341,6 +341,38 @@ def test_streaming_conv_is_bit_identical_to_the_tile_kernel(name, pre, c, T, hw,
                                     torch.tensor([slope])), 8e-3)
 
 
+@pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_deblur1", "gshift_denoise1"])
+@pytest.mark.parametrize("T,hw", [(4, (20, 44)), (2, (16, 16)), (3, (37, 70)), (2, (64, 96)), (1, (5, 3)), (5, (90, 160))])
+def test_shiftconv_on_the_matrix_cores(name, T, hw, engines):
+    """K0 = CAB2.conv1(spatial_shift2(borrowed half)) (gshift_deblur1.py:470-503,223,251) as a banded GEMM over a channel-planar LDS window
+    (sn_gsts_shiftconv_mfma) against the oracle -- temporal roll, 24 displacements with zero fill, depthwise 3x3 with zero padding -- and against
+    the VALU kernel of rounds 1-5 (same bf16 products, another accumulation order): both directions, C = 64 and 80, maps smaller than a tile,
+    ragged right / bottom tiles (the conv's padding masks on border tiles), interior tiles, several tiles per persistent workgroup."""
+    from shiftnet_amd import lib as L
+    eng, sd = engines(name)
+    V = O.VARIANTS[name]
+    C, (h, w) = V.c1, hw
+    x = bf(torch.from_numpy(synth.unit_noise((T, C, h, w), seed=82)))
+    xd = act(to_dev(x), C)
+    blk = "stage1.decoder_level1."
+    st = torch.cuda.current_stream().cuda_stream
+    for mode, rev, unit in ((1, False, "encoder_level1."), (2, True, "encoder_level1_1.")):
+        pre = blk + unit + "0."
+        src = eng._unit_src(xd, mode)
+        new = torch.full((T, h, w, C // 2), float("nan"), dtype=torch.bfloat16, device=DEV)
+        old = torch.empty_like(new)
+        L.check(eng.lib.sn_gsts_shiftconv_mfma(C_byref(src), eng.P.offs.data_ptr(), eng.P.units[pre]["w1t"].data_ptr(), new.data_ptr(), st), "shiftconv_mfma")
+        L.check(eng.lib.sn_gsts_shiftconv(C_byref(src), eng.P.offs.data_ptr(), eng.P.units[pre]["w1"].data_ptr(), old.data_ptr(), st), "shiftconv")
+        torch.cuda.synchronize()
+        _, hw_ref = O.temporal_roll(x, rev, V.wrap)
+        hw_ref = torch.nn.functional.conv2d(O.spatial_shift(hw_ref.contiguous()), sd[pre + "conv1.weight"], padding=1, groups=C // 2)
+        assert torch.isfinite(new.float()).all()
+        check(f"shiftconv_mfma_{name}_{mode}_{T}x{h}x{w}", to_cpu(new, C // 2), hw_ref, 8e-3)
+        # the two kernels round the same fp32 sums (up to the order of nine additions) to bf16: at most one bf16 step apart
+        d = (new.float() - old.float()).abs()
+        assert (d <= 2.0 ** -7 * old.float().abs().clamp_min(2.0 ** -10)).all(), d.max().item()
+
+
 @pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_denoise2", "gshift_deblur1", "gshift_denoise1"])
 def test_gsts_pieces(name, engines):
     """shiftconv alone, then CAB2 (both directions), CAB1, a whole unit and a whole Encoder_shift_block (production chain)."""
