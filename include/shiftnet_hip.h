@@ -171,13 +171,13 @@ int sn_temporal_roll(const sn_unit_src* s, void* y, void* stream);
  * zero-padded displaced neighbour-frame channels, never materialising the shifted tensor.
  * w1:[C/2][9] u32 words: the bf16 weight in the LOW half, high half zero (operand of v_dot2c_f32_bf16). */
 int sn_gsts_shiftconv(const sn_unit_src* s, const int8_t* offs, const uint32_t* w1, void* hw, void* stream);
-/* The same operator on the matrix cores (round 6): per channel and 16 x 16 output tile the depthwise 3x3 is the banded GEMM
+/* The same operator on the matrix cores (round 6), same operands: per channel and 16 x 16 output tile the depthwise 3x3 is the banded GEMM
  *   out[n][m] = sum_{ty, j} A[m][(ty, j)] * W[n + ty + 8 + dy_k][j + 8 + dx_k],   A[m][(ty, j)] = w[ty][j - m] for 0 <= j - m <= 2,
  * over a CHANNEL-PLANAR 34 x 34 LDS window (the loader transposes; hw and x stay NHWC): three 16-byte LDS reads + three MFMAs per channel and tile
- * instead of 9 two-byte reads + 9 v_dot2c per pixel and channel.  w1t = prep.pack_shiftconv_toeplitz: bf16 [C/2][3][64][8] A fragments.  Every
- * displacement in offs must be a multiple of 4 pixels (spec.shift_table: they are).  Same products, another accumulation order: within rounding of
- * sn_gsts_shiftconv, not bit-identical to it. */
-int sn_gsts_shiftconv_mfma(const sn_unit_src* s, const int8_t* offs, const void* w1t, void* hw, void* stream);
+ * instead of 9 two-byte reads + 9 v_dot2c per pixel and channel; the A fragments are built in registers from the nine weights (one v_perm_b32 per
+ * word).  Every displacement in offs must be a multiple of 4 pixels (spec.shift_table: they are).  Same products, another accumulation order:
+ * within rounding of sn_gsts_shiftconv, not bit-identical to it. */
+int sn_gsts_shiftconv_mfma(const sn_unit_src* s, const int8_t* offs, const uint32_t* w1, void* hw, void* stream);
 
 /* g1 = SimpleGate(RepConv2(body[0](norm(cat(shortcut, hw))))): LayerNorm2d over 3C/2 (CAB2) or C (CAB1) channels (eps 1e-6,
  * affine folded into the 1x1 weights), the 1x1 conv to 2C on MFMA, depthwise 3x3 + identity and the gate, with the 2C-channel

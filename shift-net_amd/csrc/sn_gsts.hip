@@ -167,42 +167,59 @@ __global__ __launch_bounds__(256) void shiftconv_kernel(const UnitK U, const Xcd
 // v_dot2c, 288 + 288 per pixel, because a channel's displaced window is 2 bytes wide in a pixel-major layout.  A depthwise 3x3 has no reduction
 // over channels to feed an MFMA, but it has one over SPACE: for one channel k of a 16 x 16 output tile
 //     out[n][m] = sum_{ty} sum_{j = m .. m + 2} w[ty][j - m] * W_k[n + ty + 8 + sy][j + 8 + sx]          (W: the 34 x 34 window, origin - 9)
-// is a GEMM with M = 16 output columns m, N = 16 output rows n, K = (ty, j) = 3 x 18: A[m][(ty, j)] = w[ty][j - m] is a banded (Toeplitz) matrix of
-// the channel's nine weights (host: prep.pack_shiftconv_toeplitz, three k-steps of 32 slots = (ty, 24 columns j, 18 used)), B[(ty, j)][n] is the
-// window itself -- eight consecutive j are eight consecutive pixels of ONE row of ONE channel: 16 contiguous bytes in a CHANNEL-PLANAR window.  So the
-// loader transposes on its way into LDS (a 16-byte piece = 8 channels of a pixel -> eight 2-byte stores into eight planes; planes skewed by 32
-// bytes per 8 so that the pieces of a pixel hit different banks), and every B fragment is one 8-byte-aligned 16-byte read (shifts are multiples of
-// 4 pixels): 3 reads + 3 MFMAs per channel and 16 x 16 tile instead of 2304 + 2304 VALU-side operations per wave.  The accumulator holds
-// out[x = 4 g + r][y = p] of the channel; a wave owns the 8 channels of one 16-byte piece, so after its eight channels a lane stores four whole
-// pieces.  Workgroups are persistent (64 / 32 per XCD walk that XCD's tile list in order: x-neighbours run concurrently on one L2, as in
-// sn_xcd_tile), the wave's 24 weight fragments stay in registers.  Zero padding of the conv ([p + tap in image]) = masks on the B fragment of
-// border tiles; zero fill of the shift = the window's own zero fill.  Same bf16 products, fp32 accumulation in the MFMA's order: within rounding of
-// shiftconv_kernel, not bit-identical to it.
+// is a GEMM with M = 16 output columns m, N = 16 output rows n, K = (ty, j): k-step ty = 32 slots j (18 used).  A[m][(ty, j)] = w[ty][j - m] is
+// a banded (Toeplitz) matrix of the channel's nine weights; B[(ty, j)][n] is the window itself -- eight consecutive j are eight consecutive pixels
+// of ONE row of ONE channel: 16 contiguous bytes in a CHANNEL-PLANAR window.  So the loader transposes on its way into LDS (a 16-byte piece =
+// 8 channels of a pixel -> eight 2-byte stores into eight planes; planes skewed by 32 bytes per 8 so that the pieces of a pixel hit different
+// banks), and a B fragment is one 8-byte-aligned 16-byte read (shifts are multiples of 4 pixels): 3 reads + 3 MFMAs per channel and 16 x 16 tile
+// instead of 2304 + 2304 VALU-side operations per wave.
+// The A fragments are never stored: with ty = the k-step, a lane's fragment word is two of {w[ty][0], w[ty][1], w[ty][2], 0} chosen by the lane's
+// (m, j) alone -- ONE v_perm_b32 with a per-lane selector (4 registers for the whole kernel) on two wave-uniform words of the channel's weights.
+// (The first version kept 24 host-built fragments per wave in 96 registers and had to stage the window in three batches, three exposed
+// memory round trips per tile: 296 us at C = 64, 20 x 360 x 640, of which the loader 160 -- profiles/r06_k0_mfma_first_version_ablation.txt.)
+// The accumulator holds out[x = 4 g + r][y = p] of the channel; a wave owns the 8 channels of one 16-byte piece, so after its eight channels a
+// lane stores four whole pieces.  Workgroups are persistent (64 / 32 per XCD walk that XCD's tile list in order: x-neighbours run concurrently
+// on one L2, as in sn_xcd_tile).  Zero padding of the conv ([p + tap in image]) = masks on the B fragment of border tiles; zero fill of the
+// shift = the window's own zero fill.  Same bf16 products, fp32 accumulation in the MFMA's order: within rounding of shiftconv_kernel.
 #ifndef K0M_SKIP         // measurement builds (tools/k0_ab.py): 1 no window loads / LDS writes, 2 no B reads / MFMAs, 4 no stores -- wrong results
 #define K0M_SKIP 0
 #endif
 template <int CH>
 __global__ __launch_bounds__(CH * 8, 2) void shiftconv_mfma_kernel(const UnitK U, const XcdTiles G, const int nfr, const int per_xcd,
-                                                              const int8_t* __restrict__ offs, const uint4* __restrict__ w1t, bf16_t* hw) {
+                                                              const int8_t* __restrict__ offs, const uint32_t* __restrict__ w1d, bf16_t* hw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RW = 34, PB = 72, PLANE = RW * PB, NTH = CH * 8, PCS = CH / 8;
-    constexpr int NIT = (RW * RW * PCS + NTH - 1) / NTH, NB = 7;
     const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), g = lane >> 4, n = lane & 15;
-    // this wave's channels 8 wv .. 8 wv + 7: Toeplitz fragments (3 k-steps each) and displacements
-    bf16x8_t A[8][3];
+    // A-fragment selectors: word e of a lane's fragment = elements j = 8 g + 2 e, + 1 of row m = n: weight index tx = j - m in 0..2, else zero.
+    // v_perm_b32 (S0 = w[ty][0] | w[ty][1] << 16, S1 = w[ty][2]): selector bytes 4..7 = S0, 0..3 = S1, 0x0c = 0x00
+    unsigned asel[4];
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
+    for (int e = 0; e < 4; ++e) {
+        const int tx0 = 8 * g + 2 * e - n, tx1 = tx0 + 1;
+        const unsigned lo = tx0 == 0 ? 0x0504u : tx0 == 1 ? 0x0706u : tx0 == 2 ? 0x0100u : 0x0c0cu;
+        const unsigned hi = tx1 == 0 ? 0x0504u : tx1 == 1 ? 0x0706u : tx1 == 2 ? 0x0100u : 0x0c0cu;
+        asel[e] = lo | (hi << 16);
+    }
+    // B fragment of k-step ty, lane group g: window row n + ty + 8 + sy, columns 8 g + 8 + sx .. + 7; g = 2: columns 16, 17 only; g = 3: no such slots
+    const uint4 bmask = make_uint4(g < 3 ? 0xffffffffu : 0u, g < 2 ? 0xffffffffu : 0u, g < 2 ? 0xffffffffu : 0u, g < 2 ? 0xffffffffu : 0u);
+    const int bcol = (g < 3 ? g : 0) * 16;
+    // A thread stages PAIRS of horizontally adjacent window pixels (rx even), one 8-channel piece of each: two 16-byte loads, then per channel ONE
+    // 4-byte LDS store of (pixel rx, pixel rx + 1) -- v_perm_b32 of the two pixels' words -- instead of two 2-byte ones (half the LDS store
+    // instructions of the first version: they were ~40 % of the loader's time).  The pairs of a thread do not depend on the tile: geo = ry << 8 | rx,
+    // lad = LDS address in plane 8 pc (-1: beyond the window), gpix = pixel offset from the window's first pixel; the piece index pc is the same for
+    // all of them (NTH is a multiple of PCS).
+    static_assert(NTH % PCS == 0 && RW % 2 == 0, "a thread's pieces share the piece index; pixel pairs do not straddle rows");
+    constexpr int NPAIR = RW * (RW / 2) * PCS, NITP = (NPAIR + NTH - 1) / NTH;
+    int geo[NITP], lad[NITP], gpix[NITP];
+    const int mypc = tid % PCS;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) A[c][s] = as_frag(w1t[((wv * 8 + c) * 3 + s) * 64 + lane]);
-    // per-lane geometry of the B fragments: k-step s, lane group g -> slot group q = 4 s + g = (ty, jg); q >= 9: no such slots
-    int boff[3];
-    uint4 bmask[3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const int q = 4 * s + g, ty = q / 3, jg = q - ty * 3;
-        boff[s] = q < 9 ? ty * PB + jg * 16 : 0;
-        const unsigned all = q < 9 ? 0xffffffffu : 0u;
-        bmask[s] = make_uint4(all, (q < 9 && jg < 2) ? 0xffffffffu : 0u, (q < 9 && jg < 2) ? 0xffffffffu : 0u, (q < 9 && jg < 2) ? 0xffffffffu : 0u);   // jg = 2: columns 16, 17 only
+    for (int k = 0; k < NITP; ++k) {
+        const int idx = tid + k * NTH, idc = idx < NPAIR ? idx : 0;
+        const int pr = idc / PCS;
+        const int ry = pr / (RW / 2), rx = (pr - ry * (RW / 2)) * 2;
+        geo[k] = ry << 8 | rx;
+        lad[k] = idx < NPAIR ? (mypc * 8) * PLANE + mypc * 32 + ry * PB + rx * 2 : -1;
+        gpix[k] = ry * U.w + rx;
     }
     const int xcd = (int)blockIdx.x & 7, j0 = (int)blockIdx.x >> 3, nwg = (int)gridDim.x >> 3;
     const int ntile_x = per_xcd * G.ntx;                      // tiles of this XCD's run of row-frames
@@ -210,61 +227,63 @@ __global__ __launch_bounds__(CH * 8, 2) void shiftconv_mfma_kernel(const UnitK U
         const int rfl = i / G.ntx, tx_ = i - rfl * G.ntx;
         const int rf = xcd * per_xcd + rfl;
         if (rf >= G.nrf) break;                               // workgroup-uniform: the last XCD's run is shorter
-        int t = rf / G.nty;
-        const int ty_ = rf - t * G.nty;
-        t += U.t0;
-        const int y0 = ty_ * 16, x0 = tx_ * 16;
-        const SnSlabs<bf16_t> sl = unit_slabs(U, t);
+        int tc = rf / G.nty;
+        const int ty_ = rf - tc * G.nty;
+        tc += U.t0;
+        const int yc = ty_ * 16, xc = tx_ * 16;
+        const SnSlabs<bf16_t> sl = unit_slabs(U, tc);
         const bf16_t* src = sl.pb;
         const int sstr = sl.sb;
-        // window -> planar LDS in batches of NB pieces per thread (the whole window at once -- 19 pieces = 76 registers -- next to the 96 of the
-        // weight fragments does not fit two waves per SIMD): per batch all global loads first (branch-free, clamped addresses), then eight 2-byte
-        // stores per piece
+        if (!(K0M_SKIP & 1)) {   // window -> planar LDS: ALL global loads first (one memory round trip per tile), then the LDS stores.
+            // (Issuing the NEXT tile's loads before this tile's MFMAs -- 80 registers live across the arithmetic -- spilled and ran 419 instead of
+            // 286 us at C = 64, 20 x 360 x 640; two workgroups per CU overlap the phases instead.)
+            uint4 v0[NITP], v1[NITP];
+            const bool wfull = yc >= 9 && xc >= 9 && yc + 25 <= U.h && xc + 25 <= U.w;      // workgroup-uniform: no test at all inside the image
+            const bf16_t* wsrc = src + ((ptrdiff_t)(yc - 9) * U.w + (xc - 9)) * sstr + mypc * 8;
+            if (wfull) {
 #pragma unroll
-        for (int k0 = 0; k0 < ((K0M_SKIP & 1) ? 0 : NIT); k0 += NB) {
-            uint4 v[NB];
-            int lo[NB];
+                for (int k = 0; k < NITP; ++k) {
+                    const bf16_t* q = wsrc + (ptrdiff_t)gpix[k] * sstr;
+                    v0[k] = *(const uint4*)q; v1[k] = *(const uint4*)(q + sstr);
+                }
+            } else {
 #pragma unroll
-            for (int kk = 0; kk < NB; ++kk) {
-                const int idx = tid + (k0 + kk) * NTH;
-                const int pix = idx / PCS, pc = idx - pix * PCS;
-                const int ry = pix / RW, rx = pix - ry * RW;
-                const int gy = y0 - 9 + ry, gx = x0 - 9 + rx;
-                const bool in = idx < RW * RW * PCS && gy >= 0 && gy < U.h && gx >= 0 && gx < U.w;
-                const int a = (pc * 8) * PLANE + pc * 32 + ry * PB + rx * 2;
-                lo[kk] = (k0 + kk < NIT && idx < RW * RW * PCS) ? (in ? a : -a - 1) : 0x7fffffff;
-                v[kk] = *(const uint4*)(src + (in ? ((size_t)gy * U.w + gx) * sstr + pc * 8 : 0));
+                for (int k = 0; k < NITP; ++k) {
+                    const int gy = yc - 9 + (geo[k] >> 8), gx = xc - 9 + (geo[k] & 255);
+                    const bool iny = gy >= 0 && gy < U.h, in0 = iny && gx >= 0 && gx < U.w, in1 = iny && gx + 1 >= 0 && gx + 1 < U.w;
+                    const bf16_t* q = wsrc + (ptrdiff_t)gpix[k] * sstr;
+                    const uint4 a = *(const uint4*)(in0 ? q : src), b = *(const uint4*)(in1 ? q + sstr : src);
+                    v0[k] = in0 ? a : make_uint4(0, 0, 0, 0); v1[k] = in1 ? b : make_uint4(0, 0, 0, 0);
+                }
             }
 #pragma unroll
-            for (int kk = 0; kk < NB; ++kk) {
-                if (lo[kk] == 0x7fffffff) continue;
-                const bool in = lo[kk] >= 0;
-                char* d = smem + (in ? lo[kk] : -(lo[kk] + 1));
-                const uint4 q = in ? v[kk] : make_uint4(0, 0, 0, 0);
-                *(uint16_t*)(d + 0 * PLANE) = (uint16_t)(q.x & 0xffffu); *(uint16_t*)(d + 1 * PLANE) = (uint16_t)(q.x >> 16);
-                *(uint16_t*)(d + 2 * PLANE) = (uint16_t)(q.y & 0xffffu); *(uint16_t*)(d + 3 * PLANE) = (uint16_t)(q.y >> 16);
-                *(uint16_t*)(d + 4 * PLANE) = (uint16_t)(q.z & 0xffffu); *(uint16_t*)(d + 5 * PLANE) = (uint16_t)(q.z >> 16);
-                *(uint16_t*)(d + 6 * PLANE) = (uint16_t)(q.w & 0xffffu); *(uint16_t*)(d + 7 * PLANE) = (uint16_t)(q.w >> 16);
+            for (int k = 0; k < NITP; ++k) {
+                if (k == NITP - 1 && lad[k] < 0) continue;                // only the last pair of a thread can be beyond the window
+                char* d = smem + lad[k];
+                const uint4 a = v0[k], b = v1[k];
+                *(uint32_t*)(d + 0 * PLANE) = __builtin_amdgcn_perm(b.x, a.x, 0x05040100u); *(uint32_t*)(d + 1 * PLANE) = __builtin_amdgcn_perm(b.x, a.x, 0x07060302u);
+                *(uint32_t*)(d + 2 * PLANE) = __builtin_amdgcn_perm(b.y, a.y, 0x05040100u); *(uint32_t*)(d + 3 * PLANE) = __builtin_amdgcn_perm(b.y, a.y, 0x07060302u);
+                *(uint32_t*)(d + 4 * PLANE) = __builtin_amdgcn_perm(b.z, a.z, 0x05040100u); *(uint32_t*)(d + 5 * PLANE) = __builtin_amdgcn_perm(b.z, a.z, 0x07060302u);
+                *(uint32_t*)(d + 6 * PLANE) = __builtin_amdgcn_perm(b.w, a.w, 0x05040100u); *(uint32_t*)(d + 7 * PLANE) = __builtin_amdgcn_perm(b.w, a.w, 0x07060302u);
             }
         }
         __syncthreads();
-        const bool interior = y0 >= 1 && x0 >= 1 && y0 + 16 < U.h && x0 + 16 < U.w;      // every tap of every output pixel inside the image
+        const bool interior = yc >= 1 && xc >= 1 && yc + 16 < U.h && xc + 16 < U.w;      // every tap of every output pixel inside the image
         uint4 tmask[3];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) tmask[s] = bmask[s];
-        if (!interior) {            // conv zero padding: the UNSHIFTED position (y0 + n + ty - 1, x0 + j - 1) of a B element must be inside the image
+        for (int s = 0; s < 3; ++s) tmask[s] = bmask;
+        if (!interior) {            // conv zero padding: the UNSHIFTED position (yc + n + ty - 1, xc + j - 1) of a B element must be inside the image
+            unsigned cw[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int qx0 = xc + g * 8 + 2 * e - 1, qx1 = qx0 + 1;
+                cw[e] = ((qx0 >= 0 && qx0 < U.w) ? 0x0000ffffu : 0u) | ((qx1 >= 0 && qx1 < U.w) ? 0xffff0000u : 0u);
+            }
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
-                const int q = 4 * s + g, ty = q / 3, jg = q - ty * 3;
-                const int qy = y0 + n + ty - 1;
-                const bool rowin = qy >= 0 && qy < U.h;
-                unsigned w[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int qx0 = x0 + jg * 8 + 2 * e - 1, qx1 = qx0 + 1;
-                    w[e] = ((rowin && qx0 >= 0 && qx0 < U.w) ? 0x0000ffffu : 0u) | ((rowin && qx1 >= 0 && qx1 < U.w) ? 0xffff0000u : 0u);
-                }
-                tmask[s].x &= w[0]; tmask[s].y &= w[1]; tmask[s].z &= w[2]; tmask[s].w &= w[3];
+                const int qy = yc + n + s - 1;
+                const unsigned rowin = (qy >= 0 && qy < U.h) ? 0xffffffffu : 0u;
+                tmask[s].x &= cw[0] & rowin; tmask[s].y &= cw[1] & rowin; tmask[s].z &= cw[2] & rowin; tmask[s].w &= cw[3] & rowin;
             }
         }
         float res[8][4];
@@ -272,26 +291,30 @@ __global__ __launch_bounds__(CH * 8, 2) void shiftconv_mfma_kernel(const UnitK U
         for (int c = 0; c < 8; ++c) {
             const int k = wv * 8 + c;
             const int sy = offs[2 * k], sx = offs[2 * k + 1];                       // multiples of 4: the 16-byte reads below are 8-byte aligned
-            const char* rb = smem + k * PLANE + wv * 32 + (n + 8 + sy) * PB + (8 + sx) * 2;
+            const char* rb = smem + k * PLANE + wv * 32 + (n + 8 + sy) * PB + (8 + sx) * 2 + bcol;
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < ((K0M_SKIP & 2) ? 0 : 3); ++s) {
-                const uint2 b0 = *(const uint2*)(rb + boff[s]), b1 = *(const uint2*)(rb + boff[s] + 8);
+                const unsigned w01 = w1d[k * 9 + s * 3] | (w1d[k * 9 + s * 3 + 1] << 16), w2z = w1d[k * 9 + s * 3 + 2];      // wave-uniform (bf16 in the low halves)
+                const uint4 a = make_uint4(__builtin_amdgcn_perm(w01, w2z, asel[0]), __builtin_amdgcn_perm(w01, w2z, asel[1]),
+                                           __builtin_amdgcn_perm(w01, w2z, asel[2]), __builtin_amdgcn_perm(w01, w2z, asel[3]));
+                const uint2 b0 = *(const uint2*)(rb + s * PB), b1 = *(const uint2*)(rb + s * PB + 8);
                 const uint4 b = make_uint4(b0.x & tmask[s].x, b0.y & tmask[s].y, b1.x & tmask[s].z, b1.y & tmask[s].w);
-                acc = mfma16(A[c][s], as_frag(b), acc);
+                acc = mfma16(as_frag(a), as_frag(b), acc);
             }
             res[c][0] = acc[0]; res[c][1] = acc[1]; res[c][2] = acc[2]; res[c][3] = acc[3];
         }
-        // lane (g, n): out[y0 + n][x0 + 4 g + r] of the wave's 8 channels = one 16-byte piece per r
-        const int oy = y0 + n;
+        // lane (g, n): out[yc + n][xc + 4 g + r] of the wave's 8 channels = one 16-byte piece per r
+        // (through an LDS tile and out as whole pixel records: measured no faster at C = 64 -- 294 vs 296 us -- and slower at C = 80, two more barriers)
+        const int oy = yc + n;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int ox = x0 + 4 * g + r;
+            const int ox = xc + 4 * g + r;
             if (oy < U.h && ox < U.w && !(K0M_SKIP & 4)) {
                 float o[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) o[c] = res[c][r];
-                *(uint4*)(hw + (((size_t)t * U.h + oy) * U.w + ox) * CH + wv * 8) = pack8(o);
+                *(uint4*)(hw + (((size_t)tc * U.h + oy) * U.w + ox) * CH + wv * 8) = pack8(o);
             }
         }
         __syncthreads();                                     // every wave is done with the window before the next one is written
@@ -456,10 +479,10 @@ int cab_phase2(const sn_unit_src* s, const void* g2, const float* ca, const void
 
 extern "C" {
 
-// K0 on the matrix cores (shiftconv_mfma_kernel): w1t = prep.pack_shiftconv_toeplitz: bf16 [C/2][3][64][8] banded A fragments of the nine taps
-int sn_gsts_shiftconv_mfma(const sn_unit_src* s, const int8_t* offs, const void* w1t, void* hw, void* stream) {
+// K0 on the matrix cores (shiftconv_mfma_kernel); operands as sn_gsts_shiftconv
+int sn_gsts_shiftconv_mfma(const sn_unit_src* s, const int8_t* offs, const uint32_t* w1, void* hw, void* stream) {
     sn_clear_error();
-    if (!unit_ok(s) || !offs || !w1t || !hw || s->mode == 0) return SN_EINVAL;
+    if (!unit_ok(s) || !offs || !w1 || !hw || s->mode == 0) return SN_EINVAL;
     SN_FRAME_RANGE(s, t0, nt);
     int dev = 0, ncu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) {
@@ -477,10 +500,10 @@ int sn_gsts_shiftconv_mfma(const sn_unit_src* s, const int8_t* offs, const void*
     const dim3 grid(8u * (unsigned)wgs);
     if (s->C == 64) {
         if (hipFuncSetAttribute((const void*)shiftconv_mfma_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH;
-        hipLaunchKernelGGL((shiftconv_mfma_kernel<32>), grid, dim3(256), lds, (hipStream_t)stream, to_k(s), G, nt, per_xcd, offs, (const uint4*)w1t, (bf16_t*)hw);
+        hipLaunchKernelGGL((shiftconv_mfma_kernel<32>), grid, dim3(256), lds, (hipStream_t)stream, to_k(s), G, nt, per_xcd, offs, w1, (bf16_t*)hw);
     } else {
         if (hipFuncSetAttribute((const void*)shiftconv_mfma_kernel<40>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SN_ELAUNCH;
-        hipLaunchKernelGGL((shiftconv_mfma_kernel<40>), grid, dim3(320), lds, (hipStream_t)stream, to_k(s), G, nt, per_xcd, offs, (const uint4*)w1t, (bf16_t*)hw);
+        hipLaunchKernelGGL((shiftconv_mfma_kernel<40>), grid, dim3(320), lds, (hipStream_t)stream, to_k(s), G, nt, per_xcd, offs, w1, (bf16_t*)hw);
     }
     return sn_check_launch();
 }

@@ -108,7 +108,6 @@ class Plan:
         if with_shift:
             w1 = sd[pre + "conv1.weight"].reshape(c // 2, 9)
             u["w1"] = self._dev((w1.to(torch.bfloat16).view(torch.int16).to(torch.int32) & 0xFFFF).contiguous())   # bf16 in the low half
-            u["w1t"] = self._dev(prep.pack_shiftconv_toeplitz(sd[pre + "conv1.weight"]))                               # K0 on the matrix cores
         g = prep.pack_ln_gemm(sd[f"{pre}body.{i}.weight"], sd[pre + "norm.weight"], sd[pre + "norm.bias"], c); i += 1
         u["w_ln"], u["b_ln"] = self._dev(g["wfrag"]), self._dev(g["bias"])
         w3 = prep.pack_dw3_gate(sd[f"{pre}body.{i}.conv_2.weight"], c); i += 1
@@ -546,7 +545,7 @@ class Engine:
             f0, n = (t0, nt) if nt else (0, T)           # frame range of this piece for the operators that take plain pointers
             if mode:
                 if self.k0_mfma:
-                    self._call("sn_gsts_shiftconv_mfma", "sn_gsts_shiftconv", C.byref(src), P.offs.data_ptr(), u["w1t"].data_ptr(), hwb.data_ptr(), st)
+                    self._call("sn_gsts_shiftconv_mfma", "sn_gsts_shiftconv", C.byref(src), P.offs.data_ptr(), u["w1"].data_ptr(), hwb.data_ptr(), st)
                 else:
                     self._call("sn_gsts_shiftconv", "sn_gsts_shiftconv", C.byref(src), P.offs.data_ptr(), u["w1"].data_ptr(), hwb.data_ptr(), st)
             hw_ptr = hwb.data_ptr() if mode else None

@@ -107,20 +107,6 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], cins: Sequence
             "k": k, "cout": cout, "n_in": n_in, "cs_in": cs_in}
 
 
-def pack_shiftconv_toeplitz(w1: torch.Tensor) -> torch.Tensor:
-    """CAB2.conv1 (depthwise 3x3 on the borrowed half, gshift_deblur1.py:223,251), weight [C/2, 1, 3, 3] -> bf16 [C/2][3][64][8]: per channel the
-    banded matrix A[m][(ty, j)] = w[ty][j - m] (0 <= j - m <= 2) of sn_gsts_shiftconv_mfma -- rows m = the 16 output columns of a tile, k-slots
-    (ty, j) = 3 kernel rows x 24 input columns (18 used) in three k-steps of 32 -- in A-fragment order (lane = 16 g + m holds slots 32 s + 8 g .. + 8)."""
-    w = w1.detach().float().cpu().numpy().reshape(-1, 3, 3)
-    ch = w.shape[0]
-    wp = np.zeros((16 * ch, 96), np.float32)
-    for ty in range(3):
-        for m in range(16):
-            for tx in range(3):
-                wp[np.arange(ch) * 16 + m, ty * 24 + m + tx] = w[:, ty, tx]
-    return pack_frag(wp)
-
-
 def pack_ln_gemm(w1: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, c: int) -> Dict[str, object]:
     """body[0] (1x1, 2C x K) with the LayerNorm affine folded in; rows/bias in gate-paired order."""
     w = w1.detach().float().cpu().numpy().reshape(2 * c, -1)

@@ -361,7 +361,7 @@ def test_shiftconv_on_the_matrix_cores(name, T, hw, engines):
         src = eng._unit_src(xd, mode)
         new = torch.full((T, h, w, C // 2), float("nan"), dtype=torch.bfloat16, device=DEV)
         old = torch.empty_like(new)
-        L.check(eng.lib.sn_gsts_shiftconv_mfma(C_byref(src), eng.P.offs.data_ptr(), eng.P.units[pre]["w1t"].data_ptr(), new.data_ptr(), st), "shiftconv_mfma")
+        L.check(eng.lib.sn_gsts_shiftconv_mfma(C_byref(src), eng.P.offs.data_ptr(), eng.P.units[pre]["w1"].data_ptr(), new.data_ptr(), st), "shiftconv_mfma")
         L.check(eng.lib.sn_gsts_shiftconv(C_byref(src), eng.P.offs.data_ptr(), eng.P.units[pre]["w1"].data_ptr(), old.data_ptr(), st), "shiftconv")
         torch.cuda.synchronize()
         _, hw_ref = O.temporal_roll(x, rev, V.wrap)

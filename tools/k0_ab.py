@@ -45,9 +45,9 @@ def main():
             if v == "valu":
                 L.check(eng.lib.sn_gsts_shiftconv(C.byref(src), P.offs.data_ptr(), P.units[pre]["w1"].data_ptr(), out[v].data_ptr(), st), v)
             elif v in vlibs:
-                L.check(vlibs[v].sn_gsts_shiftconv_mfma(C.byref(src), P.offs.data_ptr(), P.units[pre]["w1t"].data_ptr(), out[v].data_ptr(), st), v)
+                L.check(vlibs[v].sn_gsts_shiftconv_mfma(C.byref(src), P.offs.data_ptr(), P.units[pre]["w1"].data_ptr(), out[v].data_ptr(), st), v)
             else:
-                L.check(eng.lib.sn_gsts_shiftconv_mfma(C.byref(src), P.offs.data_ptr(), P.units[pre]["w1t"].data_ptr(), out[v].data_ptr(), st), v)
+                L.check(eng.lib.sn_gsts_shiftconv_mfma(C.byref(src), P.offs.data_ptr(), P.units[pre]["w1"].data_ptr(), out[v].data_ptr(), st), v)
         times = {v: [] for v in out}
         for v in out:
             launch(v)
