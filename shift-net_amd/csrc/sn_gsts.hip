@@ -236,7 +236,9 @@ __global__ __launch_bounds__(CH * 8, 2) void shiftconv_mfma_kernel(const UnitK U
         const int sstr = sl.sb;
         if (!(K0M_SKIP & 1)) {   // window -> planar LDS: ALL global loads first (one memory round trip per tile), then the LDS stores.
             // (Issuing the NEXT tile's loads before this tile's MFMAs -- 80 registers live across the arithmetic -- spilled and ran 419 instead of
-            // 286 us at C = 64, 20 x 360 x 640; two workgroups per CU overlap the phases instead.)
+            // 286 us at C = 64, 20 x 360 x 640; issuing them between the MFMAs and the stores, so that the counted vmcnt leaves the stores outstanding,
+            // still spilled 37-92 registers in hipcc's allocation and ran 349 us.  Two workgroups per CU overlap the phases instead.  The ablation of this
+            // version: loader alone 188 us, stores alone 87, together 277, everything 300: loader and stores of a wave serialise on the in-order vmcnt.)
             uint4 v0[NITP], v1[NITP];
             const bool wfull = yc >= 9 && xc >= 9 && yc + 25 <= U.h && xc + 25 <= U.w;      // workgroup-uniform: no test at all inside the image
             const bf16_t* wsrc = src + ((ptrdiff_t)(yc - 9) * U.w + (xc - 9)) * sstr + mypc * 8;
