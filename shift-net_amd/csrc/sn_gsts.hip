@@ -495,9 +495,12 @@ int sn_gsts_shiftconv_mfma(const sn_unit_src* s, const int8_t* offs, const uint3
     const int per_xcd = (G.nrf + 7) / 8;
     const int CH = s->C / 2;
     const size_t lds = (size_t)CH * 34 * 72 + (CH / 8) * 32 + 64;
+#ifndef K0M_PERSIST      // measurement builds: 0 = one workgroup per tile (the dispatcher hands out an XCD's tiles in order)
+#define K0M_PERSIST 1
+#endif
     int wgs = (s->C == 64 ? 2 : 1) * ncu / 8;                                // persistent workgroups per XCD (LDS: 78 / 98 KB each)
     const long tiles_x = (long)per_xcd * G.ntx;
-    if (wgs > tiles_x) wgs = (int)tiles_x;
+    if (wgs > tiles_x || !K0M_PERSIST) wgs = (int)tiles_x;
     if (wgs < 1) wgs = 1;
     const dim3 grid(8u * (unsigned)wgs);
     if (s->C == 64) {
