@@ -465,6 +465,8 @@ def main():
             if fn == "gsts_chain":                      # not a kernel: wall time of one chain of Encoder_shift_blocks on the launching stream
                 chain_ms += e0.elapsed_time(e1)
                 continue
+            if fn == "sn_gsts_shiftconv_mfma":          # K0 on the matrix cores: the same operator (and the same key in the PMC files) as the VALU kernel
+                fn = "sn_gsts_shiftconv"
             key = fn
             if fn == "sn_conv2d":                       # one GPU kernel per (M-tiles, tile shape): key by template instance
                 mt = -(-max(meta[5], 1) // 16) if meta[9] != 1 else -(-meta[5] * 4 // 16)
