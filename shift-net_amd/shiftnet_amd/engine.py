@@ -67,6 +67,9 @@ class Plan:
         self.cas: Dict[str, Dict[str, object]] = {}
         self.units: Dict[str, Dict[str, object]] = {}
         self.offs = prep.shift_offsets_i8(shift_table(V.c1)).to(device)
+        # sn_gsts_shiftconv_mfma reads 16 bytes of a channel-planar LDS row at a displaced column: 8-byte aligned only if every displacement is a multiple
+        # of 4 pixels (gshift_deblur1.py:411-439: they are 0, +-4, +-8) and within the 34 x 34 window; anything else stays on the VALU kernel
+        self.k0_mfma_ok = all(dx % 4 == 0 and abs(dy) <= 8 and abs(dx) <= 8 for dy, dx in shift_table(V.c1))
         self._build()
 
     # -- helpers ---------------------------------------------------------------------------------------------
@@ -544,7 +547,7 @@ class Engine:
             src = self._unit_src(x, mode, wrap=wrap, halo=halo, t0=t0, nt=nt)
             f0, n = (t0, nt) if nt else (0, T)           # frame range of this piece for the operators that take plain pointers
             if mode:
-                if self.k0_mfma:
+                if self.k0_mfma and P.k0_mfma_ok:
                     self._call("sn_gsts_shiftconv_mfma", "sn_gsts_shiftconv", C.byref(src), P.offs.data_ptr(), u["w1"].data_ptr(), hwb.data_ptr(), st)
                 else:
                     self._call("sn_gsts_shiftconv", "sn_gsts_shiftconv", C.byref(src), P.offs.data_ptr(), u["w1"].data_ptr(), hwb.data_ptr(), st)

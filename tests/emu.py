@@ -107,6 +107,48 @@ def shiftconv(x, offs, w1, mode, wrap):
     return out
 
 
+def shiftconv_mfma(x, offs, w1, mode, wrap):
+    """sn_gsts_shiftconv_mfma (csrc/sn_gsts.hip: shiftconv_mfma_kernel) as the kernel addresses it: per 16 x 16 tile a channel-planar 34 x 34 window
+    (origin -9, zero outside the image), per channel three k-steps ty of a 16 x 16 x 32 MFMA whose A fragment a lane builds from the nine weights with
+    its selector (element j = 8 g + i of row m = lane & 15: w[ty][j - m] for 0 <= j - m <= 2) and whose B fragment is 8 consecutive window pixels
+    of row n + ty + 8 + dy from column 8 g + 8 + dx (g = 2: two pixels, g = 3: none), masked where the UNSHIFTED tap position lies outside the image;
+    D[4 g + r][n] = out[y0 + n][x0 + 4 g + r].  x [T,h,w,C] -> hw [T,h,w,C/2]."""
+    T, h, w, C = x.shape; Ch = C // 2
+    out = np.zeros((T, h, w, Ch), np.float32)
+    for t in range(T):
+        *_, fb, ob = unit_slabs(T, C, t, mode, wrap)
+        for y0 in range(0, h, 16):
+            for x0 in range(0, w, 16):
+                win = np.zeros((Ch, 34, 48), np.float32)                      # planar window (+ slack columns the masked lanes may touch)
+                for ry in range(34):
+                    for rx in range(34):
+                        gy, gx = y0 - 9 + ry, x0 - 9 + rx
+                        if 0 <= gy < h and 0 <= gx < w:
+                            win[:, ry, rx] = x[fb, gy, gx, ob:ob + Ch]
+                for k in range(Ch):
+                    dy, dx = int(offs[k][0]), int(offs[k][1])
+                    assert dx % 4 == 0 and abs(dy) <= 8 and abs(dx) <= 8
+                    A = np.zeros((3, 16, 32), np.float32); B = np.zeros((3, 32, 16), np.float32)
+                    for ty in range(3):
+                        for lane in range(64):
+                            g, m = lane >> 4, lane & 15                        # A: row m; B: column n = m
+                            for i in range(8):
+                                j = 8 * g + i
+                                tx = j - m
+                                A[ty, m, j] = w1[k, ty * 3 + tx] if 0 <= tx <= 2 else 0.0
+                                if g == 3 or (g == 2 and i >= 2):
+                                    continue                                   # bmask: no such slots
+                                qy, qx = y0 + m + ty - 1, x0 + j - 1          # the tap's position before the shift: the conv's zero padding
+                                if 0 <= qy < h and 0 <= qx < w:
+                                    B[ty, j, m] = win[k, m + ty + 8 + dy, 8 * g + 8 + dx + i]
+                    D = sum(A[ty] @ B[ty] for ty in range(3))                   # D[row = output column][col = output row]
+                    for n in range(16):
+                        for mm in range(16):
+                            if y0 + n < h and x0 + mm < w:
+                                out[t, y0 + n, x0 + mm, k] = D[mm, n]
+    return out
+
+
 def ln_gemm(x, hwb, wfrag, bias, mode, wrap):
     """sn_ln_gemm: -> a [T,h,w,2C] in storage-position order."""
     wfrag = frag_to_np(wfrag); MT, KS = wfrag.shape[:2]

@@ -30,6 +30,28 @@ def frag_f32(p):
     return p
 
 
+@pytest.mark.parametrize("name,hw", [("gshift_deblur2", (20, 37)), ("gshift_deblur1", (33, 18)), ("gshift_deblur2", (3, 5))])
+def test_shiftconv_on_the_matrix_cores_emulation_matches_oracle(name, hw):
+    """K0 as a banded GEMM (round 6): the kernel's operand construction -- per-lane A selectors on the nine weights, the channel-planar window and its
+    displaced 8-pixel B fragments, the padding masks of border tiles, the D layout -- replayed in numpy against the oracle's
+    conv1(spatial_shift2(roll half)) (gshift_deblur1.py:470-503,223,251) and against the emulation of the VALU kernel, on ragged multi-tile maps."""
+    V = O.VARIANTS[name]
+    sd = synth_state_dict(name)
+    C, T, (h, w) = V.c1, 2, hw
+    x = torch.from_numpy(synth.unit_noise((T, C, h, w), seed=23))
+    offs = np.array(shift_table(C), np.int8)
+    for reverse, mode, unit in ((False, 1, "encoder_level1."), (True, 2, "encoder_level1_1.")):
+        pre = "stage1.decoder_level1." + unit + "0."
+        w1 = sd[pre + "conv1.weight"].reshape(C // 2, 9).numpy()
+        got = emu.shiftconv_mfma(nhwc(x), offs, w1, mode, V.wrap)
+        old = emu.shiftconv(nhwc(x), offs, w1, mode, V.wrap)
+        _, half = O.temporal_roll(x, reverse, V.wrap)
+        ref = torch.nn.functional.conv2d(O.spatial_shift(half.contiguous()), sd[pre + "conv1.weight"], padding=1, groups=C // 2)
+        ref = ref.permute(0, 2, 3, 1).numpy()
+        assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (name, mode, np.abs(got - ref).max())
+        assert np.abs(got - old).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize("name", ["gshift_deblur2", "gshift_denoise2", "gshift_deblur1"])
 def test_unit_emulation_matches_oracle(name):
     V, PV = O.VARIANTS[name], VARIANTS[name]
