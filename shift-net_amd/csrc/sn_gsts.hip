@@ -500,7 +500,12 @@ int sn_gsts_shiftconv_mfma(const sn_unit_src* s, const int8_t* offs, const uint3
 #endif
     int wgs = (s->C == 64 ? 2 : 1) * ncu / 8;                                // persistent workgroups per XCD (LDS: 78 / 98 KB each)
     const long tiles_x = (long)per_xcd * G.ntx;
-    if (wgs > tiles_x || !K0M_PERSIST) wgs = (int)tiles_x;
+    // C = 64 on large maps: one workgroup per tile after all -- the dispatcher hands out an XCD's tiles in order, a compact frontier that keeps more
+    // of the windows' overlap in L2 than 64 persistent workgroups drifting apart (read requests to the fabric 301 vs ~570 MB per launch at
+    // 20 x 360 x 640; 284 vs 296 us).  Smaller maps and C = 80 (the per-workgroup tables rebuilt per tile cost more than the locality buys:
+    // 70 vs 62 us at 20 x 180 x 320, 1320 vs 1121 us at C = 80) stay persistent.  Same results either way.
+    const bool per_tile = s->C == 64 && tiles_x >= 1500;
+    if (wgs > tiles_x || !K0M_PERSIST || per_tile) wgs = (int)tiles_x;
     if (wgs < 1) wgs = 1;
     const dim3 grid(8u * (unsigned)wgs);
     if (s->C == 64) {
