@@ -323,6 +323,158 @@ __global__ __launch_bounds__(CH * 8, 2) void shiftconv_mfma_kernel(const UnitK U
     }
 }
 
+// K0 on the matrix cores, WALKING form: a workgroup takes a SEGMENT of a tile column (S vertically adjacent tiles of one frame) and keeps the planar
+// window as a RING of 34 rows: the windows of vertically adjacent tiles share 18 of their 34 rows, so every tile after a segment's first stages 16 new
+// rows instead of 34 -- the loader (what the tile form waits for: 188 of 280 us at C = 64, 20 x 360 x 640) does 2.1x less per tile.  Window row wr of the
+// segment's tile jj lives in ring row (16 jj + wr) mod 34; rows are staged in blocks of up to 17 (one table per thread: pairs of pixels of a 17-row block;
+// a segment's first window = two blocks, a later one = 16 rows of one).
+// Everything else -- selectors, B fragments, masks, accumulator layout, stores -- is shiftconv_mfma_kernel's: results are bit-identical to it.
+template <int CH>
+__global__ __launch_bounds__(CH * 8, 2) void shiftconv_mfma_walk_kernel(const UnitK U, const int ntx, const int nty, const int S, const int nseg, const int nfr,
+                                                                   const int per_xcd, const int8_t* __restrict__ offs, const uint32_t* __restrict__ w1d, bf16_t* hw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RW = 34, PB = 72, PLANE = RW * PB, NTH = CH * 8, PCS = CH / 8, BR = 17;      // blocks of 17 rows: a window is two of them
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), g = lane >> 4, n = lane & 15;
+    unsigned asel[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int tx0 = 8 * g + 2 * e - n, tx1 = tx0 + 1;
+        const unsigned lo = tx0 == 0 ? 0x0504u : tx0 == 1 ? 0x0706u : tx0 == 2 ? 0x0100u : 0x0c0cu;
+        const unsigned hi = tx1 == 0 ? 0x0504u : tx1 == 1 ? 0x0706u : tx1 == 2 ? 0x0100u : 0x0c0cu;
+        asel[e] = lo | (hi << 16);
+    }
+    const uint4 bmask = make_uint4(g < 3 ? 0xffffffffu : 0u, g < 2 ? 0xffffffffu : 0u, g < 2 ? 0xffffffffu : 0u, g < 2 ? 0xffffffffu : 0u);
+    const int bcol = (g < 3 ? g : 0) * 16;
+    // a thread's pixel pairs of a 16-row block: local row lr, column rx (even), pixel offset; the piece index is the same for all of them
+    static_assert(NTH % PCS == 0, "a thread's pieces share the piece index");
+    constexpr int NPB = BR * (RW / 2) * PCS, NB = (NPB + NTH - 1) / NTH;
+    int geo[NB], gpix[NB];
+    const int mypc = tid % PCS;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int idx = tid + k * NTH;
+        const int pr = (idx < NPB ? idx : 0) / PCS;
+        const int lr = idx < NPB ? pr / (RW / 2) : 255, rx = (pr % (RW / 2)) * 2;      // lr 255: no such pair
+        geo[k] = lr << 8 | rx;
+        gpix[k] = (idx < NPB ? pr / (RW / 2) : 0) * U.w + rx;
+    }
+    char* const myplane = smem + (mypc * 8) * PLANE + mypc * 32;
+    // rows wr0 .. wr0 + nrows - 1 of the window at (y0, x0) -> ring rows (rbase + wr) mod 34: all their global loads first, then the LDS stores.
+    // (Fetching the NEXT tile's 16 rows -- 40 registers -- right after this tile's window is complete and storing them to LDS after its MFMAs, so
+    // that the round trip hides behind the arithmetic, spilled 35-47 registers in hipcc's allocation and ran 330 instead of 258 us at C = 64,
+    // 20 x 360 x 640: the third prefetch ordering on this kernel that lost to the allocator.)
+    auto stage = [&](const bf16_t* src, int sstr, int y0, int x0, int wr0, int nrows, int rbase) __attribute__((always_inline)) {
+        if (K0M_SKIP & 1) return;
+        uint4 v0[NB], v1[NB];
+        const int gy0 = y0 - 9 + wr0, gx0 = x0 - 9;
+        const bool full = gy0 >= 0 && gy0 + nrows <= U.h && gx0 >= 0 && gx0 + RW <= U.w;      // workgroup-uniform: every pixel of the block inside the image
+        const bf16_t* wsrc = src + ((ptrdiff_t)gy0 * U.w + gx0) * sstr + mypc * 8;
+        if (full) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const bf16_t* q = wsrc + (ptrdiff_t)((geo[k] >> 8) < nrows ? gpix[k] : 0) * sstr;      // (a row beyond the block: any valid address, never stored)
+                v0[k] = *(const uint4*)q; v1[k] = *(const uint4*)(q + sstr);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int lr = geo[k] >> 8, gy = gy0 + lr, gx = gx0 + (geo[k] & 255);
+                const bool iny = lr < nrows && gy >= 0 && gy < U.h, in0 = iny && gx >= 0 && gx < U.w, in1 = iny && gx + 1 >= 0 && gx + 1 < U.w;
+                const bf16_t* q = wsrc + (ptrdiff_t)gpix[k] * sstr;
+                const uint4 a = *(const uint4*)(in0 ? q : src), b = *(const uint4*)(in1 ? q + sstr : src);
+                v0[k] = in0 ? a : make_uint4(0, 0, 0, 0); v1[k] = in1 ? b : make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int lr = geo[k] >> 8;
+            if (lr >= nrows) continue;
+            int rr = rbase + wr0 + lr;
+            rr -= rr >= RW ? RW : 0; rr -= rr >= RW ? RW : 0;
+            char* d = myplane + rr * PB + (geo[k] & 255) * 2;
+            const uint4 a = v0[k], b = v1[k];
+            *(uint32_t*)(d + 0 * PLANE) = __builtin_amdgcn_perm(b.x, a.x, 0x05040100u); *(uint32_t*)(d + 1 * PLANE) = __builtin_amdgcn_perm(b.x, a.x, 0x07060302u);
+            *(uint32_t*)(d + 2 * PLANE) = __builtin_amdgcn_perm(b.y, a.y, 0x05040100u); *(uint32_t*)(d + 3 * PLANE) = __builtin_amdgcn_perm(b.y, a.y, 0x07060302u);
+            *(uint32_t*)(d + 4 * PLANE) = __builtin_amdgcn_perm(b.z, a.z, 0x05040100u); *(uint32_t*)(d + 5 * PLANE) = __builtin_amdgcn_perm(b.z, a.z, 0x07060302u);
+            *(uint32_t*)(d + 6 * PLANE) = __builtin_amdgcn_perm(b.w, a.w, 0x05040100u); *(uint32_t*)(d + 7 * PLANE) = __builtin_amdgcn_perm(b.w, a.w, 0x07060302u);
+        }
+    };
+    const int xcd = (int)blockIdx.x & 7, j0 = (int)blockIdx.x >> 3, nwg = (int)gridDim.x >> 3;
+    // items of this XCD: (frame, segment) rows of the item list x tile columns, tile column fastest: x-neighbours run concurrently on one L2
+    const int nitem_x = per_xcd * ntx, nrows_all = nfr * nseg;
+    for (int i = j0; i < nitem_x; i += nwg) {
+        const int rl = i / ntx, tx_ = i - rl * ntx, row = xcd * per_xcd + rl;
+        if (row >= nrows_all) break;                          // workgroup-uniform
+        int tc = row / nseg;
+        const int sg = row - tc * nseg, ty0 = sg * S, ntile = min(S, nty - ty0);
+        tc += U.t0;
+        const SnSlabs<bf16_t> sl = unit_slabs(U, tc);
+        const int xc = tx_ * 16;
+        for (int jj = 0; jj < ntile; ++jj) {
+            const int yc = (ty0 + jj) * 16;
+            int rbase = (16 * jj) % RW;                       // ring row of this tile's window row 0
+            // a segment's first window: two blocks of 17 rows; a later one: window rows 18 .. 33, the 16 rows the previous tile did not have
+            // (one copy of the staging code: a loop the compiler must not unroll)
+            const int nblk = jj == 0 ? 2 : 1;
+#pragma unroll 1
+            for (int b = 0; b < nblk; ++b) stage(sl.pb, sl.sb, yc, xc, jj == 0 ? b * BR : RW - 16, jj == 0 ? BR : 16, jj == 0 ? 0 : rbase);
+            __syncthreads();
+            const bool interior = yc >= 1 && xc >= 1 && yc + 16 < U.h && xc + 16 < U.w;
+            uint4 tmask[3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) tmask[s] = bmask;
+            if (!interior) {
+                unsigned cw[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qx0 = xc + g * 8 + 2 * e - 1, qx1 = qx0 + 1;
+                    cw[e] = ((qx0 >= 0 && qx0 < U.w) ? 0x0000ffffu : 0u) | ((qx1 >= 0 && qx1 < U.w) ? 0xffff0000u : 0u);
+                }
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const int qy = yc + n + s - 1;
+                    const unsigned rowin = (qy >= 0 && qy < U.h) ? 0xffffffffu : 0u;
+                    tmask[s].x &= cw[0] & rowin; tmask[s].y &= cw[1] & rowin; tmask[s].z &= cw[2] & rowin; tmask[s].w &= cw[3] & rowin;
+                }
+            }
+            float res[8][4];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int k = wv * 8 + c;
+                const int sy = offs[2 * k], sx = offs[2 * k + 1];
+                const char* cb = smem + k * PLANE + wv * 32 + (8 + sx) * 2 + bcol;
+                const int r0 = rbase + n + 8 + sy;            // ring row of window row n + 8 + sy (k-step ty adds ty), < 2 * 34
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < ((K0M_SKIP & 2) ? 0 : 3); ++s) {
+                    const unsigned w01 = w1d[k * 9 + s * 3] | (w1d[k * 9 + s * 3 + 1] << 16), w2z = w1d[k * 9 + s * 3 + 2];
+                    const uint4 a = make_uint4(__builtin_amdgcn_perm(w01, w2z, asel[0]), __builtin_amdgcn_perm(w01, w2z, asel[1]),
+                                               __builtin_amdgcn_perm(w01, w2z, asel[2]), __builtin_amdgcn_perm(w01, w2z, asel[3]));
+                    int rr = r0 + s;
+                    rr -= rr >= RW ? RW : 0;
+                    const char* rb = cb + rr * PB;
+                    const uint2 b0 = *(const uint2*)rb, b1 = *(const uint2*)(rb + 8);
+                    const uint4 b = make_uint4(b0.x & tmask[s].x, b0.y & tmask[s].y, b1.x & tmask[s].z, b1.y & tmask[s].w);
+                    acc = mfma16(as_frag(a), as_frag(b), acc);
+                }
+                res[c][0] = acc[0]; res[c][1] = acc[1]; res[c][2] = acc[2]; res[c][3] = acc[3];
+            }
+            const int oy = yc + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ox = xc + 4 * g + r;
+                if (oy < U.h && ox < U.w && !(K0M_SKIP & 4)) {
+                    float o[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) o[c] = res[c][r];
+                    *(uint4*)(hw + (((size_t)tc * U.h + oy) * U.w + ox) * CH + wv * 8) = pack8(o);
+                }
+            }
+            __syncthreads();                                 // every wave is done with the ring rows the next tile overwrites
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // K4: y = shortcut + W3' . (ca * g2) (+ bias'), beta folded into W3'/bias'; shortcut = rolled x (CAB2) or x (CAB1)
 // waves-per-SIMD target: see the register-budget note in sn_conv.hip (91 VGPRs + 80 AGPRs = 2 waves without it; 148 / 152 = 3 waves)
@@ -490,6 +642,40 @@ int sn_gsts_shiftconv_mfma(const sn_unit_src* s, const int8_t* offs, const uint3
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) {
         (void)hipGetLastError();
         return SN_ELAUNCH;
+    }
+#ifndef K0M_WALK         // 1: segments of tile columns with the window as a ring of rows (shiftconv_mfma_walk_kernel); 0: one window per tile
+#define K0M_WALK 1
+#endif
+    if (K0M_WALK) {
+        const int ntx = (s->w + 15) / 16, nty = (s->h + 15) / 16, CHw = s->C / 2;
+        const int wgs_cu = s->C == 64 ? 2 : 1;
+        const long slots = (long)wgs_cu * ncu;
+        // segment length: the longest of 8, 6, 4, 3, 2 tiles (a segment's first tile stages 34 rows, the others 16) whose item count keeps the
+        // workgroup slots busy: at least 4 items per slot, or whatever the launch has
+        int S = 2;
+        const int cand[5] = {8, 6, 4, 3, 2};
+        for (int k = 0; k < 5; ++k) {
+            const int Sk = cand[k] < nty ? cand[k] : nty, nsk = (nty + Sk - 1) / Sk;
+            if ((long)nsk * ntx * nt >= 4 * slots || k == 4) { S = Sk; break; }
+        }
+        // short segments mostly pay first tiles: measured 67 vs 62 us at 20 x 180 x 320 (S = 2) -- those launches take the tile form below
+        const bool walk = S >= 4;
+        const int nseg = (nty + (S < 1 ? 1 : S) - 1) / (S < 1 ? 1 : S);
+        const int rows = nt * nseg, per_x = (rows + 7) / 8;
+        long wg = slots / 8;
+        if (wg > (long)per_x * ntx) wg = (long)per_x * ntx;
+        if (wg < 1) wg = 1;
+        const size_t ldsw = (size_t)CHw * 34 * 72 + (CHw / 8) * 32 + 64;
+        const dim3 gridw(8u * (unsigned)wg);
+        if (!walk) {
+        } else if (s->C == 64) {
+            if (hipFuncSetAttribute((const void*)shiftconv_mfma_walk_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw) != hipSuccess) return SN_ELAUNCH;
+            hipLaunchKernelGGL((shiftconv_mfma_walk_kernel<32>), gridw, dim3(256), ldsw, (hipStream_t)stream, to_k(s), ntx, nty, S, nseg, nt, per_x, offs, w1, (bf16_t*)hw);
+        } else {
+            if (hipFuncSetAttribute((const void*)shiftconv_mfma_walk_kernel<40>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw) != hipSuccess) return SN_ELAUNCH;
+            hipLaunchKernelGGL((shiftconv_mfma_walk_kernel<40>), gridw, dim3(320), ldsw, (hipStream_t)stream, to_k(s), ntx, nty, S, nseg, nt, per_x, offs, w1, (bf16_t*)hw);
+        }
+        if (walk) return sn_check_launch();
     }
     XcdTiles G = sn_xcd_tiles((s->w + 15) / 16, (s->h + 15) / 16, nt);
     const int per_xcd = (G.nrf + 7) / 8;
