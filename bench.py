@@ -118,7 +118,7 @@ def symbol_key(sym):
     m = re.search(r"ln_gemm_gate_kernel<\d+, (true|false)>", s)
     if m:
         return "sn_ln_gemm_gate<cab2>" if m.group(1) == "true" else "sn_ln_gemm_gate<cab1>"
-    for pat, key in (("scale_gemm_res_kernel", "sn_cab_phase2"), ("shiftconv_kernel", "sn_gsts_shiftconv"), ("shiftconv_mfma_kernel", "sn_gsts_shiftconv"), ("grp5p_gemm_gate_kernel", "sn_grp5_gemm_gate"),
+    for pat, key in (("scale_gemm_res_kernel", "sn_cab_phase2"), ("shiftconv_kernel", "sn_gsts_shiftconv"), ("shiftconv_mfma_kernel", "sn_gsts_shiftconv"), ("shiftconv_mfma_walk_kernel", "sn_gsts_shiftconv"), ("grp5p_gemm_gate_kernel", "sn_grp5_gemm_gate"),
                      ("dw5m_gemm_gate_kernel", "sn_dw5m_gemm_gate"), ("ca_mlp_kernel", "sn_ca_mlp"), ("cab_ca", "sn_cab_ca"), ("gather_kernel", "sn_temporal_roll"),
                      ("ingest_kernel", "sn_ingest"), ("upsample2_add_kernel", "sn_upsample2_add")):
         if pat in s:
@@ -529,7 +529,7 @@ def main():
                 doc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
                 changed = pmc_sources_changed(doc)
                 if changed:
-                    pmc_note = f"profiles/{pmc_file} was measured on other sources of its kernels (changed since: {', '.join(changed)}): re-run tools/make_profiles_r04.sh"
+                    pmc_note = f"profiles/{pmc_file} was measured on other sources of its kernels (changed since: {', '.join(changed)}): re-run tools/final_r06.sh"
                 else:
                     pmc = {}
                     for sym, v in doc["kernels_per_window"].items():
