@@ -22,6 +22,11 @@ VARIANTS = {
     "da2": ["-DP1R_DA=2"], "nsw4": ["-DP1R_NSW64=4"], "no_mem": ["-DP1R_SKIP=6"], "no_sigmoid": ["-DP1R_SKIP=64"], "nsw2": ["-DP1R_NSW64=2"],
     "prio000": ["-DP1R_PRIO_S=0", "-DP1R_PRIO_B=0", "-DP1R_PRIO_A=0"], "prio300": ["-DP1R_PRIO_S=3", "-DP1R_PRIO_B=0", "-DP1R_PRIO_A=0"],
     "prio311": ["-DP1R_PRIO_S=3", "-DP1R_PRIO_B=1", "-DP1R_PRIO_A=1"], "prio312": ["-DP1R_PRIO_S=3", "-DP1R_PRIO_B=1", "-DP1R_PRIO_A=2"],
+    # LDS accesses with bank conflicts moved to conflict-free addresses (wrong results): what a re-pitch of each ring could buy at most
+    "nc1": ["-DP1R_NOCONF=1"], "nc2": ["-DP1R_NOCONF=2"], "nc4": ["-DP1R_NOCONF=4"], "nc8": ["-DP1R_NOCONF=8"], "nc16": ["-DP1R_NOCONF=16"], "nc31": ["-DP1R_NOCONF=31"],
+    "nc7": ["-DP1R_NOCONF=7"], "nc23": ["-DP1R_NOCONF=23"],
+    "pair0": ["-DP1R_PAIR=0"], "pair1": ["-DP1R_PAIR=1"], "pair3": ["-DP1R_PAIR=3"], "pair5": ["-DP1R_PAIR=5"], "pair6": ["-DP1R_PAIR=6"], "opad0": ["-DP1R_OPAD=0"], "oalign0": ["-DP1R_OALIGN=0"],
+    "pair1opad0": ["-DP1R_PAIR=1", "-DP1R_OPAD=0"],
     "prio210": ["-DP1R_PRIO_S=2", "-DP1R_PRIO_B=1", "-DP1R_PRIO_A=0"], "prio231": ["-DP1R_PRIO_S=2", "-DP1R_PRIO_B=3", "-DP1R_PRIO_A=1"],
 }
 if os.environ.get("P1R_EXTRA"):       # "name:-Dflag,-Dflag;name2:..."
@@ -38,7 +43,16 @@ def build(only=None):
         if only and name not in only:
             continue
         out = os.path.join(DEV, f"libp1r_{name}.so")
-        subprocess.run(base + ["-shared", "-o", out, *flags, os.path.join(csrc, "sn_phase1r.hip")], check=True)
+        src = os.path.join(csrc, "sn_phase1r.hip")
+        if any("P1R_NOCONF" in f for f in flags):
+            # the conflict-free (wrong-result) addresses are not part of the shipped source: tools/p1r_noconf.patch on a copy beside it
+            src = os.path.join(csrc, "_p1r_noconf.hip")
+            subprocess.run(["patch", "-s", "-o", src, os.path.join(csrc, "sn_phase1r.hip"), os.path.join(ROOT, "tools", "p1r_noconf.patch")], check=True)
+        try:
+            subprocess.run(base + ["-shared", "-o", out, *flags, src], check=True)
+        finally:
+            if src.endswith("_p1r_noconf.hip"):
+                os.remove(src)
         print("built", out, flush=True)
 
 
@@ -57,6 +71,8 @@ def time_all(names):
         for (T, h, w) in sizes:
             xd = torch.randn(T, h, w, Cc, device=dev).to(torch.bfloat16)
             hwb = torch.randn(T, h, w, Cc // 2, device=dev).to(torch.bfloat16)
+            if os.environ.get("P1R_DATA") == "zero":      # launch time against operand data: all-zero activations (power-limited clocks, profiles/r06_p1r_lds_*)
+                xd.zero_(); hwb.zero_()
             g2 = torch.empty((T, h, w, Cc), dtype=torch.bfloat16, device=dev)
             for name in names:
                 path = os.path.join(DEV, f"libp1r_{name}.so")
