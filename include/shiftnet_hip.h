@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SN_ABI_VERSION 16     /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
+#define SN_ABI_VERSION 17     /* bump on ANY change of a struct, signature or operand encoding (shiftnet_amd/lib.py checks it) */
 
 /* element types of NCHW tensors exchanged with the PyTorch side */
 #define SN_F32 0
@@ -258,6 +258,10 @@ typedef struct sn_se_fold {
  *   pass 1, g1_sums = 1: LayerNorm -> 1x1 -> dw3x3 -> gate only; pool receives the partial channel sums of g1 (finish them with sn_ca_mlp, or pass
  *           the inner CALayer2's weights as `se`: se->ca is then that layer's scale); g2 is not touched (may be NULL);
  *   pass 2, g1_scale = that scale [T][C] f32: the whole phase 1 with g1 multiplied by it before the RepConv.
+ *   g1_store (optional, both passes): a scratch buffer of the size sn_phase1_g1_store_bytes gives for (T, h, w, C).  Pass 1 then also writes every g1 row it
+ *           computes (fp16, unscaled, in the kernel's own strip / ring order: opaque), and pass 2 reads those rows back, scales them and runs only the
+ *           RepConv -> 1x1 -> gate half: the stagers' LayerNorm and the first 1x1 + 3x3 run once per block instead of twice.  Bit-identical to the
+ *           two passes without a store.  Both passes must see the same buffer, frame range and geometry.
  * NULL / zeros: the deblur models (no inner CALayer2).
  * team: 0 = the library chooses how many workgroups walk consecutive frames of the same rows in lock step (1, 2, 4 or 8: csrc/sn_phase1r.hip,
  * P1RPlan); a fixed value is for measurements only.  Results do not depend on it beyond the summation order of the pool rows. */
@@ -265,8 +269,10 @@ typedef struct sn_phase1_opts {
     const float* g1_scale;
     int g1_sums;
     int team;
+    void* g1_store;
 } sn_phase1_opts;
 int sn_phase1_pool_blocks(int T, int h, int w);
+int sn_phase1_g1_store_bytes(int T, int h, int w, int C, long long* bytes);
 int sn_gsts_cab2_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se,
                         const sn_phase1_opts* opt, void* stream);
 int sn_cab1_phase1(const sn_unit_src* s, const sn_phase1_weights* wt, void* g2, float* pool, const sn_se_fold* se, const sn_phase1_opts* opt, void* stream);

@@ -77,6 +77,8 @@ struct P1RArgs {
     SeFold se;
     const float* g1_scale;               // denoisers: [T][C] scale of the inner CALayer2 (gshift_denoise1.py:224,257), applied to g1 by the A waves; or NULL
     int g1_sums;                         // 1: only the channel sums of g1 (the A waves' SimpleGate output) are produced: pool / se describe g1, no g2
+    char* g1_store;                      // denoisers, or NULL: the sums pass also writes every g1 row it computes ([frame][strip][image row][P1R g1 row], fp16, unscaled),
+                                         // and the second pass (ICA 3) reads them back instead of running the stagers' LayerNorm and the A waves again
 };
 
 __device__ __forceinline__ f32x4_t mfma16h(const uint4 a, const uint4 b, const f32x4_t c) {
@@ -182,7 +184,10 @@ struct P1RItem {
 // ICA: the denoisers' inner CALayer2 on g1 (sn_phase1_opts).  0: none (deblur models); 1: sums pass (stagers + A waves only, channel sums of g1);
 // 2: g1 times A.g1_scale before the RepConv.  A template parameter: the deblur kernels sit at the 168-register limit of three waves per SIMD.
 // threads of a workgroup: the sums pass of the denoisers (ICA 1) has no B waves -- launching them idle cost the A waves a third of the register file
-template <int C, bool HW, int ICA> constexpr int p1r_threads() { return ICA == 1 ? 64 * (P1RShape<C, HW>::NGP + P1RShape<C, HW>::NSW) : P1RShape<C, HW>::NTHR; }
+// 3: second pass from stored g1 rows (P1RArgs::g1_store): B waves + stagers that load a g1 row per step, scale it and put it into the ring -- no A waves.
+template <int C, bool HW, int ICA> constexpr int p1r_threads() { return (ICA == 1 || ICA == 3) ? 64 * (P1RShape<C, HW>::NGP + P1RShape<C, HW>::NSW) : P1RShape<C, HW>::NTHR; }
+// bytes of a stored g1 row of one strip: [wave][group][column mod 4][16 lanes] x 16 B -- the ring row without its pad columns
+template <int C> constexpr int p1r_g1_row_bytes() { return (C / 16) * 8 * 256; }
 
 template <int C, bool HW, int ICA>
 __global__ __launch_bounds__((p1r_threads<C, HW, ICA>())) void cab_phase1r_kernel(const P1RArgs A_) {
@@ -245,6 +250,7 @@ __global__ __launch_bounds__((p1r_threads<C, HW, ICA>())) void cab_phase1r_kerne
     // out so that every SIMD gets one A wave (VALU-heavy), one B wave (MFMA-heavy) and one of {A4, B4, S0, S1} (C = 80) / one stager (C = 64)
     int role, q;                                                              // 0: A, 1: B, 2: S
     if (ICA == 1) { role = wv < NGP ? 0 : 2; q = wv < NGP ? wv : wv - NGP; }
+    else if (ICA == 3) { role = wv < NGP ? 1 : 2; q = wv < NGP ? wv : wv - NGP; }
     else if (wv < 4) { role = 0; q = wv; }
     else if (wv < 8) { role = 1; q = wv - 4; }
     else if (wv - 8 < 2 * (NGP - 4)) { role = (wv - 8) & 1; q = 4 + ((wv - 8) >> 1); }
@@ -254,7 +260,89 @@ __global__ __launch_bounds__((p1r_threads<C, HW, ICA>())) void cab_phase1r_kerne
     for (int e = tid; e < SH::LDS / 16; e += NTHR) ((uint4*)smem)[e] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
 
-    if (role == 2) {
+    if (role == 2 && ICA == 3) {
+        // ============================== S, second pass of the denoisers from stored g1 rows: load, scale, ring; g2 rows out ==============================
+        __builtin_amdgcn_s_setprio(P1R_PRIO_S);
+        constexpr int NSTH = 64 * SH::NSW, DROW = p1r_g1_row_bytes<C>(), NPG = DROW / 16 / NSTH;      // 16-byte pieces per lane and row: 2 (C = 64), 5 (C = 80)
+        static_assert(NPG * NSTH * 16 == DROW, "whole pieces");
+        const int stid = q * 64 + lane;
+        constexpr int NPO = C / 8, NIT = (SH::VWMAX * NPO + NSTH - 1) / NSTH;
+#pragma unroll 1
+        for (int u = u0; u < u1; ++u) {
+            Ap = p1r_fresh(Ap);
+            P1RItem I;
+            if (!item(u, I)) continue;
+            const int t = I.t, Y0 = I.Y0, Y1 = I.Y1, seg = Y1 - Y0;
+            const int NS = (seg + SH::WARM + 1) & ~1;
+            // piece e of a row = plane e / 16 (wave, group, column mod 4), lane position e % 16: the 8 channels of group e / 64
+            h2_t cm[NPG][4];
+            int gl[NPG];
+#pragma unroll
+            for (int k = 0; k < NPG; ++k) {
+                const int e = stid + NSTH * k, plane = e >> 4, gi = plane >> 2;
+                gl[k] = plane * GPL + ((e & 15) + 1) * 16;
+                const float4 c0 = *(const float4*)(A.g1_scale + (size_t)t * C + 8 * gi), c1 = *(const float4*)(A.g1_scale + (size_t)t * C + 8 * gi + 4);
+                cm[k][0] = (h2_t){(_Float16)c0.x, (_Float16)c0.y}; cm[k][1] = (h2_t){(_Float16)c0.z, (_Float16)c0.w};
+                cm[k][2] = (h2_t){(_Float16)c1.x, (_Float16)c1.y}; cm[k][3] = (h2_t){(_Float16)c1.z, (_Float16)c1.w};
+            }
+            const char* const drow = A.g1_store + ((size_t)t * A.P.nsx + I.s) * (size_t)h * DROW + stid * 16;
+            uint4 XA[NPG], XB[NPG];
+            auto issue_row = [&](int y, uint4* X) {
+                const int yc = y < 0 ? 0 : (y < h ? y : h - 1);
+#pragma unroll
+                for (int k = 0; k < NPG; ++k) X[k] = *(const uint4*)(drow + (size_t)yc * DROW + k * NSTH * 16);
+            };
+            auto stage_row = [&](int slot, const uint4* X, int y) {           // g1 row y times the inner CALayer2's scale -> ring row `slot` (zero outside the image)
+                const uint32_t m = (y >= 0 && y < h) ? 0xffffffffu : 0u;
+                char* gs = lds_g + slot * GROW;
+#pragma unroll
+                for (int k = 0; k < NPG; ++k) {
+                    uint4 o;
+                    o.x = as_u(as_h2(X[k].x) * cm[k][0]) & m; o.y = as_u(as_h2(X[k].y) * cm[k][1]) & m;
+                    o.z = as_u(as_h2(X[k].z) * cm[k][2]) & m; o.w = as_u(as_h2(X[k].w) * cm[k][3]) & m;
+                    *(uint4*)(gs + gl[k]) = o;
+                }
+            };
+            int so_l[NIT], so_g[NIT];
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int e = stid + NSTH * k, px = e / NPO, pc = e - px * NPO, rc = I.olo + px;
+                so_l[k] = ((rc & 3) * 16 + (rc >> 2)) * PSO + pc * 16;
+                so_g[k] = rc < I.ohi ? (I.xo + rc) * C + pc * 8 : -1;
+                if (so_g[k] < 0) so_l[k] = 0;
+            }
+            auto store_row = [&](int j) {
+                const int yo = Y0 - 10 + j;
+                const char* os = lds_o + ((j - 1) & 1) * OSLOT;
+                bf16_t* const g2row = A.g2 + ((size_t)t * h + yo) * w * C;
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const uint4 v = *(const uint4*)(os + so_l[k]);
+                    if (so_g[k] >= 0) *(uint4*)(g2row + so_g[k]) = v;
+                }
+            };
+            issue_row(Y0 - 5, XB);
+            issue_row(Y0 - 4, XA);
+            __syncthreads();
+            int gslot = 0;
+            // step j: g1 row Y0 - 5 + j (loaded two steps ago) -> ring row j mod 6 (what the A waves of the one-kernel pass write in step j), refill, store a g2 row
+            auto step = [&](const int j, uint4* X) {
+                if (j <= seg + 6) stage_row(gslot, X, Y0 - 5 + j);
+                issue_row(Y0 - 3 + j, X);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j >= 10 && j <= seg + 9) store_row(j);
+                gslot = gslot == SH::GRING - 1 ? 0 : gslot + 1;
+                __syncthreads();
+            };
+#pragma unroll 1
+            for (int j = 0; j < NS; j += 2) {
+                step(j, XB);
+                step(j + 1, XA);
+            }
+            Ap = p1r_fresh(Ap);
+            finish(u);
+        }
+    } else if (ICA != 3 && role == 2) {
         // =================================================== S: stagers ===================================================
         __builtin_amdgcn_s_setprio(P1R_PRIO_S);
         constexpr int LPP = SH::NSW, NSTH = 64 * SH::NSW;                     // lanes per region pixel; stager threads
@@ -378,7 +466,7 @@ __global__ __launch_bounds__((p1r_threads<C, HW, ICA>())) void cab_phase1r_kerne
             Ap = p1r_fresh(Ap);
             finish(u);
         }
-    } else if (role == 0) {
+    } else if (ICA != 3 && role == 0) {
         // =================================================== A: first 1x1, 3x3, gate ===================================================
         __builtin_amdgcn_s_setprio(P1R_PRIO_A);
         bf16x8_t W1[2][KS1];
@@ -429,6 +517,9 @@ __global__ __launch_bounds__((p1r_threads<C, HW, ICA>())) void cab_phase1r_kerne
                 const float4 cs = *(const float4*)(A.g1_scale + (size_t)t * C + 16 * q + 4 * g);
                 cmul[0] = (h2_t){(_Float16)cs.x, (_Float16)cs.y}; cmul[1] = (h2_t){(_Float16)cs.z, (_Float16)cs.w};
             }
+            // sums pass with a g1 store: this lane's 8 bytes of the strip's row y, N-tile n sit at + y * row bytes + n * 256
+            char* const gdump = (ICA == 1 && A.g1_store) ? A.g1_store + ((size_t)t * A.P.nsx + I.s) * (size_t)h * p1r_g1_row_bytes<C>()
+                                                             + ((2 * q + (g >> 1)) * 4) * 256 + p * 16 + (g & 1) * 8 : nullptr;
             float gsum[4] = {0.f, 0.f, 0.f, 0.f};
             float* const psums = (ICA == 1 && A.pool) ? A.pool + ((size_t)t * nrows + (size_t)I.s * nbh) * C + 16 * q : nullptr;      // + row block * C
             bool ownc[NX];                                                    // lane masks, not registers: this pass sits at the register limit
@@ -472,6 +563,8 @@ __global__ __launch_bounds__((p1r_threads<C, HW, ICA>())) void cab_phase1r_kerne
                         const uint32_t m = (rin && colin[n]) ? 0xffffffffu : 0u;
                         const h2_t g1a = F[n][0] * F[n][2], g1b = F[n][1] * F[n][3];
                         if constexpr (ICA == 1) {
+                            if (gdump && yg >= Y0 && yg < Y1)                              // every image row of the strip is stored by exactly one walk
+                                *(uint2*)(gdump + (size_t)yg * p1r_g1_row_bytes<C>() + n * 256) = make_uint2(as_u(g1a) & m, as_u(g1b) & m);
                             const bool cnt = yg >= Y0 && yg < Y1 && ownc[n];               // every pixel of the frame is counted by exactly one walk
                             gsum[0] += cnt ? (float)g1a[0] : 0.f; gsum[1] += cnt ? (float)g1a[1] : 0.f;
                             gsum[2] += cnt ? (float)g1b[0] : 0.f; gsum[3] += cnt ? (float)g1b[1] : 0.f;
@@ -532,6 +625,7 @@ __global__ __launch_bounds__((p1r_threads<C, HW, ICA>())) void cab_phase1r_kerne
     } else if constexpr (ICA == 1) {
         // (the sums pass has no B waves)
     } else {
+        // (ICA 3: no wave has role 0; the branch above is dead code there)
         // =================================================== B: RepConv, second 1x1, gate2 ===================================================
         __builtin_amdgcn_s_setprio(P1R_PRIO_B);
         uint4 Wg[2][8];
@@ -758,6 +852,7 @@ int p1r_launch1(P1RArgs& A, hipStream_t st) {
 template <int C, bool HW>
 int p1r_launch(P1RArgs& A, hipStream_t st) {
     if (A.g1_sums) return p1r_launch1<C, HW, 1>(A, st);
+    if (A.g1_scale && A.g1_store) return p1r_launch1<C, HW, 3>(A, st);
     return A.g1_scale ? p1r_launch1<C, HW, 2>(A, st) : p1r_launch1<C, HW, 0>(A, st);
 }
 
@@ -774,6 +869,8 @@ int cab_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt
     A.wfrag1 = (const uint4*)wt->wfrag1; A.w3 = (const uint4*)wt->w3; A.wgrp = (const uint4*)wt->wgrp; A.wfrag2 = (const uint4*)wt->wfrag2;
     A.g2 = (bf16_t*)g2; A.pool = pool;
     A.g1_scale = opt ? opt->g1_scale : nullptr; A.g1_sums = sums ? 1 : 0;
+    A.g1_store = opt ? (char*)opt->g1_store : nullptr;
+    if (A.g1_store && !sums && !A.g1_scale) return SN_EINVAL;               // a g1 store belongs to the two passes of the denoisers
     A.se.ca = nullptr; A.se.bad = nullptr;
     if (se) {
         if (!pool || !se->wa || !se->wb || !se->ticket || !se->ca || se->c != s->C || se->cr < 1 || se->cr > 128) return SN_EINVAL;
@@ -792,6 +889,15 @@ int cab_phase1(const sn_unit_src* s, const void* hw, const sn_phase1_weights* wt
 }  // namespace
 
 extern "C" {
+
+int sn_phase1_g1_store_bytes(int T, int h, int w, int C, long long* bytes) {
+    if (T < 1 || h < 1 || w < 1 || (C != 64 && C != 80) || !bytes) return SN_EINVAL;
+    int o[7];
+    const int rc = sn_p1r_plan(1, h, w, 8, 1, o);                             // the strip count depends on w alone
+    if (rc != SN_OK) return rc;
+    *bytes = (long long)T * o[0] * h * (C == 80 ? p1r_g1_row_bytes<80>() : p1r_g1_row_bytes<64>());
+    return SN_OK;
+}
 
 int sn_phase1_pool_blocks(int T, int h, int w) {
     if (T < 1 || h < 1 || w < 1) return SN_EINVAL;

@@ -328,6 +328,9 @@ class Engine:
     # K0 = CAB2.conv1(spatial_shift2(borrowed half)): "1" the depthwise 3x3 as a banded GEMM on the matrix cores over a channel-planar LDS window
     # (sn_gsts_shiftconv_mfma, round 6); "0" the VALU kernel of rounds 1-5 (nine 2-byte LDS reads + nine v_dot2c per pixel and channel)
     k0_mfma = os.environ.get("SN_K0_MFMA", "1") != "0"
+    # Denoisers (inner CALayer2 on g1): the sums pass of the fused phase 1 stores its g1 rows (fp16, kernel order) and the second pass reads them back
+    # instead of running LayerNorm -> 1x1 -> 3x3 -> gate again (sn_phase1_opts.g1_store; bit-identical).  SN_G1_STORE=0: both passes from the input.
+    g1_store = os.environ.get("SN_G1_STORE", "1") != "0"
     fold_se = True             # fused phase 1: CALayer2's MLP is finished by the frame's last workgroup (sn_se_fold) instead of an sn_ca_mlp launch
     # Phase 1 of CAB2 / CAB1.  "r": the role-split fused kernel (csrc/sn_phase1r.hip, every variant; `a`, g1 = a1 a2 2^-4 and r are fp16 inside it);
     # "0": the two-kernel chain sn_ln_gemm_gate + sn_dw5m_gemm_gate / sn_grp5_gemm_gate (g1 in bf16 through HBM: a product of two activations
@@ -523,7 +526,7 @@ class Engine:
         fused = self._fused_phase1(T)                    # phase 1 in ONE kernel: neither a, g1 nor r leave the CU
         mstencil = not V.grouped_rep                     # chain: depthwise RepConv (C = 64) as a Toeplitz-MFMA 5x5 on a channel-planar g1
         B = bufs if bufs is not None else self.naf_buffers(T, h, w, c, mode)
-        hwb, g2, y, pool2, ca2, ca1, g1, pool1 = (B.get(k) for k in ("hwb", "g2", "y", "pool2", "ca2", "ca1", "g1", "pool1"))
+        hwb, g2, y, pool2, ca2, ca1, g1, pool1, g1s = (B.get(k) for k in ("hwb", "g2", "y", "pool2", "ca2", "ca1", "g1", "pool1", "g1s"))
         nb2 = pool2.shape[1]
         if self._tickets is None and fused and self.fold_se:
             self._tickets = torch.zeros((self.MAX_TICKETS,), dtype=torch.int32, device=self.dev)
@@ -564,12 +567,13 @@ class Engine:
                 if V.denoise:      # inner CALayer2 on g1 (gshift_denoise1.py:224,257): pass 1 = the channel sums of g1 and, by the tail, its scale ca1
                     q1 = P.cas[pre + "ca1"]
                     se1 = L.SeFold(q1["wa"].data_ptr(), q1["wb"].data_ptr(), q1["c"], q1["cr"], self._tickets.data_ptr(), ca1.data_ptr(), bad)
-                    o1 = L.Phase1Opts(None, 1)
+                    g1s_ptr = g1s.data_ptr() if (g1s is not None and self.g1_store) else None
+                    o1 = L.Phase1Opts(None, 1, 0, g1s_ptr)
                     fn1 = "sn_gsts_cab2_phase1" if mode else "sn_cab1_phase1"
                     a1 = (C.byref(src), hw_ptr, wt, None, pool2.data_ptr(), C.byref(se1), C.byref(o1), st) if mode else \
                          (C.byref(src), wt, None, pool2.data_ptr(), C.byref(se1), C.byref(o1), st)
                     self._call(fn1, fn1 + "[g1 sums]", *a1)
-                    opt = C.byref(L.Phase1Opts(ca1.data_ptr(), 0))
+                    opt = C.byref(L.Phase1Opts(ca1.data_ptr(), 0, 0, g1s_ptr))
                 if mode:
                     self._call("sn_gsts_cab2_phase1", "sn_gsts_cab2_phase1", C.byref(src), hw_ptr, wt, g2.data_ptr(), pool2.data_ptr(), sep, opt, st)
                 else:
@@ -611,6 +615,10 @@ class Engine:
             nb2 = lib.sn_phase1_pool_blocks(T, h, w)
             if nb2 < 1:
                 raise L.ShiftNetLibError(f"sn_phase1_pool_blocks failed with code {nb2}")
+            if V.denoise and self.g1_store:
+                nbytes = C.c_longlong(0)
+                L.check(lib.sn_phase1_g1_store_bytes(T, h, w, c, C.byref(nbytes)), "sn_phase1_g1_store_bytes")
+                B["g1s"] = torch.empty((nbytes.value,), dtype=torch.uint8, device=self.dev)
         else:
             B["g1"] = (torch.empty((T, h, c, lib.sn_planar_pitch(w)), dtype=torch.bfloat16, device=self.dev) if mstencil else self._new(T, h, w, c))
             nb2 = lib.sn_dw5m_blocks(h, w) if mstencil else lib.sn_grp5_blocks(h, w)

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libshiftnet_hip.so")
 
 SN_F32, SN_F16, SN_BF16 = 0, 1, 2
 
-ABI_VERSION = 16     # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so from before a struct / signature change fails the check in load()
+ABI_VERSION = 17     # == SN_ABI_VERSION of include/shiftnet_hip.h; a stale .so from before a struct / signature change fails the check in load()
 
 SYMBOLS = [          # include/shiftnet_hip.h, production ABI
     "sn_abi_version", "sn_selftest_mfma", "sn_ingest", "sn_conv2d", "sn_conv_pool_blocks", "sn_upsample2_add", "sn_ca_mlp",
@@ -23,7 +23,7 @@ SYMBOLS = [          # include/shiftnet_hip.h, production ABI
     "sn_dw5m_gemm_gate", "sn_gsts_gather", "sn_temporal_roll", "sn_gsts_shiftconv", "sn_gsts_shiftconv_mfma", "sn_gsts_cab2_phase2", "sn_cab1_phase2",
     "sn_ingest_u8", "sn_egress_blocks", "sn_egress_u8", "sn_ssim_blocks", "sn_ssim_u8",
     "sn32_conv2d", "sn32_gsts_gather", "sn32_layernorm", "sn32_gate", "sn32_gate_sum", "sn32_chan_sum", "sn32_scale_residual", "sn32_ingest", "sn32_cab_ca", "sn32_dw_gate", "sn32_conv1x1_gate2", "sn32_gsts_shiftconv", "sn32_conv_csum_tiles",
-    "sn_ln_gemm_gate", "sn_lngate_blocks", "sn_grp5_gemm_gate", "sn_grp5_blocks", "sn_gsts_cab2_phase1", "sn_cab1_phase1", "sn_phase1_pool_blocks", "sn_p1r_plan", "sn_p1r_strip_begin",
+    "sn_ln_gemm_gate", "sn_lngate_blocks", "sn_grp5_gemm_gate", "sn_grp5_blocks", "sn_gsts_cab2_phase1", "sn_cab1_phase1", "sn_phase1_pool_blocks", "sn_phase1_g1_store_bytes", "sn_p1r_plan", "sn_p1r_strip_begin",
 ]
 
 
@@ -40,7 +40,7 @@ class SeFold(C.Structure):
 class Phase1Opts(C.Structure):
     """sn_phase1_opts: the denoisers' inner CALayer2 (pass 1: g1_sums = 1; pass 2: g1_scale = its scale [T][C] f32); team: 0 = the library's
     choice of how many workgroups walk consecutive frames in lock step (measurement knob)."""
-    _fields_ = [("g1_scale", C.c_void_p), ("g1_sums", C.c_int), ("team", C.c_int)]
+    _fields_ = [("g1_scale", C.c_void_p), ("g1_sums", C.c_int), ("team", C.c_int), ("g1_store", C.c_void_p)]
 
 
 def cab_phase1(lib, src: "UnitSrc", hw_ptr, wt: "Phase1Weights", g2_ptr, pool_ptr, stream, se: "SeFold" = None, opt: "Phase1Opts" = None) -> int:
@@ -138,6 +138,7 @@ def load() -> C.CDLL:
     lib.sn_grp5_gemm_gate.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.sn_grp5_blocks.argtypes = [ci, ci]
     lib.sn_phase1_pool_blocks.argtypes = [ci, ci, ci]
+    lib.sn_phase1_g1_store_bytes.argtypes = [ci, ci, ci, ci, C.POINTER(C.c_longlong)]
     lib.sn_p1r_plan.argtypes = [ci, ci, ci, ci, ci, C.POINTER(ci * 7)]
     lib.sn_p1r_strip_begin.argtypes = [C.POINTER(ci * 7), ci, ci]
     lib.sn_gsts_cab2_phase1.argtypes = [C.POINTER(UnitSrc), vp, C.POINTER(Phase1Weights), vp, vp, C.POINTER(SeFold), C.POINTER(Phase1Opts), vp]

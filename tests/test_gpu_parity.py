@@ -1251,3 +1251,22 @@ def test_cab_phase1_fused_kernel_denoisers_two_passes(T, h, w, name, engines):
         s2 = pool.sum(1).cpu()
         r2 = ref.sum((2, 3))
         assert (s2 - r2).abs().max().item() <= 1e-2 * max(1.0, r2.abs().max().item())
+        # the same two passes with a g1 store (sn_phase1_opts.g1_store): pass 1 writes its g1 rows, pass 2 reads them back instead of recomputing
+        # them -- same sums, same scale, bit-identical g2 and pool rows
+        nbv = ctypes.c_longlong(0)
+        L.check(eng.lib.sn_phase1_g1_store_bytes(T, h, w, C, ctypes.byref(nbv)), "sn_phase1_g1_store_bytes")
+        nb = nbv.value
+        assert nb > 0
+        store = torch.full((nb // 2,), float("nan"), dtype=torch.float16, device=DEV)       # NaN: a row pass 2 reads but pass 1 did not write would show
+        pool_b = torch.full((T, nblk, C), float("nan"), dtype=torch.float32, device=DEV)
+        ca1_b = torch.full((T, C), float("nan"), dtype=torch.float32, device=DEV)
+        se1_b = L.SeFold(q1["wa"].data_ptr(), q1["wb"].data_ptr(), q1["c"], q1["cr"], tickets.data_ptr(), ca1_b.data_ptr())
+        L.check(L.cab_phase1(eng.lib, src, hp, p1["desc"], None, pool_b.data_ptr(), st, se1_b, L.Phase1Opts(None, 1, 0, store.data_ptr())), "phase 1, g1 sums + store")
+        torch.cuda.synchronize()
+        assert torch.equal(ca1_b, ca1), (name, mode)
+        g2_b = torch.full((T, h, w, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+        L.check(L.cab_phase1(eng.lib, src, hp, p1["desc"], g2_b.data_ptr(), pool_b.data_ptr(), st, None, L.Phase1Opts(ca1_b.data_ptr(), 0, 0, store.data_ptr())),
+                "phase 1, pass 2 from the g1 store")
+        torch.cuda.synchronize()
+        assert torch.equal(g2_b.view(torch.int16), g2.view(torch.int16)), (name, mode, (g2_b.float() - g2.float()).abs().max().item())
+        assert torch.equal(pool_b, pool), (name, mode)
