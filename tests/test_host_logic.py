@@ -74,6 +74,22 @@ def _p1r_walks(plan, nfr, h, w, lib):
     return out
 
 
+def test_g1_store_size_is_strips_times_rows_times_ring_row():
+    """sn_phase1_g1_store_bytes (host only): the scratch of the denoisers' two passes holds one kernel-order g1 row (C / 16 waves x 2 groups x 4 planes
+    x 256 B = 128 C bytes: 64 region columns of fp16) per (frame, column strip, image row); bad arguments are refused."""
+    from shiftnet_amd import lib as L
+    lib = L.load()
+    n = ctypes.c_longlong(-1)
+    for (T, h, w, C) in ((2, 10, 70, 64), (5, 270, 480, 80), (1, 1, 1, 80), (3, 136, 224, 64)):
+        o = (ctypes.c_int * 7)()
+        assert lib.sn_p1r_plan(1, h, w, 8, 1, o) == 0
+        assert lib.sn_phase1_g1_store_bytes(T, h, w, C, ctypes.byref(n)) == 0
+        assert n.value == T * o[0] * h * 128 * C, (T, h, w, C, n.value, o[0])
+    assert lib.sn_phase1_g1_store_bytes(1, 8, 8, 48, ctypes.byref(n)) == -22
+    assert lib.sn_phase1_g1_store_bytes(0, 8, 8, 64, ctypes.byref(n)) == -22
+    assert lib.sn_phase1_g1_store_bytes(1, 8, 8, 64, None) == -22
+
+
 @pytest.mark.parametrize("ncu", [256, 304, 64, 8])
 def test_phase1_work_plan_covers_every_row_once(ncu):
     """sn_p1r_plan (the launch's own decomposition, csrc/sn_phase1r.hip): for the level sizes of every BASELINE config, ragged and tiny maps and
